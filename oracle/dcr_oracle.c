@@ -1,0 +1,298 @@
+/*
+ * CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the reference's Balanced Forman curvature and the
+ * pieces of the SDRF loop that are worth timing on a CPU.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (discrete-curvature-rewiring_amd/) never does.
+ *
+ * Parity pin: checked bit-for-bit (tests/test_oracle_golden.py) against
+ * fixtures written by running the reference itself (tools/make_golden.py).
+ *
+ * Restated from (file:line into the reference):
+ *   bfc_edge            curvature/bfc_naive.py:7-40
+ *   classical           curvature/classical_curvatures.py:14-28
+ *   candidates          rewiring/sdrf_no_cuda.py:29-37
+ *   improvements        rewiring/sdrf_no_cuda.py:41-46  (literally: add the
+ *                       edge, recompute, subtract, remove the edge)
+ *   graph container     networkx.Graph as used at sdrf_no_cuda.py:20,27,51,
+ *                       59-63,68: insertion-ordered adjacency, append on add,
+ *                       in-place delete, G.edges enumeration by (node, position)
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    int32_t *nbr;
+    int32_t deg, cap;
+} row_t;
+
+typedef struct dcro_graph {
+    int64_t n;
+    row_t *rows;
+} dcro_graph;
+
+typedef struct {
+    uint32_t *m1, *m2; /* stamp arrays: m1[w]==stamp <=> w in N(v1) */
+    uint32_t stamp;
+} scratch_t;
+
+enum { CURV_BFC = 0, CURV_1D = 1, CURV_AUGMENTED = 2, CURV_HAANTJES = 3 };
+
+static int row_find(const row_t *r, int32_t v) {
+    for (int32_t i = 0; i < r->deg; ++i)
+        if (r->nbr[i] == v) return i;
+    return -1;
+}
+
+static int row_push(row_t *r, int32_t v) {
+    if (r->deg == r->cap) {
+        int32_t nc = r->cap ? r->cap * 2 : 4;
+        int32_t *p = (int32_t *)realloc(r->nbr, (size_t)nc * sizeof(int32_t));
+        if (!p) return -1;
+        r->nbr = p;
+        r->cap = nc;
+    }
+    r->nbr[r->deg++] = v;
+    return 0;
+}
+
+static void row_erase(row_t *r, int32_t v) {
+    int i = row_find(r, v);
+    if (i < 0) return;
+    memmove(r->nbr + i, r->nbr + i + 1, (size_t)(r->deg - i - 1) * sizeof(int32_t));
+    r->deg--;
+}
+
+int dcro_has_edge(const dcro_graph *g, int32_t u, int32_t v) {
+    const row_t *a = &g->rows[u], *b = &g->rows[v];
+    return (a->deg <= b->deg ? row_find(a, v) : row_find(b, u)) >= 0;
+}
+
+int dcro_add_edge(dcro_graph *g, int32_t u, int32_t v) {
+    if (u == v || u < 0 || v < 0 || u >= g->n || v >= g->n) return -1;
+    if (dcro_has_edge(g, u, v)) return 0; /* networkx: position unchanged */
+    if (row_push(&g->rows[u], v) || row_push(&g->rows[v], u)) return -2;
+    return 0;
+}
+
+int dcro_remove_edge(dcro_graph *g, int32_t u, int32_t v) {
+    if (!dcro_has_edge(g, u, v)) return -1;
+    row_erase(&g->rows[u], v);
+    row_erase(&g->rows[v], u);
+    return 0;
+}
+
+int32_t dcro_degree(const dcro_graph *g, int32_t u) { return g->rows[u].deg; }
+
+/* to_networkx(to_undirected=True): walk edge_index in order, keep v <= u. */
+int dcro_graph_create(int64_t n, int64_t m, const int64_t *src, const int64_t *dst, dcro_graph **out) {
+    dcro_graph *g = (dcro_graph *)calloc(1, sizeof(*g));
+    if (!g) return -2;
+    g->n = n;
+    g->rows = (row_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(row_t));
+    if (!g->rows) { free(g); return -2; }
+    /* Inserting with a linear has_edge scan is O(d) per edge; inputs are coalesced
+       in practice so use a per-row "last inserted" shortcut only for speed, never
+       for semantics: duplicates are still detected by the scan. */
+    for (int64_t e = 0; e < m; ++e) {
+        int64_t u = src[e], v = dst[e];
+        if (v > u) continue;
+        if (u == v || u < 0 || v < 0 || u >= n) { *out = g; return -1; }
+        int rc = dcro_add_edge(g, (int32_t)u, (int32_t)v);
+        if (rc) { *out = g; return rc; }
+    }
+    *out = g;
+    return 0;
+}
+
+void dcro_graph_destroy(dcro_graph *g) {
+    if (!g) return;
+    for (int64_t i = 0; i < g->n; ++i) free(g->rows[i].nbr);
+    free(g->rows);
+    free(g);
+}
+
+int64_t dcro_num_edges(const dcro_graph *g) {
+    int64_t s = 0;
+    for (int64_t i = 0; i < g->n; ++i) s += g->rows[i].deg;
+    return s / 2;
+}
+
+/* from_networkx: for u in node order, v in adj[u] order. out is [2][M]. */
+int dcro_export_edge_index(const dcro_graph *g, int64_t *out) {
+    int64_t M = 2 * dcro_num_edges(g), p = 0;
+    for (int64_t u = 0; u < g->n; ++u)
+        for (int32_t i = 0; i < g->rows[u].deg; ++i) {
+            out[p] = u;
+            out[M + p] = g->rows[u].nbr[i];
+            ++p;
+        }
+    return 0;
+}
+
+/* G.edges order: (u, v) for u in node order, v in adj[u] order, v not yet an outer node. */
+int dcro_edges(const dcro_graph *g, int32_t *eu, int32_t *ev) {
+    int64_t p = 0;
+    for (int64_t u = 0; u < g->n; ++u)
+        for (int32_t i = 0; i < g->rows[u].deg; ++i) {
+            int32_t v = g->rows[u].nbr[i];
+            if (v > u) { eu[p] = (int32_t)u; ev[p] = v; ++p; }
+        }
+    return 0;
+}
+
+static scratch_t *scratch_new(int64_t n) {
+    scratch_t *s = (scratch_t *)calloc(1, sizeof(*s));
+    s->m1 = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    s->m2 = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    s->stamp = 0;
+    return s;
+}
+
+static void scratch_free(scratch_t *s) {
+    free(s->m1);
+    free(s->m2);
+    free(s);
+}
+
+/* bfc_naive.py:31-32 / 39-40: left-to-right float64, no contraction. */
+double dcro_bfc_formula(int64_t d1, int64_t d2, int64_t T, int64_t s1, int64_t s2, int64_t gamma) {
+    int64_t dmax = d1 > d2 ? d1 : d2, dmin = d1 < d2 ? d1 : d2;
+    double r = 2.0 / (double)d1;
+    r = r + 2.0 / (double)d2;
+    r = r - 2.0;
+    r = r + (double)(2 * T) / (double)dmax;
+    r = r + (double)T / (double)dmin;
+    if (s1 == 0 || s2 == 0) return r;
+    double q = 1.0 / (double)gamma;
+    q = q / (double)dmax;
+    q = q * (double)(s1 + s2);
+    return r + q;
+}
+
+static void bfc_ingredients(const dcro_graph *g, int32_t v1, int32_t v2, scratch_t *s, int64_t out[6]) {
+    const row_t *r1 = &g->rows[v1], *r2 = &g->rows[v2];
+    uint32_t st = ++s->stamp;
+    for (int32_t i = 0; i < r1->deg; ++i) s->m1[r1->nbr[i]] = st; /* S1_1, bfc_naive.py:22 */
+    for (int32_t i = 0; i < r2->deg; ++i) s->m2[r2->nbr[i]] = st; /* S1_2, :23 */
+    int64_t T = 0;
+    for (int32_t i = 0; i < r1->deg; ++i) T += (s->m2[r1->nbr[i]] == st); /* :25 */
+    int64_t n1 = 0, n2 = 0, gamma = 0;
+    /* :26-27  k in S1-S2, k != v2, (N(k) & S2) - (S1 | {v1}) non-empty.
+       :36     |N(k) & (S2 - S1)| - 1   (v1 is always in that set, hence the -1) */
+    for (int32_t i = 0; i < r1->deg; ++i) {
+        int32_t k = r1->nbr[i];
+        if (s->m2[k] == st || k == v2) continue;
+        const row_t *rk = &g->rows[k];
+        int64_t c = 0;
+        for (int32_t j = 0; j < rk->deg; ++j) {
+            int32_t w = rk->nbr[j];
+            c += (s->m2[w] == st && s->m1[w] != st && w != v1);
+        }
+        if (c > 0) { ++n1; if (c > gamma) gamma = c; }
+    }
+    /* :28-29, :37 symmetric */
+    for (int32_t i = 0; i < r2->deg; ++i) {
+        int32_t k = r2->nbr[i];
+        if (s->m1[k] == st || k == v1) continue;
+        const row_t *rk = &g->rows[k];
+        int64_t c = 0;
+        for (int32_t j = 0; j < rk->deg; ++j) {
+            int32_t w = rk->nbr[j];
+            c += (s->m1[w] == st && s->m2[w] != st && w != v2);
+        }
+        if (c > 0) { ++n2; if (c > gamma) gamma = c; }
+    }
+    out[0] = r1->deg; out[1] = r2->deg; out[2] = T; out[3] = n1; out[4] = n2; out[5] = gamma;
+}
+
+static double curv_edge(const dcro_graph *g, int32_t v1, int32_t v2, int ct, scratch_t *s) {
+    int64_t d1 = g->rows[v1].deg, d2 = g->rows[v2].deg;
+    if (ct == CURV_1D) return (double)(4 - d1 - d2);
+    if (ct == CURV_BFC) {
+        if ((d1 < d2 ? d1 : d2) == 1) return 0.0; /* bfc_naive.py:18-19 */
+        int64_t q[6];
+        bfc_ingredients(g, v1, v2, s, q);
+        return dcro_bfc_formula(q[0], q[1], q[2], q[3], q[4], q[5]);
+    }
+    /* triangles, classical_curvatures.py:17-27 */
+    const row_t *r1 = &g->rows[v1], *r2 = &g->rows[v2];
+    uint32_t st = ++s->stamp;
+    for (int32_t i = 0; i < r2->deg; ++i) s->m2[r2->nbr[i]] = st;
+    int64_t T = 0;
+    for (int32_t i = 0; i < r1->deg; ++i) T += (s->m2[r1->nbr[i]] == st);
+    if (ct == CURV_AUGMENTED) return (double)(4 - d1 - d2 + 3 * T);
+    return (double)T;
+}
+
+int dcro_bfc_ingredients(const dcro_graph *g, int32_t v1, int32_t v2, int64_t *out6) {
+    scratch_t *s = scratch_new(g->n);
+    bfc_ingredients(g, v1, v2, s, out6);
+    scratch_free(s);
+    return 0;
+}
+
+int dcro_curv_edge(const dcro_graph *g, int32_t u, int32_t v, int ct, double *out) {
+    scratch_t *s = scratch_new(g->n);
+    *out = curv_edge(g, u, v, ct, s);
+    scratch_free(s);
+    return 0;
+}
+
+/* Curvature of the listed edges (any subset, any order). */
+int dcro_curv_edges(const dcro_graph *g, int ct, int nthreads, int64_t ne, const int32_t *eu, const int32_t *ev,
+                    double *out) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        scratch_t *s = scratch_new(g->n);
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t e = 0; e < ne; ++e) out[e] = curv_edge(g, eu[e], ev[e], ct, s);
+        scratch_free(s);
+    }
+    return 0;
+}
+
+/* sdrf_no_cuda.py:29-37. Returns count through n_out; fills up to cap. */
+int dcro_candidates(const dcro_graph *g, int32_t x, int32_t y, int64_t cap, int32_t *ci, int32_t *cj,
+                    int64_t *n_out) {
+    const row_t *rx = &g->rows[x], *ry = &g->rows[y];
+    int64_t n = 0;
+    for (int32_t a = 0; a <= rx->deg; ++a) {
+        int32_t i = a < rx->deg ? rx->nbr[a] : x;
+        for (int32_t b = 0; b <= ry->deg; ++b) {
+            int32_t j = b < ry->deg ? ry->nbr[b] : y;
+            if (i != j && !dcro_has_edge(g, i, j)) {
+                if (n < cap) {
+                    ci[n] = i < j ? i : j; /* sorted((i, j)) */
+                    cj[n] = i < j ? j : i;
+                }
+                ++n;
+            }
+        }
+    }
+    *n_out = n;
+    return 0;
+}
+
+/* sdrf_no_cuda.py:41-46, literally. The graph is restored on return. */
+int dcro_improvements(dcro_graph *g, int32_t x, int32_t y, int ct, int64_t n, const int32_t *ci, const int32_t *cj,
+                      double *out) {
+    scratch_t *s = scratch_new(g->n);
+    for (int64_t c = 0; c < n; ++c) {
+        double before = curv_edge(g, x, y, ct, s);
+        dcro_add_edge(g, ci[c], cj[c]);
+        double after = curv_edge(g, x, y, ct, s);
+        out[c] = after - before;
+        dcro_remove_edge(g, ci[c], cj[c]);
+    }
+    scratch_free(s);
+    return 0;
+}

@@ -1,0 +1,108 @@
+"""Pin the CPU oracle (oracle/) to the reference's own outputs.
+
+tests/golden/*.json were written by tools/make_golden.py, which runs the
+reference's bfc_naive.py / classical_curvatures.py / sdrf_no_cuda.py.  Every
+comparison here is bit-exact (float64 compared through float.hex / ==).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle, sdrf_oracle
+
+
+def fh(s):
+    return float.fromhex(s)
+
+
+def test_formula_vectors_python_and_c():
+    rows = load_golden('formula_vectors.json')['rows']
+    for d1, d2, T, s1, s2, gamma, val in rows:
+        want = fh(val)
+        assert sdrf_oracle.bfc_formula(d1, d2, T, s1, s2, gamma) == want
+        assert c_oracle.bfc_formula(d1, d2, T, s1, s2, gamma) == want
+
+
+def test_kat():
+    for k in load_golden('kat_curvature.json')['kat']:
+        ei = np.array(k['edge_index'])
+        G = sdrf_oracle.OGraph.from_edge_index(ei, k['num_nodes'])
+        assert float(sdrf_oracle.bfc_edge(G, k['u'], k['v'])) == fh(k['bfc'])
+        C = c_oracle.CGraph(ei, k['num_nodes'])
+        assert C.curv_edge(k['u'], k['v']) == fh(k['bfc'])
+        assert C.curv_edge(k['v'], k['u']) == fh(k['bfc'])
+
+
+@pytest.mark.parametrize('fname', ['fullpass_small.json', 'fullpass_sampled.json'])
+def test_fullpass(fname):
+    for name, rec in load_golden(fname)['graphs'].items():
+        ei = np.array(rec['edge_index'])
+        n = rec['num_nodes']
+        edges = rec['edges']
+        eu = np.array([e[0] for e in edges], dtype=np.int32)
+        ev = np.array([e[1] for e in edges], dtype=np.int32)
+        C = c_oracle.CGraph(ei, n)
+        if not rec['sampled']:
+            cu, cv = C.edges()
+            assert cu.tolist() == eu.tolist() and cv.tolist() == ev.tolist(), name
+        want = np.array([fh(h) for h in rec['bfc']])
+        assert np.array_equal(C.curv_edges(eu, ev, 'bfc', nthreads=2), want), name
+        assert np.array_equal(C.curv_edges(ev, eu, 'bfc'), np.array([fh(h) for h in rec['bfc_swapped']])), name
+        for ct in ('1d', 'augmented', 'haantjes'):
+            assert np.array_equal(C.curv_edges(eu, ev, ct), np.array(rec[ct], dtype=np.float64)), (name, ct)
+        if len(edges) <= 600:
+            G = sdrf_oracle.OGraph.from_edge_index(ei, n)
+            if not rec['sampled']:
+                assert [list(e) for e in G.edges()] == edges
+            got = [float(sdrf_oracle.bfc_edge(G, u, v)) for u, v in edges]
+            assert got == want.tolist(), name
+
+
+def _check_trace(case, trace, final):
+    ref_iters = case['iterations']
+    assert len(trace) == len(ref_iters)
+    for it, (a, b) in enumerate(zip(trace, ref_iters)):
+        assert a['argmin'] == b['argmin'], it
+        assert a['candidates'] == b['candidates'], it
+        assert [float(v).hex() for v in a['improvements']] == [fh(h).hex() for h in b['improvements']], it
+        assert a['choice'] == b['choice'], it
+        assert a['added'] == b['added'], it
+        assert a['removed'] == b['removed'], it
+    assert final.tolist() == case['final_edge_index']
+
+
+def _cases(fname):
+    return load_golden(fname)['cases']
+
+
+@pytest.mark.parametrize('fname', ['sdrf_traces_small.json', 'sdrf_traces_medium.json'])
+def test_sdrf_traces_c_oracle(fname):
+    for case in _cases(fname):
+        tau = float('inf') if case['tau'] == 'inf' else case['tau']
+        trace = []
+        np.random.seed(case['seed'])
+        if case['error']:
+            with pytest.raises(ValueError):
+                c_oracle.sdrf(np.array(case['edge_index']), case['num_nodes'], case['curv_type'], case['loops'],
+                              case.get('remove_edges', True), case['removal_bound'], tau, trace=trace)
+            continue
+        final = c_oracle.sdrf(np.array(case['edge_index']), case['num_nodes'], case['curv_type'], case['loops'],
+                              case.get('remove_edges', True), case['removal_bound'], tau, trace=trace)
+        _check_trace(case, trace, final)
+
+
+def test_sdrf_traces_python_oracle():
+    for case in _cases('sdrf_traces_small.json'):
+        if case['num_nodes'] > 40:
+            continue
+        tau = float('inf') if case['tau'] == 'inf' else case['tau']
+        trace = []
+        np.random.seed(case['seed'])
+        if case['error']:
+            with pytest.raises(ValueError):
+                sdrf_oracle.sdrf(np.array(case['edge_index']), case['num_nodes'], case['curv_type'], case['loops'],
+                                 case.get('remove_edges', True), case['removal_bound'], tau, trace=trace)
+            continue
+        final = sdrf_oracle.sdrf(np.array(case['edge_index']), case['num_nodes'], case['curv_type'], case['loops'],
+                                 case.get('remove_edges', True), case['removal_bound'], tau, trace=trace)
+        _check_trace(case, trace, final)

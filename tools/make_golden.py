@@ -1,0 +1,422 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by RUNNING THE REFERENCE (build container only).
+
+The reference (``/root/reference``) cannot travel to the GPU box, so its
+outputs are captured here as small data fixtures.  This script imports the
+reference's own ``curvature/bfc_naive.py``, ``curvature/classical_curvatures.py``,
+``utils/softmax.py`` and ``rewiring/sdrf_no_cuda.py`` unmodified and adds
+only harness-side glue:
+
+  1. a stand-in ``torch_geometric.utils`` module exposing ``to_networkx`` /
+     ``from_networkx`` with PyG-2.0.3 semantics (PyG is not installed here);
+  2. ``nx.adj_matrix`` restored to its networkx-2.6.3 behaviour (returns a
+     ``csr_matrix``; networkx>=3 removed it; bfc_naive.py:34 calls it);
+  3. ``compute_curvature_graph/edge`` as seen by ``rewiring.sdrf_no_cuda``
+     re-bound so that ``'bfc'`` dispatches to ``bfc_naive.bfc_edge``
+     (the reference's dispatcher has no CPU BFC branch; BASELINE.json names
+     this composition as the parity target).
+
+Nothing from the reference is written to the fixtures except numbers: inputs
+(edge lists, parameters, seeds) and outputs (curvatures as float64 hex,
+per-iteration traces, final edge_index).
+
+Usage:  python tools/make_golden.py [--only kat|fullpass|sdrf|timing] [--fast]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, os.path.join(REPO, 'discrete-curvature-rewiring_amd'))
+
+import networkx as nx  # noqa: E402
+import scipy.sparse  # noqa: E402
+import torch  # noqa: E402
+
+from dcr.data import Data  # noqa: E402
+from dcr import synthetic  # noqa: E402
+
+
+# ----------------------------------------------------------------------------
+# harness-side glue
+# ----------------------------------------------------------------------------
+class TracingGraph(nx.Graph):
+    """nx.Graph that logs add_edge/remove_edge once ``trace`` is switched on."""
+    trace = None
+
+    def add_edge(self, u, v, **attr):
+        if self.trace is not None:
+            self.trace.append(('add', int(u), int(v)))
+        return super().add_edge(u, v, **attr)
+
+    def remove_edge(self, u, v):
+        if self.trace is not None:
+            self.trace.append(('rm', int(u), int(v)))
+        return super().remove_edge(u, v)
+
+
+def _to_networkx(data, node_attrs=None, edge_attrs=None, to_undirected=False, remove_self_loops=False):
+    """PyG 2.0.3 torch_geometric.utils.to_networkx, restated (graph part only)."""
+    G = TracingGraph() if to_undirected else nx.DiGraph()
+    G.add_nodes_from(range(data.num_nodes))
+    for (u, v) in data.edge_index.t().tolist():
+        if to_undirected and v > u:
+            continue
+        if remove_self_loops and u == v:
+            continue
+        G.add_edge(u, v)
+    return G
+
+
+def _from_networkx(G):
+    """PyG 2.0.3 torch_geometric.utils.from_networkx, restated (edge_index only)."""
+    G = nx.convert_node_labels_to_integers(G)
+    G = G.to_directed() if not nx.is_directed(G) else G
+    edges = list(G.edges)
+    ei = torch.tensor(edges, dtype=torch.long).t().contiguous().view(2, -1)
+    return Data(edge_index=ei, num_nodes=G.number_of_nodes())
+
+
+def install_shims():
+    tg = types.ModuleType('torch_geometric')
+    tgu = types.ModuleType('torch_geometric.utils')
+    tgu.to_networkx = _to_networkx
+    tgu.from_networkx = _from_networkx
+    tg.utils = tgu
+    sys.modules['torch_geometric'] = tg
+    sys.modules['torch_geometric.utils'] = tgu
+    nx.adj_matrix = lambda G: scipy.sparse.csr_matrix(nx.adjacency_matrix(G))
+    sys.path.insert(0, REF)
+
+
+install_shims()
+import curvature.bfc_naive as ref_bfc  # noqa: E402  (reference)
+import curvature.classical_curvatures as ref_cc  # noqa: E402  (reference)
+import rewiring.sdrf_no_cuda as ref_sdrf  # noqa: E402  (reference)
+import utils.softmax as ref_softmax  # noqa: E402  (reference)
+
+assert ref_bfc.__file__.startswith(REF) and ref_sdrf.__file__.startswith(REF)
+
+
+def _edge(G, e, curv_type):
+    if curv_type == 'bfc':
+        return ref_bfc.bfc_edge(G, e[0], e[1])
+    return ref_cc.compute_curvature_edge(G, e, curv_type)
+
+
+def _graph(G, curv_type):
+    if curv_type == 'bfc':
+        d = {}
+        for (v1, v2) in G.edges():
+            d.setdefault(v1, {})[v2] = ref_bfc.bfc_edge(G, v1, v2)
+        return d
+    return ref_cc.compute_curvature_graph(G, curv_type)
+
+
+def hx(v):
+    return float(v).hex()
+
+
+# ----------------------------------------------------------------------------
+# graphs
+# ----------------------------------------------------------------------------
+def nx_to_edge_index(G):
+    G = nx.convert_node_labels_to_integers(G, ordering='sorted') if not all(
+        isinstance(n, int) for n in G.nodes) else G
+    src = [u for u, v in G.edges()]
+    dst = [v for u, v in G.edges()]
+    return synthetic.coalesced_edge_index(src, dst, G.number_of_nodes()), G.number_of_nodes()
+
+
+def graph_catalog():
+    cat = {}
+    cat['C4'] = nx_to_edge_index(nx.cycle_graph(4))
+    cat['C5'] = nx_to_edge_index(nx.cycle_graph(5))
+    cat['K4'] = nx_to_edge_index(nx.complete_graph(4))
+    cat['K33'] = nx_to_edge_index(nx.complete_bipartite_graph(3, 3))
+    cat['petersen'] = nx_to_edge_index(nx.petersen_graph())
+    cat['P3'] = nx_to_edge_index(nx.path_graph(3))
+    cat['star6'] = nx_to_edge_index(nx.star_graph(5))
+    cat['grid3x3'] = synthetic.grid_graph(3, 3)
+    cat['grid5x5'] = synthetic.grid_graph(5, 5)
+    cat['karate'] = nx_to_edge_index(nx.karate_club_graph())
+    cat['ba200m3'] = synthetic.powerlaw_graph(200, 3, seed=0)
+    cat['ba2000m5'] = synthetic.powerlaw_graph(2000, 5, seed=0)
+    cat['ba2485m2'] = synthetic.powerlaw_graph(2485, 2, seed=0)
+    cat['er60p15'] = synthetic.erdos_renyi_graph(60, 0.15, seed=3)
+    cat['ba300m8'] = synthetic.powerlaw_graph(300, 8, seed=7)
+    return cat
+
+
+def build_nx(ei, n):
+    return _to_networkx(Data(edge_index=torch.from_numpy(ei), num_nodes=n), to_undirected=True)
+
+
+# ----------------------------------------------------------------------------
+# fixture families
+# ----------------------------------------------------------------------------
+def make_fullpass(names, out_name, sample=None):
+    """Per-edge curvature in G.edges order for whole graphs (bfc + classical)."""
+    cat = graph_catalog()
+    out = {'_about': 'reference curvature per undirected edge, G.edges order; float64 hex', 'graphs': {}}
+    for name in names:
+        ei, n = cat[name]
+        G = build_nx(ei, n)
+        edges = [(int(u), int(v)) for u, v in G.edges]
+        if sample is not None and len(edges) > sample:
+            rng = np.random.Generator(np.random.PCG64(99))
+            pick = sorted(rng.choice(len(edges), size=sample, replace=False).tolist())
+            edges = [edges[i] for i in pick]
+        t0 = time.time()
+        rec = {'num_nodes': n, 'edge_index': ei.tolist(), 'edges': edges,
+               'sampled': sample is not None and sample < G.number_of_edges()}
+        rec['bfc'] = [hx(ref_bfc.bfc_edge(G, u, v)) for u, v in edges]
+        rec['bfc_swapped'] = [hx(ref_bfc.bfc_edge(G, v, u)) for u, v in edges]
+        for ct in ('1d', 'augmented', 'haantjes'):
+            rec[ct] = [int(ref_cc.compute_curvature_edge(G, (u, v), ct)) for u, v in edges]
+        out['graphs'][name] = rec
+        print(f'fullpass {name}: n={n} edges={len(edges)} {time.time() - t0:.1f}s', flush=True)
+    with open(os.path.join(GOLDEN, out_name), 'w') as f:
+        json.dump(out, f, separators=(',', ':'))
+
+
+def run_sdrf_traced(ei, n, curv_type, loops, remove_edges, removal_bound, tau, seed):
+    """Run the reference's sdrf_no_cuda verbatim and record what it did."""
+    iters = []
+    cur = {}
+    events = []
+
+    def graph_hook(G, ct):
+        # called once at the top of every iteration (sdrf_no_cuda.py:24)
+        if cur:
+            _close_iter(cur, events, iters)
+        cur.clear()
+        cur['started'] = True
+        events.clear()
+        G.trace = events
+        return _graph(G, ct)
+
+    def edge_hook(G, e, ct):
+        if 'argmin' not in cur:
+            cur['argmin'] = [int(e[0]), int(e[1])]
+        return _edge(G, e, ct)
+
+    def softmax_hook(a, tau=1):
+        cur['improvements'] = [hx(v) for v in np.asarray(a, dtype=np.float64)]
+        return ref_softmax.softmax(a, tau=tau)
+
+    real_choice = np.random.choice
+
+    def choice_hook(a, size=None, replace=True, p=None):
+        r = real_choice(a, size=size, replace=replace, p=p)
+        cur['choice'] = int(r)
+        return r
+
+    ref_sdrf.compute_curvature_graph = graph_hook
+    ref_sdrf.compute_curvature_edge = edge_hook
+    ref_sdrf.softmax = softmax_hook
+    ref_sdrf.tqdm = lambda it: it
+    np.random.choice = choice_hook
+    err = None
+    try:
+        np.random.seed(seed)
+        data = Data(edge_index=torch.from_numpy(ei), num_nodes=n)
+        data.x = torch.zeros(n, 1)
+        out = ref_sdrf.sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau)
+        final = out.edge_index.numpy()
+    except ValueError as ex:  # numpy raises when softmax overflowed to NaN
+        err = f'ValueError: {ex}'
+        final = None
+    finally:
+        np.random.choice = real_choice
+    if cur:
+        _close_iter(cur, events, iters)
+    return iters, final, err
+
+
+def _close_iter(cur, events, iters):
+    ev = list(events)
+    rec = {'argmin': cur.get('argmin')}
+    n_imp = len(cur.get('improvements', []))
+    # 2*n_imp events are the candidate add/remove probes, in candidate order
+    cands = []
+    for q in range(n_imp):
+        a, r = ev[2 * q], ev[2 * q + 1]
+        assert a[0] == 'add' and r[0] == 'rm' and a[1:] == r[1:]
+        cands.append([a[1], a[2]])
+    rest = ev[2 * n_imp:]
+    rec['candidates'] = cands
+    rec['improvements'] = cur.get('improvements', [])
+    rec['choice'] = cur.get('choice')
+    rec['added'] = None
+    rec['removed'] = None
+    for e in rest:
+        if e[0] == 'add':
+            rec['added'] = [e[1], e[2]]
+        else:
+            rec['removed'] = [e[1], e[2]]
+    iters.append(rec)
+
+
+def make_sdrf(cases, out_name):
+    cat = graph_catalog()
+    out = {'_about': 'reference sdrf_no_cuda traces (bfc via bfc_naive.bfc_edge); float64 hex', 'cases': []}
+    for c in cases:
+        ei, n = cat[c['graph']]
+        tau = float('inf') if c['tau'] == 'inf' else c['tau']
+        t0 = time.time()
+        iters, final, err = run_sdrf_traced(ei, n, c['curv_type'], c['loops'], c.get('remove_edges', True),
+                                            c['removal_bound'], tau, c['seed'])
+        rec = dict(c)
+        rec['num_nodes'] = n
+        rec['edge_index'] = ei.tolist()
+        rec['iterations'] = iters
+        rec['error'] = err
+        rec['final_edge_index'] = None if final is None else final.tolist()
+        out['cases'].append(rec)
+        print(f"sdrf {c}: iters={len(iters)} err={err} {time.time() - t0:.1f}s", flush=True)
+    with open(os.path.join(GOLDEN, out_name), 'w') as f:
+        json.dump(out, f, separators=(',', ':'))
+
+
+def make_kat():
+    """Closed-form known answers, SURVEY.md §4 table."""
+    cat = graph_catalog()
+    out = {'_about': 'bfc_naive.bfc_edge known answers; float64 hex', 'kat': []}
+    probes = {
+        'C4': [(0, 1)], 'C5': [(0, 1)], 'K4': [(0, 1)], 'K33': [(0, 3)], 'petersen': [(0, 1)],
+        'P3': [(0, 1)], 'star6': [(0, 1)],
+        'grid3x3': [(0, 3), (0, 1), (1, 4), (1, 2)],
+        'karate': [(0, 1), (0, 2), (0, 3), (0, 4)],
+    }
+    for name, edges in probes.items():
+        ei, n = cat[name]
+        G = build_nx(ei, n)
+        for (u, v) in edges:
+            val = ref_bfc.bfc_edge(G, u, v)
+            out['kat'].append({'graph': name, 'num_nodes': n, 'edge_index': ei.tolist(), 'u': u, 'v': v,
+                               'bfc': hx(val), 'bfc_repr': repr(float(val))})
+            print(f'kat {name} ({u},{v}) = {float(val)!r}')
+    with open(os.path.join(GOLDEN, 'kat_curvature.json'), 'w') as f:
+        json.dump(out, f, separators=(',', ':'))
+
+
+def make_formula_vectors():
+    """Float64 results of the reference's closing expression (bfc_naive.py:31-32,
+    39-40) on integer tuples, to pin the GPU's operation order and division."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    rows = []
+    for _ in range(4000):
+        d1 = int(rng.integers(2, 5000))
+        d2 = int(rng.integers(2, 5000))
+        if rng.random() < 0.3:
+            d1 = int(rng.integers(2, 40))
+            d2 = int(rng.integers(2, 40))
+        dmax, dmin = max(d1, d2), min(d1, d2)
+        T = int(rng.integers(0, dmin))
+        if rng.random() < 0.25:
+            v = 2 / d1 + 2 / d2 - 2 + 2 * T / dmax + T / dmin
+            rows.append([d1, d2, T, 0, 0, 0, hx(v)])
+        else:
+            s1 = int(rng.integers(1, d1 + 1))
+            s2 = int(rng.integers(1, d2 + 1))
+            gamma = np.int64(rng.integers(1, dmin + 1))
+            v = 2 / d1 + 2 / d2 - 2 + 2 * T / dmax + T / dmin + 1 / gamma / dmax * (s1 + s2)
+            rows.append([d1, d2, T, s1, s2, int(gamma), hx(v)])
+    with open(os.path.join(GOLDEN, 'formula_vectors.json'), 'w') as f:
+        json.dump({'_about': 'rows: d1,d2,T,s1,s2,gamma,value(hex); s1=s2=0 -> no 4-cycle branch', 'rows': rows},
+                  f, separators=(',', ':'))
+    print('formula vectors:', len(rows))
+
+
+def make_timing():
+    """Reference-as-is CPU cost at the north-star size:
+    bfc_edge on sampled edges of the identical S100k graph, single core."""
+    ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    G = build_nx(ei, n)
+    edges = list(G.edges)
+    rng = np.random.Generator(np.random.PCG64(7))
+    pick = rng.choice(len(edges), size=40, replace=False).tolist()
+    times = []
+    vals = []
+    for i in pick:
+        u, v = edges[i]
+        t0 = time.perf_counter()
+        val = ref_bfc.bfc_edge(G, u, v)
+        times.append(time.perf_counter() - t0)
+        vals.append([int(u), int(v), hx(val)])
+        print(f'timing edge ({u},{v}) {times[-1]:.3f}s', flush=True)
+    rec = {
+        '_about': 'reference bfc_naive.bfc_edge timed on sampled edges of S100k (powerlaw_graph(100000,10,seed=12345)); '
+                  'single core, build container; extrapolated pass = mean * E',
+        'num_edges': len(edges), 'sampled': len(pick), 'sec_per_edge_mean': float(np.mean(times)),
+        'sec_per_edge_median': float(np.median(times)), 'edges_per_sec': float(1.0 / np.mean(times)),
+        'extrapolated_pass_seconds': float(np.mean(times) * len(edges)),
+        'host': {'cpus': os.cpu_count(), 'python': sys.version.split()[0], 'numpy': np.__version__,
+                 'networkx': nx.__version__, 'scipy': scipy.__version__},
+        'values': vals,
+    }
+    with open(os.path.join(GOLDEN, 'reference_timing_s100k.json'), 'w') as f:
+        json.dump(rec, f, separators=(',', ':'))
+    print(rec['sec_per_edge_mean'], 's/edge')
+
+
+SDRF_CASES_SMALL = [
+    {'graph': 'karate', 'curv_type': 'bfc', 'loops': 10, 'removal_bound': 0.5, 'tau': 'inf', 'seed': 0},
+    {'graph': 'karate', 'curv_type': 'bfc', 'loops': 10, 'removal_bound': 0.5, 'tau': 50, 'seed': 0},
+    {'graph': 'karate', 'curv_type': 'bfc', 'loops': 50, 'removal_bound': 0.95, 'tau': 163, 'seed': 1},
+    {'graph': 'karate', 'curv_type': 'bfc', 'loops': 12, 'removal_bound': 0.5, 'tau': 20, 'seed': 2,
+     'remove_edges': False},
+    {'graph': 'karate', 'curv_type': '1d', 'loops': 5, 'removal_bound': 0.5, 'tau': 50, 'seed': 0},
+    {'graph': 'karate', 'curv_type': 'augmented', 'loops': 5, 'removal_bound': 0.5, 'tau': 50, 'seed': 0},
+    {'graph': 'karate', 'curv_type': 'haantjes', 'loops': 5, 'removal_bound': 0.5, 'tau': 50, 'seed': 0},
+    {'graph': 'karate', 'curv_type': 'augmented', 'loops': 30, 'removal_bound': 0.5, 'tau': 2, 'seed': 1},
+    {'graph': 'grid5x5', 'curv_type': 'bfc', 'loops': 20, 'removal_bound': 0.2, 'tau': 163, 'seed': 0},
+    {'graph': 'petersen', 'curv_type': 'bfc', 'loops': 10, 'removal_bound': 0.5, 'tau': 'inf', 'seed': 0},
+    {'graph': 'K4', 'curv_type': 'bfc', 'loops': 5, 'removal_bound': 5.0, 'tau': 10, 'seed': 0},
+    {'graph': 'K4', 'curv_type': 'bfc', 'loops': 5, 'removal_bound': 0.5, 'tau': 10, 'seed': 0},
+    {'graph': 'er60p15', 'curv_type': 'bfc', 'loops': 25, 'removal_bound': 0.3, 'tau': 100, 'seed': 2},
+    {'graph': 'karate', 'curv_type': 'bfc', 'loops': 6, 'removal_bound': 0.5, 'tau': 5000, 'seed': 0},
+]
+
+SDRF_CASES_MEDIUM = [
+    {'graph': 'ba200m3', 'curv_type': 'bfc', 'loops': 10, 'removal_bound': 0.5, 'tau': 163, 'seed': 0},
+    {'graph': 'ba200m3', 'curv_type': 'bfc', 'loops': 10, 'removal_bound': 0.95, 'tau': 'inf', 'seed': 1},
+    {'graph': 'ba300m8', 'curv_type': 'bfc', 'loops': 6, 'removal_bound': 0.5, 'tau': 163, 'seed': 0},
+    {'graph': 'ba200m3', 'curv_type': 'augmented', 'loops': 40, 'removal_bound': 0.5, 'tau': 3, 'seed': 0},
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    todo = [args.only] if args.only else ['kat', 'formula', 'fullpass', 'sdrf', 'sdrf_medium', 'fullpass_big', 'timing']
+    for what in todo:
+        if what == 'kat':
+            make_kat()
+        elif what == 'formula':
+            make_formula_vectors()
+        elif what == 'fullpass':
+            make_fullpass(['C4', 'C5', 'K4', 'K33', 'petersen', 'P3', 'star6', 'grid3x3', 'grid5x5', 'karate',
+                           'er60p15', 'ba200m3', 'ba300m8'], 'fullpass_small.json')
+        elif what == 'fullpass_big':
+            make_fullpass(['ba2000m5', 'ba2485m2'], 'fullpass_sampled.json', sample=400)
+        elif what == 'sdrf':
+            make_sdrf(SDRF_CASES_SMALL, 'sdrf_traces_small.json')
+        elif what == 'sdrf_medium':
+            make_sdrf(SDRF_CASES_MEDIUM, 'sdrf_traces_medium.json')
+        elif what == 'timing':
+            make_timing()
+
+
+if __name__ == '__main__':
+    main()
