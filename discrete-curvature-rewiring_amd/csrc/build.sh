@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libdcr_hip.so for gfx950 (cross-compiles without a GPU).  No fast-math, no FMA contraction:
+# the float64 closing expression must round exactly like the reference's Python arithmetic.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -Wall -Wno-unused-function"
+OBJS=""
+for f in dcr_graph dcr_bfc dcr_sdrf dcr_gcn; do
+  [ -f $f.hip ] || continue
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ dcr_internal.h -nt $f.o ] || [ ../../include/dcr.h -nt $f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o $f.o &
+  fi
+  OBJS="$OBJS $f.o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libdcr_hip.so $OBJS
+echo "built $(pwd)/libdcr_hip.so"

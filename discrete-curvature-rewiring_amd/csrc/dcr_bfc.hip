@@ -1,0 +1,464 @@
+// Curvature pass of libdcr_hip.so — the hot path.
+//
+// Replaces compute_curvature_graph(G, curv_type) at rewiring/sdrf_no_cuda.py:24, i.e. E calls of
+// bfc_naive.bfc_edge (curvature/bfc_naive.py:7-40) or compute_curvature_edge
+// (curvature/classical_curvatures.py:14-28), with one classify kernel plus one kernel per work bin.
+//
+// Per undirected edge (u,v), a team of threads (one wave for small neighbourhoods, a whole workgroup
+// for hubs):
+//   1. stages N(u) ∪ N(v) ∪ {u,v} as a tagged hash set in LDS (tag bits: "in N(u)", "in N(v)");
+//      T = |N(u) ∩ N(v)| falls out of the second insertion sweep              (bfc_naive.py:22-25)
+//   2. for every k in N(u) \ N(v), k != v: streams row k from HBM (coalesced, one wave per row),
+//      probes each neighbour against the LDS set and counts the lanes that hit "N(v) only" with
+//      ballot + popcount.  count > 0 puts k in sq1, max count is gamma         (bfc_naive.py:26-27,36)
+//   3. same for v's side                                                        (bfc_naive.py:28-29,37)
+//   4. lane 0 evaluates the float64 closing expression in the reference's order (bfc_naive.py:31-40)
+// u and v themselves are stored with both tags, which removes them from every set difference the
+// reference writes out explicitly (k != v2, "- (S1 ∪ {v1})", the "- 1" in gamma).
+#include "dcr_internal.h"
+
+namespace dcr {
+
+constexpr unsigned TAG_U = 1u << 30;
+constexpr unsigned TAG_V = 1u << 31;
+constexpr unsigned KEY_MASK = (1u << 30) - 1u;
+constexpr unsigned EMPTY = 0xFFFFFFFFu;
+
+enum { MODE_BFC = 0, MODE_TRI = 1, MODE_BYTES = 2 };
+
+struct View {
+    const int2 *rowinfo;
+    const int32_t *col;
+    const int32_t *slot_row;
+};
+
+struct WorkLists {
+    int32_t *w[NBINS];
+};
+
+// keys (= du + dv + 2) admitted per bin: load factor <= 1/4 except the last bin (<= 1/2)
+__host__ __device__ constexpr int bin_max_keys(int b) {
+    return b == 0 ? 32 : b == 1 ? 128 : b == 2 ? 512 : b == 3 ? 2048 : 16384;
+}
+
+// bfc_naive.py:31-32 / 39-40, left to right in float64; compiled with -ffp-contract=off
+__device__ __host__ inline double bfc_formula(int d1, int d2, int T, int s1, int s2, int gamma) {
+    int dmax = d1 > d2 ? d1 : d2, dmin = d1 < d2 ? d1 : d2;
+    double r = 2.0 / (double)d1;
+    r = r + 2.0 / (double)d2;
+    r = r - 2.0;
+    r = r + (double)(2 * (int64_t)T) / (double)dmax;
+    r = r + (double)T / (double)dmin;
+    if (s1 == 0 || s2 == 0) return r;
+    double q = 1.0 / (double)gamma;
+    q = q / (double)dmax;
+    q = q * (double)(s1 + s2);
+    return r + q;
+}
+
+template <int SLOTS>
+__device__ inline unsigned hash_slot(unsigned key) {
+    constexpr int BITS = __builtin_ctz(SLOTS);
+    return (key * 0x9E3779B1u) >> (32 - BITS);
+}
+
+template <int SLOTS>
+__device__ inline void table_insert(unsigned *tab, unsigned entry) {
+    unsigned h = hash_slot<SLOTS>(entry & KEY_MASK);
+    while (true) {
+        unsigned old = atomicCAS(&tab[h], EMPTY, entry);
+        if (old == EMPTY) return;
+        h = (h + 1) & (SLOTS - 1);
+    }
+}
+
+// returns the entry holding key, or EMPTY
+template <int SLOTS>
+__device__ inline unsigned table_lookup(const unsigned *tab, unsigned key) {
+    unsigned h = hash_slot<SLOTS>(key);
+    while (true) {
+        unsigned e = tab[h];
+        if (e == EMPTY || (e & KEY_MASK) == key) return e;
+        h = (h + 1) & (SLOTS - 1);
+    }
+}
+
+template <int TEAM>
+__device__ inline void team_sync() {
+    __syncthreads();  // single-wave teams: the compiler lowers this to a wait, no s_barrier
+}
+
+struct Ingredients {
+    int du, dv, T, s1, s2, gamma;
+    double bytes;
+};
+
+// Whole team cooperates; the result is valid in thread 0.
+template <int SLOTS, int TEAM, int MODE>
+__device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsigned *tab, int *red) {
+    constexpr int NW = TEAM / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int2 ru = g.rowinfo[u], rv = g.rowinfo[v];
+    const int32_t *rowu = g.col + ru.x, *rowv = g.col + rv.x;
+
+    for (int i = tid; i < SLOTS; i += TEAM) tab[i] = EMPTY;
+    team_sync<TEAM>();
+    if (tid == 0) {
+        table_insert<SLOTS>(tab, (unsigned)u | TAG_U | TAG_V);
+        table_insert<SLOTS>(tab, (unsigned)v | TAG_U | TAG_V);
+    }
+    for (int i = tid; i < ru.y; i += TEAM) {
+        int k = rowu[i];
+        if (k != v) table_insert<SLOTS>(tab, (unsigned)k | TAG_U);
+    }
+    team_sync<TEAM>();
+    int tcount = 0;
+    for (int i = tid; i < rv.y; i += TEAM) {
+        unsigned k = (unsigned)rowv[i];
+        if ((int)k == u) continue;
+        unsigned h = hash_slot<SLOTS>(k);
+        while (true) {
+            unsigned e = tab[h];
+            if (e == EMPTY) {
+                e = atomicCAS(&tab[h], EMPTY, k | TAG_V);
+                if (e == EMPTY) break;
+            }
+            if ((e & KEY_MASK) == k) {  // already there from N(u): a triangle
+                atomicOr(&tab[h], TAG_V);
+                ++tcount;
+                break;
+            }
+            h = (h + 1) & (SLOTS - 1);
+        }
+    }
+    team_sync<TEAM>();
+
+    // wave-level popcount of the triangle hits, then across waves through LDS
+    int T = 0;
+    {
+        int t = tcount;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (NW == 1) {
+            T = t;
+        } else {
+            if (lane == 0) red[wid] = t;
+            team_sync<TEAM>();
+            for (int w = 0; w < NW; ++w) T += red[w];
+            team_sync<TEAM>();
+        }
+    }
+    Ingredients out;
+    out.du = ru.y;
+    out.dv = rv.y;
+    out.T = T;
+    out.s1 = out.s2 = out.gamma = 0;
+    out.bytes = 0.0;
+    if (MODE == MODE_TRI) return out;
+
+    int s1 = 0, s2 = 0, gam = 0;
+    long long rows_len = 0;
+    int rows_cnt = 0;
+    // side 0: k in N(u) only, count neighbours that are in N(v) only; side 1 mirrored
+    for (int side = 0; side < 2; ++side) {
+        const int32_t *row = side == 0 ? rowu : rowv;
+        const int deg = side == 0 ? ru.y : rv.y;
+        const unsigned mine = side == 0 ? 1u : 2u;    // tag pattern (>>30) of "only this side"
+        const unsigned other = side == 0 ? 2u : 1u;
+        int scount = 0;
+        for (int p = wid; p < deg; p += NW) {
+            const int k = row[p];
+            const unsigned ek = table_lookup<SLOTS>(tab, (unsigned)k);
+            if ((ek >> 30) != mine) continue;  // triangle node, or the edge's own endpoint
+            const int2 rk = g.rowinfo[k];
+            const int32_t *rowk = g.col + rk.x;
+            if (MODE == MODE_BYTES) {
+                rows_len += rk.y;
+                rows_cnt += 1;
+                continue;
+            }
+            int c = 0;
+            for (int base = 0; base < rk.y; base += 64) {
+                const int i = base + lane;
+                bool hit = false;
+                if (i < rk.y) {
+                    const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[i]);
+                    hit = (e != EMPTY) && ((e >> 30) == other);
+                }
+                c += __popcll(__ballot(hit));
+            }
+            if (c > 0) {
+                ++scount;
+                gam = c > gam ? c : gam;
+            }
+        }
+        if (side == 0) s1 = scount; else s2 = scount;
+    }
+    if (NW > 1) {
+        if (lane == 0) {
+            red[wid] = s1;
+            red[NW + wid] = s2;
+            red[2 * NW + wid] = gam;
+            red[3 * NW + wid] = rows_cnt;
+            ((long long *)(red + 4 * NW))[wid] = rows_len;
+        }
+        team_sync<TEAM>();
+        s1 = s2 = gam = rows_cnt = 0;
+        rows_len = 0;
+        for (int w = 0; w < NW; ++w) {
+            s1 += red[w];
+            s2 += red[NW + w];
+            gam = red[2 * NW + w] > gam ? red[2 * NW + w] : gam;
+            rows_cnt += red[3 * NW + w];
+            rows_len += ((long long *)(red + 4 * NW))[w];
+        }
+        team_sync<TEAM>();
+    }
+    out.s1 = s1;
+    out.s2 = s2;
+    out.gamma = gam;
+    if (MODE == MODE_BYTES) {
+        // rows of u and v, the row of every non-triangle neighbour, row-pointer pairs, output
+        out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)rows_len + 8.0 * (double)(2 + rows_cnt) + 8.0;
+    }
+    return out;
+}
+
+template <int SLOTS, int TEAM, int MODE>
+__global__ void __launch_bounds__(TEAM) k_edge_pass(View g, const int32_t *work, const int32_t *work_count,
+                                                     int curv_type, double *curv, double *bytes_total) {
+    __shared__ unsigned tab[SLOTS];
+    __shared__ int red[6 * (TEAM / 64) + 2];
+    const int count = *work_count;
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const int s = work[item];
+        const int u = g.slot_row[s];
+        const int v = g.col[s];
+        Ingredients q = edge_ingredients<SLOTS, TEAM, MODE>(g, u, v, tab, red);
+        if (threadIdx.x == 0) {
+            if (MODE == MODE_BFC) {
+                curv[s] = bfc_formula(q.du, q.dv, q.T, q.s1, q.s2, q.gamma);
+            } else if (MODE == MODE_TRI) {
+                curv[s] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - q.du - q.dv + 3 * q.T) : (double)q.T;
+            } else {
+                atomicAdd(bytes_total, q.bytes);
+            }
+        }
+    }
+}
+
+// one edge given directly (dcr_curvature_edge / dcr_bfc_ingredients)
+template <int SLOTS, int TEAM>
+__global__ void __launch_bounds__(TEAM) k_edge_single(View g, int u, int v, int64_t *out6) {
+    __shared__ unsigned tab[SLOTS];
+    __shared__ int red[6 * (TEAM / 64) + 2];
+    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE_BFC>(g, u, v, tab, red);
+    if (threadIdx.x == 0) {
+        out6[0] = q.du; out6[1] = q.dv; out6[2] = q.T; out6[3] = q.s1; out6[4] = q.s2; out6[5] = q.gamma;
+    }
+}
+
+// Classify every adjacency slot: undirected edges are the slots whose neighbour id exceeds the row id.
+// Trivial cases are finished here ('1d'; BFC with a degree-1 endpoint, bfc_naive.py:18-19); the rest go to
+// the work list of the bin that fits their neighbourhood.
+__global__ void __launch_bounds__(256) k_classify(View g, int64_t cap_total, int curv_type, int mode, double *curv,
+                                                   WorkLists wl, DevResult *res, double *bytes_total) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x; s0 < cap_total; s0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = s0 + threadIdx.x;
+        int bin = -1;
+        if (s < cap_total) {
+            const int u = g.slot_row[s];
+            const int2 ru = g.rowinfo[u];
+            if ((int)(s - ru.x) < ru.y) {
+                const int v = g.col[s];
+                if (v > u) {
+                    const int dv = g.rowinfo[v].y, du = ru.y;
+                    if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
+                        curv[s] = (double)(4 - du - dv);
+                    } else if (curv_type == DCR_CURV_BFC && (du < dv ? du : dv) == 1) {
+                        if (mode == MODE_BYTES) atomicAdd(bytes_total, 24.0);
+                        else curv[s] = 0.0;
+                    } else {
+                        const int keys = du + dv + 2;
+                        bin = NBINS;
+                        for (int b = NBINS - 1; b >= 0; --b)
+                            if (keys <= bin_max_keys(b)) bin = b;
+                        if (bin == NBINS) {
+                            res->flag_too_big = 1;
+                            bin = -1;
+                        }
+                    }
+                }
+            }
+        }
+        for (int b = 0; b < NBINS; ++b) {
+            const unsigned long long m = __ballot(bin == b);
+            if (m == 0) continue;
+            int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&res->work_count[b], __popcll(m));
+            base = __shfl(base, leader);
+            if (bin == b) wl.w[b][base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+        }
+    }
+}
+
+__global__ void k_clear_counts(DevResult *res) {
+    if (threadIdx.x < NBINS) res->work_count[threadIdx.x] = 0;
+    if (threadIdx.x == 0) res->flag_too_big = 0;
+}
+
+static int ensure_work(dcr_graph *g) {
+    if (g->work_cap >= g->cap_total / 2 + 64 && g->work[0]) return DCR_OK;
+    int64_t cap = g->cap_total / 2 + 64;  // at most one undirected edge per two directed slots
+    for (int b = 0; b < NBINS; ++b) {
+        if (g->work[b]) (void)hipFree(g->work[b]);
+        g->work[b] = nullptr;
+        DCR_TRY(dev_alloc(&g->work[b], cap));
+    }
+    g->work_cap = cap;
+    return DCR_OK;
+}
+
+template <int B, int MODE>
+static void launch_bin(dcr_graph *g, const View &vw, int curv_type, double *bytes_total, int num_cu) {
+    constexpr int SLOTS = BIN_SLOTS[B];
+    constexpr int TEAM = BIN_TEAM[B];
+    // persistent grid: enough teams to fill every CU's wave slots / LDS, items dealt round-robin
+    int per_cu = TEAM == 64 ? 32 : TEAM == 256 ? (SLOTS * 4 <= 8192 ? 8 : 4) : 1;
+    int grid = num_cu * per_cu;
+    hipLaunchKernelGGL((k_edge_pass<SLOTS, TEAM, MODE>), dim3(grid), dim3(TEAM), 0, g->stream, vw, g->work[B],
+                       &g->dres->work_count[B], curv_type, g->curv, bytes_total);
+}
+
+template <int MODE>
+static int run_pass(dcr_graph *g, int curv_type, double *bytes_total) {
+    DCR_TRY(ensure_work(g));
+    View vw{g->rowinfo, g->col, g->slot_row};
+    WorkLists wl;
+    for (int b = 0; b < NBINS; ++b) wl.w[b] = g->work[b];
+    int num_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0)
+        num_cu = prop.multiProcessorCount;
+    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, g->stream, g->dres);
+    int64_t blocks = (g->cap_total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_classify, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->cap_total, curv_type, MODE,
+                       g->curv, wl, g->dres, bytes_total);
+    if (curv_type != DCR_CURV_1D || MODE == MODE_BYTES) {
+        launch_bin<0, MODE>(g, vw, curv_type, bytes_total, num_cu);
+        launch_bin<1, MODE>(g, vw, curv_type, bytes_total, num_cu);
+        launch_bin<2, MODE>(g, vw, curv_type, bytes_total, num_cu);
+        launch_bin<3, MODE>(g, vw, curv_type, bytes_total, num_cu);
+        launch_bin<4, MODE>(g, vw, curv_type, bytes_total, num_cu);
+    }
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+int launch_curvature_pass(dcr_graph *g, int curv_type) {
+    if (curv_type == DCR_CURV_BFC || curv_type == DCR_CURV_1D) return run_pass<MODE_BFC>(g, curv_type, nullptr);
+    return run_pass<MODE_TRI>(g, curv_type, nullptr);
+}
+
+template <int B>
+static void launch_single(dcr_graph *g, const View &vw, int u, int v, int64_t *out6) {
+    hipLaunchKernelGGL((k_edge_single<BIN_SLOTS[B], BIN_TEAM[B]>), dim3(1), dim3(BIN_TEAM[B]), 0, g->stream, vw, u, v,
+                       out6);
+}
+
+}  // namespace dcr
+
+using namespace dcr;
+
+extern "C" {
+
+int dcr_curvature_pass(dcr_graph *g, int curv_type) {
+    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
+    if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
+    DCR_HIP(hipSetDevice(g->device));
+    if (g->profile) DCR_HIP(hipEventRecord(g->ev0, g->stream));
+    DCR_TRY(launch_curvature_pass(g, curv_type));
+    if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
+    DCR_TRY(sync_result(g));
+    if (g->profile) {
+        float ms = 0.f;
+        DCR_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+        g->pass_ms_total += ms;
+        g->pass_count += 1;
+    }
+    if (g->hres->flag_too_big)
+        DCR_FAIL(DCR_ECAPACITY, "an edge has deg(u)+deg(v)+2 > 16384: beyond the LDS table of the largest bin");
+    g->curv_type_last = curv_type;
+    g->curv_valid = true;
+    return DCR_OK;
+}
+
+int dcr_bfc_ingredients(dcr_graph *g, int32_t u, int32_t v, int64_t out6[6]) {
+    if (!g || !out6) DCR_FAIL(DCR_EINVAL, "null argument");
+    if (u < 0 || v < 0 || u >= g->n || v >= g->n || u == v) DCR_FAIL(DCR_EINVAL, "bad node ids");
+    DCR_HIP(hipSetDevice(g->device));
+    int32_t du, dv;
+    DCR_TRY(dcr_graph_degree(g, u, &du));
+    DCR_TRY(dcr_graph_degree(g, v, &dv));
+    const int keys = du + dv + 2;
+    int64_t *d_out = nullptr;
+    DCR_TRY(dev_alloc(&d_out, 6));
+    View vw{g->rowinfo, g->col, g->slot_row};
+    if (keys <= bin_max_keys(0)) launch_single<0>(g, vw, u, v, d_out);
+    else if (keys <= bin_max_keys(1)) launch_single<1>(g, vw, u, v, d_out);
+    else if (keys <= bin_max_keys(2)) launch_single<2>(g, vw, u, v, d_out);
+    else if (keys <= bin_max_keys(3)) launch_single<3>(g, vw, u, v, d_out);
+    else if (keys <= bin_max_keys(4)) launch_single<4>(g, vw, u, v, d_out);
+    else {
+        (void)hipFree(d_out);
+        DCR_FAIL(DCR_ECAPACITY, "deg(u)+deg(v)+2 > 16384");
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out6, d_out, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) DCR_FAIL(DCR_EHIP, hipGetErrorString(e));
+    return DCR_OK;
+}
+
+int dcr_curvature_edge(dcr_graph *g, int32_t u, int32_t v, int curv_type, double *out) {
+    if (!out) DCR_FAIL(DCR_EINVAL, "null out");
+    int64_t q[6];
+    DCR_TRY(dcr_bfc_ingredients(g, u, v, q));
+    const int du = (int)q[0], dv = (int)q[1], T = (int)q[2];
+    switch (curv_type) {
+        case DCR_CURV_1D: *out = (double)(4 - du - dv); break;
+        case DCR_CURV_AUGMENTED: *out = (double)(4 - du - dv + 3 * T); break;
+        case DCR_CURV_HAANTJES: *out = (double)T; break;
+        case DCR_CURV_BFC:
+            // the closing expression is evaluated by the same inline function the kernels use
+            *out = (du < dv ? du : dv) == 1 ? 0.0 : bfc_formula(du, dv, T, (int)q[3], (int)q[4], (int)q[5]);
+            break;
+        default: DCR_FAIL(DCR_EINVAL, "unknown curvature type");
+    }
+    return DCR_OK;
+}
+
+int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes) {
+    if (!g || !out_bytes) DCR_FAIL(DCR_EINVAL, "null argument");
+    DCR_HIP(hipSetDevice(g->device));
+    double *d_total = nullptr;
+    DCR_TRY(dev_alloc(&d_total, 1));
+    DCR_HIP(hipMemsetAsync(d_total, 0, sizeof(double), g->stream));
+    int rc = run_pass<MODE_BYTES>(g, DCR_CURV_BFC, d_total);
+    if (rc == DCR_OK) {
+        hipError_t e = hipMemcpyAsync(out_bytes, d_total, sizeof(double), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) {
+            set_error(hipGetErrorString(e));
+            rc = DCR_EHIP;
+        }
+    }
+    (void)hipFree(d_total);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// Internal declarations shared by the translation units of libdcr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "dcr.h"
+
+namespace dcr {
+
+void set_error(const std::string &msg);
+
+#define DCR_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            ::dcr::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+            return DCR_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define DCR_TRY(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != DCR_OK) return _rc; \
+    } while (0)
+
+#define DCR_FAIL(code, msg)       \
+    do {                          \
+        ::dcr::set_error(msg);    \
+        return (code);            \
+    } while (0)
+
+// ---- curvature-pass work bins ----------------------------------------------
+// An undirected edge (u,v) needs an LDS hash set over N(u) ∪ N(v) ∪ {u,v}; the bin is chosen by
+// that size so the table keeps a load factor <= 1/2.  Threads per edge ("team") grow with the bin.
+constexpr int NBINS = 5;
+constexpr int BIN_SLOTS[NBINS] = {128, 512, 2048, 8192, 32768};
+constexpr int BIN_TEAM[NBINS] = {64, 64, 256, 256, 1024};
+constexpr int MAX_TABLE_KEYS = BIN_SLOTS[NBINS - 1] / 2;  // du + dv + 2 must not exceed this
+constexpr int32_t MAX_NODES = (1 << 30) - 2;              // two tag bits live above the key
+
+// small result block mirrored in pinned host memory
+struct DevResult {
+    double ext_val;       // argext value
+    int32_t ext_slot;     // argext slot (-1: none)
+    int32_t ext_u, ext_v;
+    int32_t add_status;   // 0 ok, 1 row overflow (nothing changed), 2 already present
+    int32_t removed_u, removed_v;
+    int32_t overflow_row;
+    int32_t max_keys;     // largest du+dv+2 seen by classify
+    int32_t work_count[NBINS];
+    int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS
+    int64_t n_cand;
+    int64_t imp_argmax;
+    int32_t cand_i, cand_j;
+    int32_t misc[4];
+};
+
+struct ImpStats {  // per (x,y) statistics for the improvement kernels; lives in device memory
+    int32_t x, y, dx, dy;
+    int32_t T, s1, s2;
+    int32_t max1, cnt1, max2, cnt2, sec1, sec2;  // maxima of c1/c2, their multiplicity, runner-up
+    int32_t table_mask;
+    int32_t deg_min_is_one;
+    int32_t pos_x_in_y;  // position of x inside row y
+    int32_t pad_;
+    double before;
+};
+
+}  // namespace dcr
+
+struct dcr_graph {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0;
+    int64_t n_edges = 0;    // undirected, tracked on the host
+    int64_t cap_total = 0;  // adjacency slots allocated
+
+    // HBM-resident graph: rows in insertion order, slack-padded
+    int2 *rowinfo = nullptr;     // [n] {start slot, degree}
+    int32_t *rowcap = nullptr;   // [n] capacity of each row
+    int32_t *col = nullptr;      // [cap_total] neighbour ids
+    int32_t *slot_row = nullptr; // [cap_total] owning row of each slot
+    double *curv = nullptr;      // [cap_total] curvature of the undirected edge stored at slot (col > row)
+
+    int curv_type_last = -1;
+    bool curv_valid = false;
+
+    // curvature-pass work lists
+    int32_t *work[dcr::NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t work_cap = 0;
+
+    // reductions / scans
+    void *red_scratch = nullptr;  // argext partials
+    int32_t *scan_a = nullptr, *scan_b = nullptr;
+    int64_t scan_cap = 0;
+
+    // improvement pipeline scratch (grown on demand)
+    int32_t *imp_table = nullptr;  // hash keys
+    int32_t *imp_posx = nullptr, *imp_posy = nullptr;
+    int64_t imp_table_cap = 0;
+    int32_t *imp_c1 = nullptr, *imp_c2 = nullptr;  // per position in row x / row y
+    double *imp_b = nullptr, *imp_c = nullptr;     // class B / C improvements per position
+    int32_t *imp_rowcount = nullptr, *imp_rowoff = nullptr;
+    uint32_t *imp_adjbits = nullptr;               // (dx+1) x words(dy+1)
+    int64_t imp_rows_cap = 0, imp_bits_cap = 0;
+    double *imp_out = nullptr;                     // compacted improvements (device)
+    int32_t *imp_ci = nullptr, *imp_cj = nullptr;
+    int64_t imp_out_cap = 0;
+    double *imp_out_h = nullptr;                   // pinned host mirrors
+    int32_t *imp_ci_h = nullptr, *imp_cj_h = nullptr;
+    int64_t imp_out_h_cap = 0, imp_cand_h_cap = 0;
+    int64_t imp_n = 0;
+    dcr::ImpStats *imp_stats = nullptr;
+
+    dcr::DevResult *dres = nullptr;  // device
+    dcr::DevResult *hres = nullptr;  // pinned host
+
+    // profiling
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double pass_ms_total = 0.0;
+    int64_t pass_count = 0;
+    bool profile = false;
+};
+
+namespace dcr {
+
+// dcr_graph.hip
+int device_exclusive_scan(dcr_graph *g, const int32_t *in, int32_t *out, int64_t n, int64_t *total_out);
+int ensure_scan(dcr_graph *g, int64_t n);
+int relayout(dcr_graph *g);
+int sync_result(dcr_graph *g);  // D2H of DevResult + stream sync
+void launch_add_edge(dcr_graph *g, int32_t u, int32_t v);          // u < 0: no-op that clears add_status
+void launch_remove_if_above(dcr_graph *g, double bound);           // acts on the last argext result
+
+// dcr_bfc.hip
+int launch_curvature_pass(dcr_graph *g, int curv_type);
+
+template <typename T>
+int dev_alloc(T **p, int64_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+        return DCR_ENOMEM;
+    }
+    *p = (T *)q;
+    return DCR_OK;
+}
+
+template <typename T>
+int dev_regrow(T **p, int64_t *cap, int64_t need) {
+    if (need <= *cap) return DCR_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    int64_t nc = need + need / 4 + 64;
+    DCR_TRY(dev_alloc(p, nc));
+    *cap = nc;
+    return DCR_OK;
+}
+
+}  // namespace dcr

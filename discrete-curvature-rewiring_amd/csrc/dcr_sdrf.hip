@@ -1,0 +1,843 @@
+// SDRF-side kernels of libdcr_hip.so: arg-min/arg-max over edges, the candidate/improvement tensor and the
+// add/remove tail of one iteration (rewiring/sdrf_no_cuda.py:27-66).
+//
+// Improvements.  The reference evaluates bfc_edge(x,y) twice per candidate (sdrf_no_cuda.py:41-46).  Here the
+// integer ingredients of bfc_edge(x,y) on G + (i,j) are derived exactly from per-neighbour counters of the base
+// graph, and the float64 closing expression (bfc_naive.py:31-40) is evaluated on those integers, so
+// after - before is bit-identical to the reference while the work per candidate is O(1):
+//   c1[a] = |N(i_a) ∩ DY| for i_a in DX = N(x) \ N(y) \ {y};  c2[b] = |N(j_b) ∩ DX| for j_b in DY.
+//   * i in N(x), j in N(y) (neither is x or y): only (i in DX, j in DY) changes anything: c1[a]+1, c2[b]+1.
+//   * i == x, j in DY: deg(x)+1, T+1, j leaves DY: c1[k] drops by [k ~ j]; needs one scan of row j.
+//   * j == y, i in DX: mirrored.
+//   * every other admissible pair leaves all ingredients unchanged: improvement = +0.0.
+#include "dcr_internal.h"
+
+namespace dcr {
+
+struct View {
+    const int2 *rowinfo;
+    const int32_t *col;
+    const int32_t *slot_row;
+};
+
+__device__ __host__ inline double bfc_formula(int d1, int d2, int T, int s1, int s2, int gamma) {
+    int dmax = d1 > d2 ? d1 : d2, dmin = d1 < d2 ? d1 : d2;
+    double r = 2.0 / (double)d1;
+    r = r + 2.0 / (double)d2;
+    r = r - 2.0;
+    r = r + (double)(2 * (int64_t)T) / (double)dmax;
+    r = r + (double)T / (double)dmin;
+    if (s1 == 0 || s2 == 0) return r;
+    double q = 1.0 / (double)gamma;
+    q = q / (double)dmax;
+    q = q * (double)(s1 + s2);
+    return r + q;
+}
+
+__device__ inline double bfc_value(int d1, int d2, int T, int s1, int s2, int gamma) {
+    if ((d1 < d2 ? d1 : d2) == 1) return 0.0;  // bfc_naive.py:18-19
+    return bfc_formula(d1, d2, T, s1, s2, gamma);
+}
+
+// ---------------------------------------------------------------------------------------------
+// arg-extremum over undirected edges, first in G.edges order (= smallest slot) on ties
+// ---------------------------------------------------------------------------------------------
+struct Ext {
+    double val;
+    int32_t slot;
+    int32_t pad;
+};
+
+__device__ inline Ext ext_better(const Ext &a, const Ext &b, int want_max) {
+    if (b.slot < 0) return a;
+    if (a.slot < 0) return b;
+    bool take_b = want_max ? (b.val > a.val) : (b.val < a.val);
+    if (!take_b && b.val == a.val && b.slot < a.slot) take_b = true;
+    return take_b ? b : a;
+}
+
+__device__ inline Ext ext_wave_reduce(Ext e, int want_max) {
+    for (int off = 32; off > 0; off >>= 1) {
+        Ext o;
+        o.val = __shfl_xor(e.val, off);
+        o.slot = __shfl_xor(e.slot, off);
+        e = ext_better(e, o, want_max);
+    }
+    return e;
+}
+
+__device__ inline Ext ext_block_reduce(Ext e, int want_max, Ext *sh) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    e = ext_wave_reduce(e, want_max);
+    if (lane == 0) sh[wid] = e;
+    __syncthreads();
+    if (wid == 0) {
+        Ext t;
+        t.val = 0.0;
+        t.slot = -1;
+        if (lane < nw) t = sh[lane];
+        t = ext_wave_reduce(t, want_max);
+        if (lane == 0) sh[0] = t;
+    }
+    __syncthreads();
+    return sh[0];
+}
+
+__global__ void __launch_bounds__(256) k_argext_edges(View g, int64_t cap_total, const double *curv, int want_max,
+                                                       int excl_u, int excl_v, Ext *partial) {
+    __shared__ Ext sh[4];
+    Ext best;
+    best.val = 0.0;
+    best.slot = -1;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap_total;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int u = g.slot_row[s];
+        const int2 ru = g.rowinfo[u];
+        if ((int)(s - ru.x) >= ru.y) continue;
+        const int v = g.col[s];
+        if (v <= u) continue;
+        if (u == excl_u && v == excl_v) continue;
+        Ext c;
+        c.val = curv[s];
+        c.slot = (int32_t)s;
+        best = ext_better(best, c, want_max);
+    }
+    best = ext_block_reduce(best, want_max, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+
+__global__ void __launch_bounds__(256) k_argext_final(View g, const Ext *partial, int nparts, int want_max,
+                                                       DevResult *res) {
+    __shared__ Ext sh[4];
+    Ext best;
+    best.val = 0.0;
+    best.slot = -1;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) best = ext_better(best, partial[i], want_max);
+    best = ext_block_reduce(best, want_max, sh);
+    if (threadIdx.x == 0) {
+        res->ext_val = best.val;
+        res->ext_slot = best.slot;
+        res->ext_u = best.slot >= 0 ? g.slot_row[best.slot] : -1;
+        res->ext_v = best.slot >= 0 ? g.col[best.slot] : -1;
+    }
+}
+
+// first maximum of a plain array (np.argmax of the improvements, utils/softmax.py:7)
+__global__ void __launch_bounds__(256) k_argmax_array(const double *a, int64_t n, Ext *partial, int64_t *idx_hi) {
+    __shared__ Ext sh[4];
+    Ext best;
+    best.val = 0.0;
+    best.slot = -1;
+    // indices may exceed int32 only beyond 2^31 candidates, which the row capacity already excludes
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        Ext c;
+        c.val = a[i];
+        c.slot = (int32_t)i;
+        best = ext_better(best, c, 1);
+    }
+    best = ext_block_reduce(best, 1, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+    (void)idx_hi;
+}
+
+__global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int nparts, DevResult *res) {
+    __shared__ Ext sh[4];
+    Ext best;
+    best.val = 0.0;
+    best.slot = -1;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) best = ext_better(best, partial[i], 1);
+    best = ext_block_reduce(best, 1, sh);
+    if (threadIdx.x == 0) res->imp_argmax = best.slot;
+}
+
+constexpr int ARGEXT_BLOCKS = 1024;
+
+static int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
+    if (!g->red_scratch) {
+        Ext *p = nullptr;
+        DCR_TRY(dev_alloc(&p, ARGEXT_BLOCKS));
+        g->red_scratch = p;
+    }
+    View vw{g->rowinfo, g->col, g->slot_row};
+    int64_t blocks = (g->cap_total + 255) / 256;
+    if (blocks > ARGEXT_BLOCKS) blocks = ARGEXT_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_argext_edges, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->cap_total, g->curv,
+                       want_max, excl_u, excl_v, (Ext *)g->red_scratch);
+    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, g->stream, vw, (const Ext *)g->red_scratch, (int)blocks,
+                       want_max, g->dres);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// improvement pipeline
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned T_EMPTY = 0xFFFFFFFFu;
+
+__device__ inline unsigned g_hash(unsigned key, unsigned mask) { return (key * 0x9E3779B1u >> 7) & mask; }
+
+// slot index of key in the global table, or -1
+__device__ inline int g_find(const int32_t *keys, unsigned mask, int key) {
+    unsigned h = g_hash((unsigned)key, mask);
+    while (true) {
+        const int e = keys[h];
+        if (e == key) return (int)h;
+        if ((unsigned)e == T_EMPTY) return -1;
+        h = (h + 1) & mask;
+    }
+}
+
+struct ImpBuf {
+    int32_t *keys, *posx, *posy;  // hash table over N(x) ∪ N(y) minus {x,y}
+    int32_t *c1, *c2;             // [dx], [dy]
+    int32_t *clsx, *clsy;         // 0: only in own row (DX / DY), 1: in both rows (triangle), 2: the other endpoint
+    double *impb, *impc;          // class B (i == x) per b, class C (j == y) per a
+    int32_t *rowcount, *rowoff;   // [dx+1]
+    uint32_t *adjbits;            // [dx+1][words]
+    ImpStats *st;
+};
+
+// K1a: insert row x.  grid-stride, any grid.
+__global__ void k_imp_insert_x(View g, ImpBuf B, int x, int y, unsigned mask) {
+    const int2 rx = g.rowinfo[x];
+    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < rx.y; a += gridDim.x * blockDim.x) {
+        const int k = g.col[rx.x + a];
+        if (k == y) {
+            B.clsx[a] = 2;
+            continue;
+        }
+        B.clsx[a] = 0;
+        unsigned h = g_hash((unsigned)k, mask);
+        while (true) {
+            const unsigned old = atomicCAS((unsigned *)&B.keys[h], T_EMPTY, (unsigned)k);
+            if (old == T_EMPTY) break;
+            h = (h + 1) & mask;
+        }
+        B.posx[h] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int2 ry = g.rowinfo[y];
+        B.st->x = x;
+        B.st->y = y;
+        B.st->dx = rx.y;
+        B.st->dy = ry.y;
+        B.st->table_mask = (int)mask;
+        B.st->T = 0;
+        B.st->pos_x_in_y = -1;
+        B.st->deg_min_is_one = (rx.y < ry.y ? rx.y : ry.y) == 1;
+    }
+}
+
+// K1b: insert row y; a key already present came from row x: a triangle node.
+__global__ void k_imp_insert_y(View g, ImpBuf B, int x, int y, unsigned mask) {
+    const int2 ry = g.rowinfo[y];
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < ry.y; b += gridDim.x * blockDim.x) {
+        const int k = g.col[ry.x + b];
+        if (k == x) {
+            B.clsy[b] = 2;
+            B.st->pos_x_in_y = b;
+            continue;
+        }
+        unsigned h = g_hash((unsigned)k, mask);
+        int cls = 0;
+        while (true) {
+            unsigned e = __hip_atomic_load((unsigned *)&B.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e == T_EMPTY) {
+                e = atomicCAS((unsigned *)&B.keys[h], T_EMPTY, (unsigned)k);
+                if (e == T_EMPTY) break;
+            }
+            if (e == (unsigned)k) {
+                cls = 1;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        B.posy[h] = b;
+        B.clsy[b] = cls;
+        if (cls == 1) {
+            B.clsx[B.posx[h]] = 1;  // posx was written by the previous kernel
+            atomicAdd(&B.st->T, 1);
+        }
+    }
+}
+
+// K2: c1[a] for a in DX by streaming row i_a; every hit also bumps c2 of the DY node it lands on.
+__global__ void __launch_bounds__(256) k_imp_count(View g, ImpBuf B, int x, unsigned mask) {
+    const int2 rx = g.rowinfo[x];
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (a >= rx.y) return;
+    if (B.clsx[a] != 0) {
+        if (lane == 0) B.c1[a] = 0;
+        return;
+    }
+    const int i = g.col[rx.x + a];
+    const int2 ri = g.rowinfo[i];
+    int c = 0;
+    for (int base = 0; base < ri.y; base += 64) {
+        const int t = base + lane;
+        bool hit = false;
+        if (t < ri.y) {
+            const int w = g.col[ri.x + t];
+            const int h = g_find(B.keys, mask, w);
+            if (h >= 0 && B.posx[h] < 0) {  // in N(y) only (x and y are never in the table)
+                hit = true;
+                atomicAdd(&B.c2[B.posy[h]], 1);
+            }
+        }
+        c += __popcll(__ballot(hit));
+    }
+    if (lane == 0) B.c1[a] = c;
+}
+
+struct Mx {
+    int m, c, s;  // maximum, how many attain it, largest value below it
+};
+
+__device__ inline Mx mx_join(Mx a, Mx b) {
+    Mx r;
+    if (a.m == b.m) {
+        r.m = a.m;
+        r.c = a.c + b.c;
+        r.s = a.s > b.s ? a.s : b.s;
+    } else if (a.m > b.m) {
+        r.m = a.m;
+        r.c = a.c;
+        r.s = a.s > b.m ? a.s : b.m;
+    } else {
+        r.m = b.m;
+        r.c = b.c;
+        r.s = b.s > a.m ? b.s : a.m;
+    }
+    return r;
+}
+
+__device__ inline Mx mx_add(Mx a, int v) {
+    Mx b;
+    b.m = v;
+    b.c = 1;
+    b.s = -1;
+    return mx_join(a, b);
+}
+
+__device__ inline void block_stats(const int32_t *c, int n, int *cnt_pos, Mx *mx, int *shi) {
+    int pos = 0;
+    Mx m;
+    m.m = -1;
+    m.c = 0;
+    m.s = -1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = c[i];
+        pos += v > 0;
+        m = mx_add(m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        pos += __shfl_xor(pos, off);
+        Mx o;
+        o.m = __shfl_xor(m.m, off);
+        o.c = __shfl_xor(m.c, off);
+        o.s = __shfl_xor(m.s, off);
+        m = mx_join(m, o);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        shi[wid * 4 + 0] = pos;
+        shi[wid * 4 + 1] = m.m;
+        shi[wid * 4 + 2] = m.c;
+        shi[wid * 4 + 3] = m.s;
+    }
+    __syncthreads();
+    pos = 0;
+    m.m = -1;
+    m.c = 0;
+    m.s = -1;
+    for (int w = 0; w < nw; ++w) {
+        pos += shi[w * 4];
+        Mx o;
+        o.m = shi[w * 4 + 1];
+        o.c = shi[w * 4 + 2];
+        o.s = shi[w * 4 + 3];
+        m = mx_join(m, o);
+    }
+    *cnt_pos = pos;
+    *mx = m;
+}
+
+// K3: |sq1|, |sq2|, maxima (with multiplicity and runner-up) and the base curvature.
+__global__ void __launch_bounds__(1024) k_imp_stats(ImpBuf B, int curv_type) {
+    __shared__ int shi[16 * 4];
+    ImpStats *st = B.st;
+    const int dx = st->dx, dy = st->dy;
+    int s1, s2;
+    Mx m1, m2;
+    block_stats(B.c1, dx, &s1, &m1, shi);
+    block_stats(B.c2, dy, &s2, &m2, shi);
+    if (threadIdx.x == 0) {
+        st->s1 = s1;
+        st->s2 = s2;
+        st->max1 = m1.m < 0 ? 0 : m1.m;
+        st->cnt1 = m1.c;
+        st->sec1 = m1.s < 0 ? 0 : m1.s;
+        st->max2 = m2.m < 0 ? 0 : m2.m;
+        st->cnt2 = m2.c;
+        st->sec2 = m2.s < 0 ? 0 : m2.s;
+        const int gam = st->max1 > st->max2 ? st->max1 : st->max2;
+        double before;
+        switch (curv_type) {
+            case DCR_CURV_1D: before = (double)(4 - dx - dy); break;
+            case DCR_CURV_AUGMENTED: before = (double)(4 - dx - dy + 3 * st->T); break;
+            case DCR_CURV_HAANTJES: before = (double)st->T; break;
+            default: before = bfc_value(dx, dy, st->T, s1, s2, gam);
+        }
+        st->before = before;
+    }
+}
+
+// K4: class B (i == x, j = y_nb[b] in DY) for waves [0,dy), class C (j == y, i = x_nb[a] in DX) for waves [dy,dy+dx).
+__global__ void __launch_bounds__(256) k_imp_bc(View g, ImpBuf B, int x, int y, unsigned mask, int curv_type) {
+    const ImpStats st = *B.st;
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wv >= st.dx + st.dy) return;
+    const bool isB = wv < st.dy;
+    const int p = isB ? wv : wv - st.dy;
+    const int cls = isB ? B.clsy[p] : B.clsx[p];
+    double *out = isB ? B.impb : B.impc;
+    if (cls != 0) {
+        if (lane == 0) out[p] = 0.0;
+        return;
+    }
+    if (curv_type != DCR_CURV_BFC) {
+        // 4 - d1 - d2 (+3T): one degree grows, one triangle appears (classical_curvatures.py:14-28)
+        const double d = curv_type == DCR_CURV_1D ? -1.0 : curv_type == DCR_CURV_AUGMENTED ? 2.0 : 1.0;
+        if (lane == 0) out[p] = d;
+        return;
+    }
+    const int2 rown = g.rowinfo[isB ? y : x];
+    const int node = g.col[rown.x + p];  // j for class B, i for class C
+    const int2 rn = g.rowinfo[node];
+    const int32_t *cnt_other = isB ? B.c1 : B.c2;  // counters of the side that loses edges
+    const int max_other = isB ? st.max1 : st.max2;
+    int n_dec0 = 0, n_maxadj = 0;
+    for (int base = 0; base < rn.y; base += 64) {
+        const int t = base + lane;
+        bool dec0 = false, mxa = false;
+        if (t < rn.y) {
+            const int w = g.col[rn.x + t];
+            const int h = g_find(B.keys, mask, w);
+            if (h >= 0) {
+                const int px = B.posx[h], py = B.posy[h];
+                const bool other_only = isB ? (px >= 0 && py < 0) : (py >= 0 && px < 0);
+                if (other_only) {
+                    const int c = cnt_other[isB ? px : py];
+                    dec0 = (c == 1);
+                    mxa = (c == max_other);
+                }
+            }
+        }
+        n_dec0 += __popcll(__ballot(dec0));
+        n_maxadj += __popcll(__ballot(mxa));
+    }
+    if (lane != 0) return;
+    int s1, s2, m1, m2, d1, d2;
+    if (isB) {
+        const int cb = B.c2[p];
+        s1 = st.s1 - n_dec0;
+        m1 = (st.max1 > 0 && n_maxadj == st.cnt1) ? st.max1 - 1 : st.max1;
+        s2 = st.s2 - (cb > 0);
+        m2 = (cb == st.max2 && st.cnt2 == 1) ? st.sec2 : st.max2;
+        d1 = st.dx + 1;
+        d2 = st.dy;
+    } else {
+        const int ca = B.c1[p];
+        s2 = st.s2 - n_dec0;
+        m2 = (st.max2 > 0 && n_maxadj == st.cnt2) ? st.max2 - 1 : st.max2;
+        s1 = st.s1 - (ca > 0);
+        m1 = (ca == st.max1 && st.cnt1 == 1) ? st.sec1 : st.max1;
+        d1 = st.dx;
+        d2 = st.dy + 1;
+    }
+    const double after = bfc_value(d1, d2, st.T + 1, s1, s2, m1 > m2 ? m1 : m2);
+    out[p] = after - st.before;
+}
+
+// K5: per candidate row a (i = x_nb[a], a == dx: i = x): which j in y_nb + [y] are ruled out
+// (i == j or has_edge(i,j), sdrf_no_cuda.py:35), as a bitmap, plus the count of admitted ones.
+__global__ void __launch_bounds__(256) k_imp_rows(View g, ImpBuf B, int x, int y, unsigned mask, int words) {
+    extern __shared__ uint32_t bits[];
+    __shared__ int cnt_sh;
+    const ImpStats st = *B.st;
+    const int pos_x_in_y = st.pos_x_in_y;  // x is an endpoint, so it is not in the table
+    const int a = blockIdx.x;
+    const int i = a < st.dx ? g.col[g.rowinfo[x].x + a] : x;
+    for (int w = threadIdx.x; w < words; w += blockDim.x) bits[w] = 0u;
+    if (threadIdx.x == 0) cnt_sh = 0;
+    __syncthreads();
+    const int2 ri = g.rowinfo[i];
+    for (int t = threadIdx.x; t < ri.y; t += blockDim.x) {
+        const int w = g.col[ri.x + t];
+        int b = -1;
+        if (w == y) b = st.dy;
+        else if (w == x) b = pos_x_in_y;
+        else {
+            const int h = g_find(B.keys, mask, w);
+            if (h >= 0) b = B.posy[h];
+        }
+        if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
+    }
+    if (threadIdx.x == 0) {  // i == j
+        int b = -1;
+        if (i == y) b = st.dy;
+        else if (i == x) b = pos_x_in_y;
+        else {
+            const int h = g_find(B.keys, mask, i);
+            if (h >= 0) b = B.posy[h];
+        }
+        if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
+    }
+    __syncthreads();
+    int c = 0;
+    const int nb = st.dy + 1;
+    for (int w = threadIdx.x; w < words; w += blockDim.x) {
+        uint32_t v = bits[w];
+        const int lo = w * 32;
+        const uint32_t live = (nb - lo >= 32) ? 0xFFFFFFFFu : ((1u << (nb - lo)) - 1u);
+        c += __popc(~v & live);
+        B.adjbits[(size_t)a * words + w] = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt_sh, c);
+    __syncthreads();
+    if (threadIdx.x == 0) B.rowcount[a] = cnt_sh;
+}
+
+// K6: exclusive scan of rowcount[0..rows) by one block; total -> res->n_cand
+__global__ void __launch_bounds__(1024) k_imp_scan(ImpBuf B, int rows, DevResult *res) {
+    __shared__ int wsum[16];
+    __shared__ int carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < rows; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < rows ? B.rowcount[i] : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int carry = carry_sh;
+        if (i < rows) B.rowoff[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_sh = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) res->n_cand = carry_sh;
+}
+
+// K7: write the admitted candidates of row a, in j order, with their improvements.
+__global__ void __launch_bounds__(256) k_imp_emit(View g, ImpBuf B, int x, int y, int words, int curv_type,
+                                                   double *out, int32_t *ci, int32_t *cj) {
+    __shared__ int wsum[4];
+    __shared__ int carry_sh;
+    const ImpStats st = *B.st;
+    const int a = blockIdx.x;
+    if (B.rowcount[a] == 0) return;
+    const int2 rx = g.rowinfo[x], ry = g.rowinfo[y];
+    const int i = a < st.dx ? g.col[rx.x + a] : x;
+    const int cls_a = a < st.dx ? B.clsx[a] : 3;
+    const int c1a = (a < st.dx && cls_a == 0) ? B.c1[a] : 0;
+    const int gam = st.max1 > st.max2 ? st.max1 : st.max2;
+    const int nb = st.dy + 1;
+    const int64_t row_base = B.rowoff[a];
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int wbase = 0; wbase < words; wbase += 256) {
+        const int w = wbase + threadIdx.x;
+        uint32_t ok = 0u;
+        if (w < words) {
+            const int lo = w * 32;
+            const uint32_t live = (nb - lo >= 32) ? 0xFFFFFFFFu : ((1u << (nb - lo)) - 1u);
+            ok = ~B.adjbits[(size_t)a * words + w] & live;
+        }
+        const int v = __popc(ok);
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < wid; ++q) woff += wsum[q];
+        const int carry = carry_sh;
+        int64_t o = row_base + carry + woff + incl - v;
+        while (ok) {
+            const int bit = __ffs((int)ok) - 1;
+            ok &= ok - 1u;
+            const int b = w * 32 + bit;
+            const int j = b < st.dy ? g.col[ry.x + b] : y;
+            double val;
+            if (a == st.dx) {
+                val = B.impb[b];  // i == x: admitted only for j in DY
+            } else if (b == st.dy) {
+                val = B.impc[a];  // j == y: admitted only for i in DX
+            } else if (curv_type == DCR_CURV_BFC && cls_a == 0 && B.clsy[b] == 0) {
+                const int c2b = B.c2[b];
+                const int m = (c1a + 1 > c2b + 1 ? c1a + 1 : c2b + 1);
+                const double after = bfc_value(st.dx, st.dy, st.T, st.s1 + (c1a == 0), st.s2 + (c2b == 0),
+                                               m > gam ? m : gam);
+                val = after - st.before;
+            } else {
+                val = 0.0;
+            }
+            out[o] = val;
+            ci[o] = i < j ? i : j;  // sorted((i, j)), sdrf_no_cuda.py:37
+            cj[o] = i < j ? j : i;
+            ++o;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry_sh = carry + woff + incl;
+        __syncthreads();
+    }
+}
+
+template <typename T>
+static int pinned_regrow(T **p, int64_t *cap, int64_t need) {
+    if (need <= *cap) return DCR_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    int64_t nc = need + need / 4 + 1024;
+    void *q = nullptr;
+    hipError_t e = hipHostMalloc(&q, (size_t)nc * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return DCR_ENOMEM;
+    }
+    *p = (T *)q;
+    *cap = nc;
+    return DCR_OK;
+}
+
+}  // namespace dcr
+
+using namespace dcr;
+
+extern "C" {
+
+int dcr_argext(dcr_graph *g, int want_max, int32_t excl_u, int32_t excl_v, int32_t *out_u, int32_t *out_v,
+               double *out_val) {
+    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
+    if (!g->curv_valid) DCR_FAIL(DCR_ESTATE, "dcr_argext needs a curvature pass first");
+    DCR_HIP(hipSetDevice(g->device));
+    if (excl_u > excl_v) {
+        int32_t t = excl_u;
+        excl_u = excl_v;
+        excl_v = t;
+    }
+    DCR_TRY(launch_argext(g, want_max, excl_u, excl_v));
+    DCR_TRY(sync_result(g));
+    if (g->hres->ext_slot < 0) DCR_FAIL(DCR_ENOTFOUND, "graph has no (eligible) edges");
+    if (out_u) *out_u = g->hres->ext_u;
+    if (out_v) *out_v = g->hres->ext_v;
+    if (out_val) *out_val = g->hres->ext_val;
+    return DCR_OK;
+}
+
+int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want_candidates, int64_t *n_out,
+                     const double **out_improvement, const int32_t **out_ci, const int32_t **out_cj) {
+    if (!g || !n_out) DCR_FAIL(DCR_EINVAL, "null argument");
+    if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
+    if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
+    DCR_HIP(hipSetDevice(g->device));
+    int2 rxy[2];
+    DCR_HIP(hipMemcpyAsync(&rxy[0], g->rowinfo + x, sizeof(int2), hipMemcpyDeviceToHost, g->stream));
+    DCR_HIP(hipMemcpyAsync(&rxy[1], g->rowinfo + y, sizeof(int2), hipMemcpyDeviceToHost, g->stream));
+    DCR_HIP(hipStreamSynchronize(g->stream));
+    const int dx = rxy[0].y, dy = rxy[1].y;
+    const int64_t keys = (int64_t)dx + dy;
+    int64_t ts = 64;
+    while (ts < 4 * keys) ts <<= 1;
+    const unsigned mask = (unsigned)(ts - 1);
+    const int rows = dx + 1;
+    const int words = (dy + 1 + 31) / 32;
+    if ((size_t)words * 4 > 150 * 1024) DCR_FAIL(DCR_ECAPACITY, "deg(y) too large for the candidate bitmap");
+    const int64_t upper = (int64_t)(dx + 1) * (dy + 1);
+    if (upper > INT32_MAX) DCR_FAIL(DCR_ECAPACITY, "more than 2^31 candidate pairs");
+
+    // scratch
+    if (ts > g->imp_table_cap) {
+        for (int32_t **p : {&g->imp_table, &g->imp_posx, &g->imp_posy}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+            DCR_TRY(dev_alloc(p, ts));
+        }
+        g->imp_table_cap = ts;
+    }
+    const int64_t rows_need = (int64_t)(dx > dy ? dx : dy) + 2;
+    if (rows_need > g->imp_rows_cap) {
+        const int64_t nc = rows_need + rows_need / 2 + 64;
+        for (int32_t **p : {&g->imp_c1, &g->imp_c2, &g->imp_rowcount, &g->imp_rowoff, &g->scan_a, &g->scan_b}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+            DCR_TRY(dev_alloc(p, nc));
+        }
+        for (double **p : {&g->imp_b, &g->imp_c}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+            DCR_TRY(dev_alloc(p, nc));
+        }
+        g->imp_rows_cap = nc;
+    }
+    DCR_TRY(dev_regrow(&g->imp_adjbits, &g->imp_bits_cap, (int64_t)rows * words));
+    if (upper > g->imp_out_cap) {
+        if (g->imp_out) (void)hipFree(g->imp_out);
+        if (g->imp_ci) (void)hipFree(g->imp_ci);
+        if (g->imp_cj) (void)hipFree(g->imp_cj);
+        g->imp_out = nullptr;
+        g->imp_ci = g->imp_cj = nullptr;
+        const int64_t nc = upper + upper / 4 + 1024;
+        DCR_TRY(dev_alloc(&g->imp_out, nc));
+        DCR_TRY(dev_alloc(&g->imp_ci, nc));
+        DCR_TRY(dev_alloc(&g->imp_cj, nc));
+        g->imp_out_cap = nc;
+    }
+
+    ImpBuf B;
+    B.keys = g->imp_table;
+    B.posx = g->imp_posx;
+    B.posy = g->imp_posy;
+    B.c1 = g->imp_c1;
+    B.c2 = g->imp_c2;
+    B.clsx = g->scan_a;
+    B.clsy = g->scan_b;
+    B.impb = g->imp_b;
+    B.impc = g->imp_c;
+    B.rowcount = g->imp_rowcount;
+    B.rowoff = g->imp_rowoff;
+    B.adjbits = g->imp_adjbits;
+    B.st = g->imp_stats;
+    View vw{g->rowinfo, g->col, g->slot_row};
+
+    DCR_HIP(hipMemsetAsync(B.keys, 0xff, sizeof(int32_t) * (size_t)ts, g->stream));
+    DCR_HIP(hipMemsetAsync(B.posx, 0xff, sizeof(int32_t) * (size_t)ts, g->stream));
+    DCR_HIP(hipMemsetAsync(B.posy, 0xff, sizeof(int32_t) * (size_t)ts, g->stream));
+    DCR_HIP(hipMemsetAsync(B.c1, 0, sizeof(int32_t) * (size_t)(dx + 1), g->stream));
+    DCR_HIP(hipMemsetAsync(B.c2, 0, sizeof(int32_t) * (size_t)(dy + 1), g->stream));
+    const int gx = dx > 0 ? (dx + 255) / 256 : 1, gy = dy > 0 ? (dy + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_imp_insert_x, dim3(gx), dim3(256), 0, g->stream, vw, B, x, y, mask);
+    hipLaunchKernelGGL(k_imp_insert_y, dim3(gy), dim3(256), 0, g->stream, vw, B, x, y, mask);
+    if (curv_type == DCR_CURV_BFC && dx > 0)
+        hipLaunchKernelGGL(k_imp_count, dim3((dx + 3) / 4), dim3(256), 0, g->stream, vw, B, x, mask);
+    hipLaunchKernelGGL(k_imp_stats, dim3(1), dim3(1024), 0, g->stream, B, curv_type);
+    if (dx + dy > 0)
+        hipLaunchKernelGGL(k_imp_bc, dim3((dx + dy + 3) / 4), dim3(256), 0, g->stream, vw, B, x, y, mask, curv_type);
+    hipLaunchKernelGGL(k_imp_rows, dim3(rows), dim3(256), (size_t)words * 4, g->stream, vw, B, x, y, mask, words);
+    hipLaunchKernelGGL(k_imp_scan, dim3(1), dim3(1024), 0, g->stream, B, rows, g->dres);
+    hipLaunchKernelGGL(k_imp_emit, dim3(rows), dim3(256), 0, g->stream, vw, B, x, y, words, curv_type, g->imp_out,
+                       g->imp_ci, g->imp_cj);
+    DCR_HIP(hipGetLastError());
+    DCR_TRY(sync_result(g));
+    const int64_t n = g->hres->n_cand;
+    g->imp_n = n;
+    *n_out = n;
+    if (n > 0 && out_improvement) {
+        DCR_TRY(pinned_regrow(&g->imp_out_h, &g->imp_out_h_cap, n));
+        DCR_HIP(hipMemcpyAsync(g->imp_out_h, g->imp_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, g->stream));
+    }
+    if (n > 0 && want_candidates) {
+        if (n > g->imp_cand_h_cap) {
+            int64_t c1 = g->imp_cand_h_cap, c2 = g->imp_cand_h_cap;
+            DCR_TRY(pinned_regrow(&g->imp_ci_h, &c1, n));
+            DCR_TRY(pinned_regrow(&g->imp_cj_h, &c2, n));
+            g->imp_cand_h_cap = c1 < c2 ? c1 : c2;
+        }
+        DCR_HIP(hipMemcpyAsync(g->imp_ci_h, g->imp_ci, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, g->stream));
+        DCR_HIP(hipMemcpyAsync(g->imp_cj_h, g->imp_cj, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, g->stream));
+    }
+    DCR_HIP(hipStreamSynchronize(g->stream));
+    if (out_improvement) *out_improvement = n > 0 ? g->imp_out_h : nullptr;
+    if (out_ci) *out_ci = (n > 0 && want_candidates) ? g->imp_ci_h : nullptr;
+    if (out_cj) *out_cj = (n > 0 && want_candidates) ? g->imp_cj_h : nullptr;
+    return DCR_OK;
+}
+
+int dcr_improvements_argmax(dcr_graph *g, int64_t *out_index) {
+    if (!g || !out_index) DCR_FAIL(DCR_EINVAL, "null argument");
+    if (g->imp_n <= 0) DCR_FAIL(DCR_ESTATE, "no candidates from the last dcr_improvements call");
+    DCR_HIP(hipSetDevice(g->device));
+    if (!g->red_scratch) {
+        Ext *p = nullptr;
+        DCR_TRY(dev_alloc(&p, ARGEXT_BLOCKS));
+        g->red_scratch = p;
+    }
+    int64_t blocks = (g->imp_n + 255) / 256;
+    if (blocks > ARGEXT_BLOCKS) blocks = ARGEXT_BLOCKS;
+    hipLaunchKernelGGL(k_argmax_array, dim3((unsigned)blocks), dim3(256), 0, g->stream, g->imp_out, g->imp_n,
+                       (Ext *)g->red_scratch, (int64_t *)nullptr);
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, (const Ext *)g->red_scratch, (int)blocks,
+                       g->dres);
+    DCR_HIP(hipGetLastError());
+    DCR_TRY(sync_result(g));
+    *out_index = g->hres->imp_argmax;
+    return DCR_OK;
+}
+
+int dcr_candidate_at(dcr_graph *g, int64_t index, int32_t *out_i, int32_t *out_j) {
+    if (!g || !out_i || !out_j) DCR_FAIL(DCR_EINVAL, "null argument");
+    if (index < 0 || index >= g->imp_n) DCR_FAIL(DCR_EINVAL, "candidate index out of range");
+    DCR_HIP(hipSetDevice(g->device));
+    DCR_HIP(hipMemcpyAsync(out_i, g->imp_ci + index, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    DCR_HIP(hipMemcpyAsync(out_j, g->imp_cj + index, sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    DCR_HIP(hipStreamSynchronize(g->stream));
+    return DCR_OK;
+}
+
+int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
+                  int32_t out_removed[2], double *out_max_val) {
+    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
+    if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
+    if (add_k >= 0) {
+        if (add_l < 0 || add_k >= g->n || add_l >= g->n || add_k == add_l) DCR_FAIL(DCR_EINVAL, "bad edge to add");
+        if (add_k > add_l) {
+            int32_t t = add_k;
+            add_k = add_l;
+            add_l = t;
+        }
+    }
+    DCR_HIP(hipSetDevice(g->device));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        launch_add_edge(g, add_k, add_l);
+        if (do_remove) {
+            DCR_TRY(launch_argext(g, 1, add_k >= 0 ? add_k : -1, add_k >= 0 ? add_l : -1));
+            launch_remove_if_above(g, removal_bound);
+        }
+        DCR_HIP(hipGetLastError());
+        DCR_TRY(sync_result(g));
+        if (g->hres->add_status != 1) break;
+        if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
+        DCR_TRY(relayout(g));
+    }
+    if (add_k >= 0 && g->hres->add_status == 0) g->n_edges++;
+    int32_t ru = -1, rv = -1;
+    if (do_remove) {
+        ru = g->hres->removed_u;
+        rv = g->hres->removed_v;
+        if (ru >= 0) g->n_edges--;
+        if (out_max_val) *out_max_val = g->hres->ext_slot >= 0 ? g->hres->ext_val : 0.0;
+    }
+    if (out_removed) {
+        out_removed[0] = ru;
+        out_removed[1] = rv;
+    }
+    return DCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""ctypes loader for libdcr_hip.so (the C ABI declared in include/dcr.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible
+the product path raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libdcr_hip.so')
+
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_f64 = ctypes.c_double
+_vp = ctypes.c_void_p
+_i32p = ctypes.POINTER(_i32)
+_i64p = ctypes.POINTER(_i64)
+_f64p = ctypes.POINTER(_f64)
+
+# name -> (restype, argtypes); every symbol include/dcr.h declares
+SIGNATURES = {
+    'dcr_last_error': (ctypes.c_char_p, []),
+    'dcr_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'dcr_graph_create': (ctypes.c_int, [ctypes.c_int, _i64, _i64, _i64p, _i64p, ctypes.POINTER(_vp)]),
+    'dcr_graph_destroy': (ctypes.c_int, [_vp]),
+    'dcr_graph_num_nodes': (ctypes.c_int, [_vp, _i64p]),
+    'dcr_graph_num_edges': (ctypes.c_int, [_vp, _i64p]),
+    'dcr_graph_add_edge': (ctypes.c_int, [_vp, _i32, _i32]),
+    'dcr_graph_remove_edge': (ctypes.c_int, [_vp, _i32, _i32]),
+    'dcr_graph_has_edge': (ctypes.c_int, [_vp, _i32, _i32, ctypes.POINTER(ctypes.c_int)]),
+    'dcr_graph_degree': (ctypes.c_int, [_vp, _i32, _i32p]),
+    'dcr_graph_neighbors': (ctypes.c_int, [_vp, _i32, _i64, _i32p, _i64p]),
+    'dcr_graph_edges': (ctypes.c_int, [_vp, _i32p, _i32p]),
+    'dcr_graph_export_edge_index': (ctypes.c_int, [_vp, _i64p]),
+    'dcr_curvature_pass': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'dcr_curvature_read': (ctypes.c_int, [_vp, _f64p, _i32p, _i32p]),
+    'dcr_curvature_edge': (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_int, _f64p]),
+    'dcr_bfc_ingredients': (ctypes.c_int, [_vp, _i32, _i32, _i64p]),
+    'dcr_argext': (ctypes.c_int, [_vp, ctypes.c_int, _i32, _i32, _i32p, _i32p, _f64p]),
+    'dcr_improvements': (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_int, ctypes.c_int, _i64p, ctypes.POINTER(_f64p),
+                                        ctypes.POINTER(_i32p), ctypes.POINTER(_i32p)]),
+    'dcr_improvements_argmax': (ctypes.c_int, [_vp, _i64p]),
+    'dcr_candidate_at': (ctypes.c_int, [_vp, _i64, _i32p, _i32p]),
+    'dcr_sdrf_tail': (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_int, _f64, _i32p, _f64p]),
+    'dcr_profile_reset': (ctypes.c_int, [_vp]),
+    'dcr_profile_read': (ctypes.c_int, [_vp, _f64p, _i64p]),
+    'dcr_bfc_algorithmic_bytes': (ctypes.c_int, [_vp, _f64p]),
+    'dcr_spmm_csr_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),
+}
+
+_LIB = None
+
+
+class DcrError(RuntimeError):
+    pass
+
+
+def build():
+    """Compile csrc/*.hip for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(['bash', os.path.join(CSRC, 'build.sh')])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DcrError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(there is no CPU fallback for the curvature / SDRF path)')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dcr_last_error().decode('utf-8', 'replace')
+        if rc == -1:
+            raise ValueError(msg)
+        if rc == -5:
+            raise KeyError(msg)
+        raise DcrError(f'libdcr_hip error {rc}: {msg}')

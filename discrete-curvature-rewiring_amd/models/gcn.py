@@ -1,0 +1,265 @@
+"""GCN — call surface of the reference's models/gcn.py:12-44.
+
+``GCN(dataset, hidden=[64], dropout=0.5)`` with ``.layers`` (a ModuleList of
+GCNConv), ``.reg_params`` / ``.non_reg_params`` (gcn.py:22-23),
+``.reset_parameters()`` and ``.forward(data) -> log_softmax [N, C]``.
+
+``GCNConv`` restates torch_geometric 2.0.3's layer (third-party, not vendored
+by the reference; call sites gcn.py:19,30,36): ``gcn_norm`` with self loops,
+``lin`` = bias-free Linear with glorot init (state_dict key ``lin.weight``
+[out, in]), aggregation at the target node, ``bias`` added after aggregation
+(state_dict key ``bias``).  The dense contraction X·Wᵀ runs on the matrix cores
+through the ROCm GEMM library; the sparse aggregation Â·(XWᵀ) + b is the
+hand-written HIP kernel ``dcr_spmm_csr_f32_dev`` (csrc/dcr_gcn.hip), wrapped in
+an autograd Function whose backward is the same kernel on Âᵀ.
+"""
+import ctypes
+import math
+from typing import List
+
+import torch
+from torch.nn import Dropout, ModuleList, Parameter, ReLU
+
+# 'hip': the product path (ROCm tensors only, raises otherwise).
+# 'torch': plain-torch aggregation; selected explicitly by CPU-only tests (gloo) — never automatically.
+_AGG_BACKEND = 'hip'
+
+
+def set_aggregate_backend(name):
+    global _AGG_BACKEND
+    if name not in ('hip', 'torch'):
+        raise ValueError(name)
+    _AGG_BACKEND = name
+
+
+class NormCSR:
+    """Â = D^-1/2 (A + I) D^-1/2 as CSR by target row, plus the CSR of Âᵀ for the backward pass."""
+
+    def __init__(self, rowptr, col, val, rowptr_t, col_t, val_t, n_rows, n_cols):
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.rowptr_t, self.col_t, self.val_t = rowptr_t, col_t, val_t
+        self.n_rows, self.n_cols = n_rows, n_cols
+
+
+def _csr_from_coo(target, source, w, n_rows):
+    perm = torch.argsort(target, stable=True)
+    counts = torch.bincount(target, minlength=n_rows)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=target.device)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    return rowptr, source[perm].to(torch.int32).contiguous(), w[perm].contiguous()
+
+
+def gcn_norm_csr(edge_index, edge_weight=None, num_nodes=None, add_self_loops=True, row_range=None):
+    """PyG 2.0.3 ``gcn_norm`` (flow source_to_target): weights 1 if None;
+    ``add_remaining_self_loops(fill_value=1)``; deg = scatter_add(w, target);
+    norm = deg^-1/2[source] * w * deg^-1/2[target] (inf -> 0).
+
+    ``row_range=(r0, r1)`` keeps only target rows r0..r1-1 (row-partitioned Â for data parallelism);
+    normalisation always uses the full graph's degrees.
+    """
+    row, col = edge_index[0], edge_index[1]
+    n = int(num_nodes)
+    dev = edge_index.device
+    w = torch.ones(row.shape[0], dtype=torch.float32, device=dev) if edge_weight is None else edge_weight.float()
+    if add_self_loops:
+        keep = row != col
+        loop_w = torch.ones(n, dtype=torch.float32, device=dev)
+        if (~keep).any():
+            loop_w[row[~keep]] = w[~keep]
+        ar = torch.arange(n, dtype=row.dtype, device=dev)
+        row = torch.cat([row[keep], ar])
+        col = torch.cat([col[keep], ar])
+        w = torch.cat([w[keep], loop_w])
+    deg = torch.zeros(n, dtype=torch.float32, device=dev).scatter_add_(0, col, w)
+    dinv = deg.pow(-0.5)
+    dinv[torch.isinf(dinv)] = 0
+    norm = dinv[row] * w * dinv[col]
+    if row_range is not None:
+        r0, r1 = row_range
+        sel = (col >= r0) & (col < r1)
+        row, col, norm = row[sel], col[sel] - r0, norm[sel]
+        n_rows = r1 - r0
+    else:
+        n_rows = n
+    rowptr, cidx, val = _csr_from_coo(col, row, norm, n_rows)          # Â: rows = targets
+    rowptr_t, cidx_t, val_t = _csr_from_coo(row, col, norm, n)          # Âᵀ: rows = sources
+    return NormCSR(rowptr, cidx, val, rowptr_t, cidx_t, val_t, n_rows, n)
+
+
+def _spmm_hip(rowptr, col, val, B, n_rows, bias=None, relu=False):
+    if not B.is_cuda:
+        raise RuntimeError('GCN aggregation runs on the MI355X HIP kernel: move the model and data to a ROCm '
+                           'device (there is no CPU fallback)')
+    from dcr import _lib
+    B = B.contiguous()
+    if B.dtype != torch.float32:
+        raise TypeError('dcr_spmm_csr_f32_dev is fp32')
+    F = B.shape[1]
+    C = torch.empty((n_rows, F), dtype=torch.float32, device=B.device)
+    stream = torch.cuda.current_stream(B.device).cuda_stream
+    rc = _lib.lib().dcr_spmm_csr_f32_dev(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), B.data_ptr(),
+                                         C.data_ptr(), n_rows, F, F, F,
+                                         bias.data_ptr() if bias is not None else None, int(relu),
+                                         ctypes.c_void_p(stream))
+    _lib.check(rc)
+    return C
+
+
+def _spmm_torch(rowptr, col, val, B, n_rows, bias=None, relu=False):
+    counts = rowptr[1:] - rowptr[:-1]
+    tgt = torch.repeat_interleave(torch.arange(n_rows, device=B.device), counts)
+    out = torch.zeros((n_rows, B.shape[1]), dtype=B.dtype, device=B.device)
+    out.index_add_(0, tgt, B[col.long()] * val[:, None])
+    if bias is not None:
+        out = out + bias
+    return torch.relu(out) if relu else out
+
+
+def spmm(rowptr, col, val, B, n_rows, bias=None, relu=False):
+    fn = _spmm_hip if _AGG_BACKEND == 'hip' else _spmm_torch
+    return fn(rowptr, col, val, B, n_rows, bias, relu)
+
+
+class _Aggregate(torch.autograd.Function):
+    """out = Â·Z + b ; dZ = Âᵀ·dout ; db = Σ_rows dout."""
+
+    @staticmethod
+    def forward(ctx, z, bias, csr):
+        ctx.csr = csr
+        ctx.has_bias = bias is not None
+        return spmm(csr.rowptr, csr.col, csr.val, z, csr.n_rows, bias=bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        csr = ctx.csr
+        grad_out = grad_out.contiguous()
+        gz = spmm(csr.rowptr_t, csr.col_t, csr.val_t, grad_out, csr.n_cols) if ctx.needs_input_grad[0] else None
+        gb = grad_out.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gz, gb, None
+
+
+def aggregate(z, bias, csr):
+    return _Aggregate.apply(z, bias, csr)
+
+
+class _Linear(torch.nn.Module):
+    """torch_geometric.nn.dense.linear.Linear(in, out, bias=False, weight_initializer='glorot')."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.empty(out_channels, in_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        a = math.sqrt(6.0 / (self.in_channels + self.out_channels))  # glorot
+        with torch.no_grad():
+            self.weight.uniform_(-a, a)
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight)
+
+
+class GCNConv(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, add_self_loops=True, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.add_self_loops = add_self_loops
+        self.lin = _Linear(in_channels, out_channels)
+        if bias:
+            self.bias = Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._cache_key = None
+        self._cache_csr = None
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+        self._cache_key = self._cache_csr = None
+
+    def norm_csr(self, edge_index, edge_weight, num_nodes):
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+               None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version), str(edge_index.device))
+        if key != self._cache_key:
+            self._cache_csr = gcn_norm_csr(edge_index, edge_weight, num_nodes, self.add_self_loops)
+            self._cache_key = key
+        return self._cache_csr
+
+    def forward(self, x, edge_index, edge_weight=None):
+        csr = self.norm_csr(edge_index, edge_weight, x.shape[0])
+        z = self.lin(x)                       # dense contraction on MFMA via the GEMM library
+        return aggregate(z, self.bias, csr)   # sparse aggregation + bias: HIP kernel
+
+
+class GCN(torch.nn.Module):
+    def __init__(self, dataset, hidden: List[int] = [64], dropout: float = 0.5):
+        super(GCN, self).__init__()
+
+        num_features = [dataset.data.x.shape[1]] + hidden + [dataset.num_classes]
+        layers = []
+        for in_features, out_features in zip(num_features[:-1], num_features[1:]):
+            layers.append(GCNConv(in_features, out_features))
+        self.layers = ModuleList(layers)
+
+        self.reg_params = list(layers[0].parameters())
+        self.non_reg_params = list([p for l in layers[1:] for p in l.parameters()])
+
+        self.dropout = Dropout(p=dropout)
+        self.act_fn = ReLU()
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            layer.reset_parameters()
+
+    def forward(self, data):
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+
+        for i, layer in enumerate(self.layers):
+            x = layer(x, edge_index, edge_weight=edge_attr)
+
+            if i == len(self.layers) - 1:
+                break
+
+            x = self.act_fn(x)
+            x = self.dropout(x)
+
+        return torch.nn.functional.log_softmax(x, dim=1)
+
+
+def dense_reference_logits(model, x, edge_index, num_nodes):
+    """Dense fp64 restatement Â = D^-1/2 (A+I) D^-1/2, log_softmax(Â·relu(Â·X·W1ᵀ+b1)·W2ᵀ+b2) in eval mode —
+    the build's own pin for GCNConv."""
+    n = num_nodes
+    A = torch.zeros((n, n), dtype=torch.float64, device=x.device)
+    A[edge_index[1], edge_index[0]] = 1.0
+    A = A + torch.eye(n, dtype=torch.float64, device=x.device)
+    dinv = A.sum(1).pow(-0.5)
+    Ah = dinv[:, None] * A * dinv[None, :]
+    h = x.double()
+    for i, layer in enumerate(model.layers):
+        h = Ah @ (h @ layer.lin.weight.double().t()) + layer.bias.double()
+        if i < len(model.layers) - 1:
+            h = torch.relu(h)
+    return torch.log_softmax(h, dim=1)
+
+
+def smoke_gcn(edge_index, num_nodes, device='cuda:0'):
+    from dcr.data import Data, Dataset
+    torch.manual_seed(0)
+    x = torch.randn(num_nodes, 32)
+    y = torch.randint(0, 5, (num_nodes,))
+    data = Data(x=x, edge_index=edge_index, y=y, num_nodes=num_nodes).to(device)
+    model = GCN(Dataset(data, 5), hidden=[16], dropout=0.5).to(device)
+    model.eval()
+    got = model(data)
+    want = dense_reference_logits(model, data.x, data.edge_index, num_nodes)
+    err = (got.double() - want).abs().max().item()
+    assert err < 1e-5, f'GCN logits differ from the dense reference by {err}'
+    model.train()
+    loss = torch.nn.functional.nll_loss(model(data), data.y)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    return err

@@ -1,0 +1,103 @@
+"""SDRF rewiring loop — call surface of the reference's rewiring/sdrf_no_cuda.py:9-68.
+
+Same signature, same loop, same results (edge list bit-identical for a given
+``np.random.seed``); every step that touches the graph runs on the MI355X:
+
+  reference line                       here
+  :20  to_networkx                     DcrGraph.from_data  (HBM-resident rows, insertion order)
+  :24  compute_curvature_graph         G.curvature_pass    (csrc/dcr_bfc.hip)
+  :27  min(G.edges, key=...)           G.argext(False)     (wavefront reduction, first minimum)
+  :29-46 candidates + improvements     G.improvements      (csrc/dcr_sdrf.hip)
+  :49-50 softmax + np.random.choice    host numpy, unchanged (bit-exact draw)
+  :51,57-66 add / stale arg-max / remove   G.sdrf_tail     (one fused device step)
+  :68  from_networkx                   G.to_edge_index
+
+``curv_type='bfc'`` is accepted in addition to the reference's classical kinds
+(the reference raises there; BASELINE.json names this composition as the parity
+target).  ``trace`` (optional list) receives one dict per iteration.
+"""
+import numpy as np
+
+from dcr.graph import DcrGraph, curv_code
+from utils.softmax import softmax
+
+
+def _make_data(data, edge_index):
+    import torch
+    ei = torch.from_numpy(edge_index)
+    try:
+        from torch_geometric.data import Data as PygData  # real PyG when installed
+        return PygData(x=getattr(data, 'x', None), edge_index=ei)
+    except Exception:
+        from dcr.data import Data
+        return Data(x=getattr(data, 'x', None), edge_index=ei, num_nodes=data.num_nodes)
+
+
+def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0):
+    """
+    Perform SDRF graph rewiring using the given discrete curvature type.
+    :param data: data to be rewired (undirected by default in this work).
+    :param curv_type: '1d' | 'augmented' | 'haantjes' | 'bfc'.
+    :param loops: number of edge addition/deletion iterations.
+    :param remove_edges: whether to delete highly curved edges each iteration to compensate for the addition.
+    :param removal_bound: curvature lower bound of deleting edges (delete edges only with higher curvature).
+    :param tau: softmax temperature for choosing the edge to add; if infinite, the max value is chosen.
+    :return: rewired data.
+    """
+    curv_code(curv_type)
+    G = DcrGraph.from_data(data, device=device)
+    want_trace = trace is not None
+
+    for _ in range(loops):
+        can_add = True
+        G.curvature_pass(curv_type)
+
+        # Choose the edge with the lowest curvature (first minimum in G.edges order).
+        try:
+            x, y, _ = G.argext(False)
+        except KeyError:
+            raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
+        rec = {'argmin': [x, y]} if want_trace else None
+
+        k = l = None
+        if tau == float('inf') and not want_trace:
+            # softmax is one-hot at the first arg-max (utils/softmax.py:5-8): the draw is that
+            # index whatever the uniform is; consume the one double np.random.choice would.
+            n_cand = G.improvements_count(x, y, curv_type)
+            if n_cand:
+                idx = G.improvements_argmax()
+                np.random.random_sample()
+                k, l = G.candidate_at(idx)
+        else:
+            imp, ci, cj = G.improvements(x, y, curv_type, want_candidates=want_trace)
+            n_cand = imp.shape[0]
+            if n_cand:
+                idx = int(np.random.choice(n_cand, p=softmax(np.array(imp), tau=tau)))
+                if want_trace:
+                    k, l = int(ci[idx]), int(cj[idx])
+                    rec['candidates'] = np.stack([ci, cj], 1).tolist()
+                    rec['improvements'] = imp.tolist()
+                    rec['choice'] = idx
+                else:
+                    k, l = G.candidate_at(idx)
+        if want_trace and not n_cand:
+            rec.update(candidates=[], improvements=[], choice=None)
+
+        if not n_cand:
+            can_add = False
+            if not remove_edges:
+                if want_trace:
+                    rec.update(added=None, removed=None)
+                    trace.append(rec)
+                break
+
+        # add (k, l); then the stale arg-max (excluding the new edge) is removed if above the bound
+        removed, _ = G.sdrf_tail((k, l) if n_cand else None, remove_edges, removal_bound)
+        if want_trace:
+            rec['added'] = [k, l] if n_cand else None
+            rec['removed'] = list(removed) if removed else None
+            trace.append(rec)
+        if remove_edges and removed is None and can_add is False:
+            break
+
+    return _make_data(data, G.to_edge_index())

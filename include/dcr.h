@@ -1,0 +1,134 @@
+/*
+ * dcr.h — C ABI of libdcr_hip.so: MI355X (gfx950) Balanced Forman curvature,
+ * SDRF rewiring primitives and the GCN sparse aggregation.
+ *
+ * The reference (jakubbober/discrete-curvature-rewiring) is pure Python and has
+ * no FFI of its own; its only native launches are numba kernels taking torch
+ * CUDA tensors (curvature/bfc_cuda.py:64,157).  This header is the boundary a
+ * maintainer binds with ctypes underneath the reference's Python call surface
+ * (see INTEGRATION.md).  Each entry point names the reference code it replaces
+ * (file:line into the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DCR_E* code on failure;
+ *     dcr_last_error() returns a thread-local message for the last failure;
+ *   - plain pointers and sizes only; HOST pointers unless the name says _dev;
+ *   - the caller owns every buffer it passes in; buffers returned through
+ *     `const T**` are library-owned pinned host memory, valid until the next
+ *     call on the same handle;
+ *   - a dcr_graph handle is not thread-safe; distinct handles are independent;
+ *   - all calls are synchronous on return (the library owns one HIP stream
+ *     per handle) unless documented otherwise.
+ */
+#ifndef DCR_H
+#define DCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dcr_graph dcr_graph;
+
+enum {
+    DCR_OK = 0,
+    DCR_EINVAL = -1,   /* bad argument (self-loop, id out of range, ...)        */
+    DCR_ENOMEM = -2,   /* host or device allocation failed                      */
+    DCR_EHIP = -3,     /* a HIP runtime call or kernel failed                   */
+    DCR_ECAPACITY = -4,/* caller buffer too small / degree beyond kernel limit  */
+    DCR_ENOTFOUND = -5,/* edge not present                                      */
+    DCR_ESTATE = -6    /* call sequence error (e.g. argext before a pass)       */
+};
+
+/* curvature kinds: curvature/bfc_naive.py:7 and curvature/classical_curvatures.py:14-28 */
+enum { DCR_CURV_BFC = 0, DCR_CURV_1D = 1, DCR_CURV_AUGMENTED = 2, DCR_CURV_HAANTJES = 3 };
+
+const char *dcr_last_error(void);
+int dcr_device_count(int *out);
+
+/* ---- graph container ------------------------------------------------------
+ * Replaces the nx.Graph built by torch_geometric.utils.to_networkx(data,
+ * to_undirected=True) at rewiring/sdrf_no_cuda.py:20: walks (src[e], dst[e]) in
+ * order, keeps pairs with dst <= src, appends each new neighbour at the end of
+ * both adjacency rows (insertion order is part of the contract: SURVEY §8 A5).
+ * Rows live in HBM as slack-padded int32 arrays in insertion order. */
+int dcr_graph_create(int device, int64_t num_nodes, int64_t m_directed, const int64_t *src, const int64_t *dst,
+                     dcr_graph **out);
+int dcr_graph_destroy(dcr_graph *g);
+int dcr_graph_num_nodes(const dcr_graph *g, int64_t *out);
+int dcr_graph_num_edges(const dcr_graph *g, int64_t *out_undirected);
+
+/* G.add_edge / G.remove_edge / G.has_edge / G.degree — sdrf_no_cuda.py:35,43,46,51,63 */
+int dcr_graph_add_edge(dcr_graph *g, int32_t u, int32_t v);
+int dcr_graph_remove_edge(dcr_graph *g, int32_t u, int32_t v);
+int dcr_graph_has_edge(dcr_graph *g, int32_t u, int32_t v, int *out);
+int dcr_graph_degree(dcr_graph *g, int32_t u, int32_t *out);
+/* list(G.neighbors(u)) in insertion order — sdrf_no_cuda.py:29-30 */
+int dcr_graph_neighbors(dcr_graph *g, int32_t u, int64_t cap, int32_t *out, int64_t *n_out);
+
+/* G.edges enumeration order — sdrf_no_cuda.py:27,59,61; out_u/out_v sized num_edges */
+int dcr_graph_edges(dcr_graph *g, int32_t *out_u, int32_t *out_v);
+/* from_networkx(G).edge_index — sdrf_no_cuda.py:68; out is int64 [2][2*num_edges] */
+int dcr_graph_export_edge_index(dcr_graph *g, int64_t *out2xM);
+
+/* ---- curvature ------------------------------------------------------------ */
+/* One full pass: compute_curvature_graph(G, curv_type), sdrf_no_cuda.py:24
+ * (classical_curvatures.py:38-46; 'bfc' = bfc_naive.bfc(G), bfc_naive.py:43-52).
+ * Values stay in HBM, keyed by adjacency slot; the stale-read semantics of
+ * sdrf_no_cuda.py:57-61 follow from later calls reading that buffer. */
+int dcr_curvature_pass(dcr_graph *g, int curv_type);
+/* Copy the last pass out in G.edges order (float64 per undirected edge). */
+int dcr_curvature_read(dcr_graph *g, double *out_curv, int32_t *out_u, int32_t *out_v);
+/* bfc_edge(G, v1, v2), bfc_naive.py:7-40 / compute_curvature_edge, classical_curvatures.py:6 */
+int dcr_curvature_edge(dcr_graph *g, int32_t u, int32_t v, int curv_type, double *out);
+/* integer ingredients of bfc_edge: d1,d2,triangles,|sq1|,|sq2|,gamma (diagnostic / tests) */
+int dcr_bfc_ingredients(dcr_graph *g, int32_t u, int32_t v, int64_t out6[6]);
+
+/* min(G.edges, key=curv) / max([e for e in G.edges if e != (k,l)], key=curv):
+ * first extremum in G.edges order over the buffer of the last pass
+ * (sdrf_no_cuda.py:27,59,61).  excl_u < 0 means no exclusion. */
+int dcr_argext(dcr_graph *g, int want_max, int32_t excl_u, int32_t excl_v, int32_t *out_u, int32_t *out_v,
+               double *out_val);
+
+/* Candidate set and improvements for edge (x, y): sdrf_no_cuda.py:29-46.
+ * Candidates are produced in the reference's nested-loop order (duplicates
+ * kept) as sorted pairs; improvement[c] = curv(x,y | G + cand[c]) - curv(x,y | G).
+ * *n_out is the candidate count; the three arrays are library-owned pinned
+ * host buffers (cand arrays are filled only if want_candidates != 0). */
+int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want_candidates, int64_t *n_out,
+                     const double **out_improvement, const int32_t **out_ci, const int32_t **out_cj);
+/* first index of the maximum improvement of the last dcr_improvements call
+ * (np.argmax, utils/softmax.py:7) and the candidate pair at any index */
+int dcr_improvements_argmax(dcr_graph *g, int64_t *out_index);
+int dcr_candidate_at(dcr_graph *g, int64_t index, int32_t *out_i, int32_t *out_j);
+
+/* Tail of one SDRF iteration, sdrf_no_cuda.py:51,56-66, fused on the device:
+ * add (k,l) if add_k >= 0; then, if do_remove, take the first maximum of the
+ * stale buffer (excluding (k,l) when it was added) and remove that edge iff
+ * its value > removal_bound.  out_removed = {u, v} or {-1,-1}; out_max_val =
+ * the maximum examined. */
+int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
+                  int32_t out_removed[2], double *out_max_val);
+
+/* Timing hooks for bench.py: accumulated device time (HIP events on the
+ * handle's stream) of the curvature-pass kernels since the last reset. */
+int dcr_profile_reset(dcr_graph *g);
+int dcr_profile_read(dcr_graph *g, double *pass_ms_total, int64_t *pass_count);
+/* SURVEY §8(d) algorithmic bytes of one BFC pass on the current graph. */
+int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes);
+
+/* ---- GCN aggregation (device pointers, caller's stream) --------------------
+ * Replaces the propagate/scatter step of torch_geometric GCNConv (third-party,
+ * call site models/gcn.py:36): C[i,:] = (bias ? bias : 0) + sum_e val[e] * B[col[e],:]
+ * over CSR row i, optionally followed by ReLU.  fp32, row-major; ldb/ldc in
+ * elements.  Rows are accumulated in CSR order with fused multiply-adds, so the
+ * result is deterministic for a given CSR.  Asynchronous on hip_stream. */
+int dcr_spmm_csr_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev,
+                         const float *B_dev, float *C_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
+                         const float *bias_dev, int relu, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCR_H */

@@ -125,15 +125,30 @@ int64_t dcro_num_edges(const dcro_graph *g) {
     return s / 2;
 }
 
-/* from_networkx: for u in node order, v in adj[u] order. out is [2][M]. */
+static int cmp_i32(const void *a, const void *b) {
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* from_networkx: convert_node_labels_to_integers re-adds the edges in G.edges order, so row u
+   lists its smaller neighbours ascending, then its larger ones in adj[u] order. out is [2][M]. */
 int dcro_export_edge_index(const dcro_graph *g, int64_t *out) {
     int64_t M = 2 * dcro_num_edges(g), p = 0;
-    for (int64_t u = 0; u < g->n; ++u)
-        for (int32_t i = 0; i < g->rows[u].deg; ++i) {
-            out[p] = u;
-            out[M + p] = g->rows[u].nbr[i];
-            ++p;
+    for (int64_t u = 0; u < g->n; ++u) {
+        const row_t *r = &g->rows[u];
+        int64_t p0 = p;
+        for (int32_t i = 0; i < r->deg; ++i)
+            if (r->nbr[i] < u) { out[p] = u; out[M + p] = r->nbr[i]; ++p; }
+        /* sort the smaller neighbours (stored as int64): small rows, insertion sort is fine */
+        for (int64_t a = p0 + 1; a < p; ++a) {
+            int64_t key = out[M + a], b = a - 1;
+            while (b >= p0 && out[M + b] > key) { out[M + b + 1] = out[M + b]; --b; }
+            out[M + b + 1] = key;
         }
+        for (int32_t i = 0; i < r->deg; ++i)
+            if (r->nbr[i] > u) { out[p] = u; out[M + p] = r->nbr[i]; ++p; }
+    }
+    (void)cmp_i32;
     return 0;
 }
 

@@ -80,10 +80,14 @@ class OGraph:
         return sum(len(a) for a in self.adj) // 2
 
     def to_edge_index(self):
-        # from_networkx: G.to_directed().edges -> for u in node order, v in adj[u] order
+        # from_networkx: convert_node_labels_to_integers rebuilds the graph by adding edges in
+        # G.edges order, so row u holds first its smaller neighbours (ascending: one edge per
+        # earlier outer node), then its larger ones in adj[u] order; to_directed().edges then
+        # walks rows in node order.
         src, dst = [], []
         for u in range(self.n):
-            for v in self.adj[u]:
+            row = sorted(v for v in self.adj[u] if v < u) + [v for v in self.adj[u] if v > u]
+            for v in row:
                 src.append(u)
                 dst.append(v)
         return np.array([src, dst], dtype=np.int64).reshape(2, -1)
