@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — SDRF iterations/sec (+ BFC edges/sec, roofline, CPU baseline) on the north-star graph.
+
+A "step" is ONE SDRF iteration (rewiring/sdrf_no_cuda.py:22-66) in full-recompute mode on the synthetic
+power-law graph S100k (N=100,000, m=10, E=999,900; BASELINE.json configs[2]): a full Balanced Forman pass over
+every edge, arg-min, candidate/improvement tensor, host softmax draw, add, stale arg-max, conditional remove.
+The graph is resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+
+SDRF is inherently sequential (each iteration depends on the previous graph), so with N > 1 every rank runs an
+independent replica (its own numpy seed) — "replicas only", no data-path collective; value = N*K / max-rank time.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, 'discrete-curvature-rewiring_amd')
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(ei, n, E, budget_s=12.0):
+    """The CPU oracle (oracle/dcr_oracle.c, kind="port") timed on this box's host cores on a bounded sample."""
+    from oracle import c_oracle
+    cores = len(os.sched_getaffinity(0))
+    C = c_oracle.CGraph(ei, n)
+    eu, ev = C.edges()
+    rng = np.random.Generator(np.random.PCG64(2024))
+    probe = rng.choice(E, size=min(E, 4000), replace=False)
+    t0 = time.perf_counter()
+    C.curv_edges(eu[probe], ev[probe], 'bfc', nthreads=cores)
+    t_probe = time.perf_counter() - t0
+    n_sample = int(min(E, max(4000, budget_s * 0.7 / max(t_probe / len(probe), 1e-9))))
+    pick = rng.choice(E, size=n_sample, replace=False)
+    t0 = time.perf_counter()
+    cv = C.curv_edges(eu[pick], ev[pick], 'bfc', nthreads=cores)
+    t_pass = time.perf_counter() - t0
+    edges_per_s = n_sample / t_pass
+    pass_s = E / edges_per_s
+    # improvements for the most negatively curved sampled edge: literal add/recompute/remove, serial as in the loop
+    m = int(np.argmin(cv))
+    x, y = int(eu[pick[m]]), int(ev[pick[m]])
+    ci, cj = C.candidates(x, y)
+    n_cand = len(ci)
+    k = min(n_cand, 300)
+    imp_s = 0.0
+    if k:
+        sel = np.sort(rng.choice(n_cand, size=k, replace=False))
+        t0 = time.perf_counter()
+        C.improvements(x, y, ci[sel], cj[sel], 'bfc')
+        imp_s = (time.perf_counter() - t0) * n_cand / k
+    iter_s = pass_s + imp_s
+    return {
+        'value': 1.0 / iter_s, 'unit': 'SDRF iterations/sec', 'cores': cores, 'kind': 'port',
+        'sample': f'BFC pass over {n_sample} of {E} randomly sampled edges on {cores} threads (extrapolated x{E / n_sample:.1f}) '
+                  f'+ {k} of {n_cand} candidate improvements of edge ({x},{y}) on 1 thread (extrapolated)',
+        'bfc_edges_per_sec': edges_per_s, 'pass_seconds_extrapolated': pass_s, 'improvements_seconds_extrapolated': imp_s,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--nodes', type=int, default=100000)
+    ap.add_argument('--m', type=int, default=10)
+    ap.add_argument('--tau', type=float, default=163.0)
+    ap.add_argument('--removal-bound', type=float, default=0.95)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from dcr import synthetic
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import SdrfRun
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the measured path)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ei, n = synthetic.powerlaw_graph(args.nodes, args.m, seed=12345)
+    E = ei.shape[1] // 2
+    data = Data(edge_index=torch.from_numpy(ei), num_nodes=n)
+    run = SdrfRun(data, 'bfc', True, args.removal_bound, args.tau, device=local_rank)
+    G = run.G
+    np.random.seed(rank)  # replica seed; rank 0 matches BASELINE.md's np.random.seed(0)
+
+    for _ in range(args.warmup):
+        run.step()
+    bytes0 = G.bfc_algorithmic_bytes()
+    G.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    steps_done = 0
+    for _ in range(args.steps):
+        steps_done += 1
+        if not run.step():
+            break
+    barrier()
+    elapsed = time.perf_counter() - t0
+    pass_ms_total, pass_count = G.profile_read()
+    bytes1 = G.bfc_algorithmic_bytes()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([steps_done], dtype=torch.int64, device='cuda')
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        total_steps = int(s.item())
+    else:
+        total_steps = steps_done
+
+    if rank == 0:
+        pass_ms = pass_ms_total / max(pass_count, 1)
+        alg_bytes = 0.5 * (bytes0 + bytes1)
+        achieved = alg_bytes / (pass_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'SDRF iterations/sec', 'value': total_steps / elapsed, 'unit': 'iterations/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / max(steps_done, 1) * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'S100k: preferential-attachment graph N={n} m={args.m} E={E} (PCG64 seed 12345), '
+                                   f'Balanced Forman curvature, full recompute every iteration, remove_edges=True, '
+                                   f'tau={args.tau}, removal_bound={args.removal_bound}',
+                       'parallelism': 'replicas only' if world > 1 else 'single GPU'},
+            'bfc_edges_per_sec': E / (pass_ms * 1e-3),
+            'bfc_pass_ms': pass_ms,
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'curvature pass = k_classify + k_edge_pass<bin 0..4>',
+                         'algorithmic_bytes_per_launch': alg_bytes, 'launch_ms': pass_ms, 'launches': pass_count},
+        }
+        ref_fix = os.path.join(REPO, 'tests', 'golden', 'reference_timing_s100k.json')
+        if os.path.exists(ref_fix) and args.nodes == 100000 and args.m == 10:
+            with open(ref_fix) as f:
+                r = json.load(f)
+            out['reference_cpu_extrapolated'] = {
+                'bfc_edges_per_sec': r['edges_per_sec'], 'pass_seconds': r['extrapolated_pass_seconds'],
+                'note': 'reference bfc_naive.bfc_edge itself, timed in the build container on sampled edges of this '
+                        'same graph (tools/make_golden.py); the Python reference cannot travel to the GPU box'}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(ei, n, E)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -33,22 +33,23 @@ def _make_data(data, edge_index):
         return Data(x=getattr(data, 'x', None), edge_index=ei, num_nodes=data.num_nodes)
 
 
-def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0):
-    """
-    Perform SDRF graph rewiring using the given discrete curvature type.
-    :param data: data to be rewired (undirected by default in this work).
-    :param curv_type: '1d' | 'augmented' | 'haantjes' | 'bfc'.
-    :param loops: number of edge addition/deletion iterations.
-    :param remove_edges: whether to delete highly curved edges each iteration to compensate for the addition.
-    :param removal_bound: curvature lower bound of deleting edges (delete edges only with higher curvature).
-    :param tau: softmax temperature for choosing the edge to add; if infinite, the max value is chosen.
-    :return: rewired data.
-    """
-    curv_code(curv_type)
-    G = DcrGraph.from_data(data, device=device)
-    want_trace = trace is not None
+class SdrfRun:
+    """One SDRF rewiring run, steppable: ``step()`` is one iteration of the loop body
+    sdrf_no_cuda.py:22-66 and returns False when the reference loop would ``break``."""
 
-    for _ in range(loops):
+    def __init__(self, data, curv_type, remove_edges, removal_bound, tau, trace=None, device=0):
+        curv_code(curv_type)
+        self.data = data
+        self.curv_type = curv_type
+        self.remove_edges = remove_edges
+        self.removal_bound = removal_bound
+        self.tau = tau
+        self.trace = trace
+        self.G = DcrGraph.from_data(data, device=device)
+
+    def step(self):
+        G, curv_type, tau, trace = self.G, self.curv_type, self.tau, self.trace
+        want_trace = trace is not None
         can_add = True
         G.curvature_pass(curv_type)
 
@@ -85,19 +86,39 @@ def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace
 
         if not n_cand:
             can_add = False
-            if not remove_edges:
+            if not self.remove_edges:
                 if want_trace:
                     rec.update(added=None, removed=None)
                     trace.append(rec)
-                break
+                return False
 
         # add (k, l); then the stale arg-max (excluding the new edge) is removed if above the bound
-        removed, _ = G.sdrf_tail((k, l) if n_cand else None, remove_edges, removal_bound)
+        removed, _ = G.sdrf_tail((k, l) if n_cand else None, self.remove_edges, self.removal_bound)
         if want_trace:
             rec['added'] = [k, l] if n_cand else None
             rec['removed'] = list(removed) if removed else None
             trace.append(rec)
-        if remove_edges and removed is None and can_add is False:
-            break
+        if self.remove_edges and removed is None and can_add is False:
+            return False
+        return True
 
-    return _make_data(data, G.to_edge_index())
+    def result(self):
+        return _make_data(self.data, self.G.to_edge_index())
+
+
+def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0):
+    """
+    Perform SDRF graph rewiring using the given discrete curvature type.
+    :param data: data to be rewired (undirected by default in this work).
+    :param curv_type: '1d' | 'augmented' | 'haantjes' | 'bfc'.
+    :param loops: number of edge addition/deletion iterations.
+    :param remove_edges: whether to delete highly curved edges each iteration to compensate for the addition.
+    :param removal_bound: curvature lower bound of deleting edges (delete edges only with higher curvature).
+    :param tau: softmax temperature for choosing the edge to add; if infinite, the max value is chosen.
+    :return: rewired data.
+    """
+    run = SdrfRun(data, curv_type, remove_edges, removal_bound, tau, trace=trace, device=device)
+    for _ in range(loops):
+        if not run.step():
+            break
+    return run.result()
