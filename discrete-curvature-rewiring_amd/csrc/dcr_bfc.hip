@@ -15,6 +15,9 @@
 //   4. lane 0 evaluates the float64 closing expression in the reference's order (bfc_naive.py:31-40)
 // u and v themselves are stored with both tags, which removes them from every set difference the
 // reference writes out explicitly (k != v2, "- (S1 ∪ {v1})", the "- 1" in gamma).
+#include <cstdio>
+#include <cstdlib>
+
 #include "dcr_internal.h"
 
 namespace dcr {
@@ -30,7 +33,18 @@ struct View {
     const int2 *rowinfo;
     const int32_t *col;
     const int32_t *slot_row;
+    int64_t cap_total;
+    int32_t *guard;  // [8] first violated invariant: code, block, item data (debug / safety net)
 };
+
+__device__ inline bool row_ok(const View &g, const int2 rk, int code, int a, int b) {
+    const bool ok = rk.x >= 0 && rk.y >= 0 && (int64_t)rk.x + rk.y <= g.cap_total;
+    if (!ok && atomicCAS(&g.guard[0], 0, code) == 0) {
+        g.guard[1] = rk.x; g.guard[2] = rk.y; g.guard[3] = a; g.guard[4] = b; g.guard[5] = blockIdx.x;
+        g.guard[6] = threadIdx.x;
+    }
+    return ok;
+}
 
 struct WorkLists {
     int32_t *w[NBINS];
@@ -94,11 +108,21 @@ struct Ingredients {
 };
 
 // Whole team cooperates; the result is valid in thread 0.
-template <int SLOTS, int TEAM, int MODE>
-__device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsigned *tab, int *red) {
+constexpr int LONG_ROW = 48;  // rows longer than this are streamed by a whole wave, shorter ones by 16 lanes
+
+template <int SLOTS, int TEAM, int MODE, int DESC_CAP>
+__device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsigned *tab, int *red, int2 *desc,
+                                               int *cnts) {
     constexpr int NW = TEAM / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int2 ru = g.rowinfo[u], rv = g.rowinfo[v];
+    int2 ru = g.rowinfo[u], rv = g.rowinfo[v];
+    if (!row_ok(g, ru, 3, u, v)) ru = make_int2(0, 0);
+    if (!row_ok(g, rv, 4, u, v)) rv = make_int2(0, 0);
+    if (ru.y + rv.y + 2 > (DESC_CAP > 0 ? DESC_CAP : SLOTS / 2)) {
+        row_ok(g, make_int2(-1, ru.y + rv.y), 5, u, v);
+        ru.y = 0;
+        rv.y = 0;
+    }
     const int32_t *rowu = g.col + ru.x, *rowv = g.col + rv.x;
 
     for (int i = tid; i < SLOTS; i += TEAM) tab[i] = EMPTY;
@@ -164,34 +188,142 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
         const int deg = side == 0 ? ru.y : rv.y;
         const unsigned mine = side == 0 ? 1u : 2u;    // tag pattern (>>30) of "only this side"
         const unsigned other = side == 0 ? 2u : 1u;
-        int scount = 0;
-        for (int p = wid; p < deg; p += NW) {
-            const int k = row[p];
-            const unsigned ek = table_lookup<SLOTS>(tab, (unsigned)k);
-            if ((ek >> 30) != mine) continue;  // triangle node, or the edge's own endpoint
-            const int2 rk = g.rowinfo[k];
-            const int32_t *rowk = g.col + rk.x;
-            if (MODE == MODE_BYTES) {
-                rows_len += rk.y;
-                rows_cnt += 1;
-                continue;
+        int scount = 0;  // per-lane partial: rows owned by this lane that close at least one 4-cycle
+        if (DESC_CAP > 0) {
+            // (a) descriptor build, lane-parallel: every member of this side's difference set gets its
+            //     {row start, row length} fetched at once; short rows are listed from the front of desc[],
+            //     long rows from the back.
+            if (tid == 0) {
+                cnts[0] = 0;
+                cnts[1] = 0;
             }
-            int c = 0;
-            for (int base = 0; base < rk.y; base += 64) {
-                const int i = base + lane;
-                bool hit = false;
-                if (i < rk.y) {
-                    const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[i]);
-                    hit = (e != EMPTY) && ((e >> 30) == other);
+            team_sync<TEAM>();
+            for (int p0 = 0; p0 < deg; p0 += TEAM) {
+                const int p = p0 + tid;
+                bool want = false;
+                int2 rk = make_int2(0, 0);
+                if (p < deg) {
+                    const int k = row[p];
+                    const unsigned ek = table_lookup<SLOTS>(tab, (unsigned)k);
+                    if ((ek >> 30) == mine) {  // not a triangle node, not the edge's own endpoint
+                        rk = g.rowinfo[k];
+                        want = true;
+                    }
                 }
-                c += __popcll(__ballot(hit));
+                const bool is_long = want && rk.y > LONG_ROW;
+                const bool is_short = want && !is_long;
+                const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (ms) {
+                    int base = 0;
+                    const int leader = __ffsll((long long)ms) - 1;
+                    if (lane == leader) base = atomicAdd(&cnts[0], __popcll(ms));
+                    base = __shfl(base, leader);
+                    if (is_short) desc[base + __popcll(ms & below)] = rk;
+                }
+                if (ml) {
+                    int base = 0;
+                    const int leader = __ffsll((long long)ml) - 1;
+                    if (lane == leader) base = atomicAdd(&cnts[1], __popcll(ml));
+                    base = __shfl(base, leader);
+                    if (is_long) desc[DESC_CAP - 1 - (base + __popcll(ml & below))] = rk;
+                }
             }
-            if (c > 0) {
-                ++scount;
-                gam = c > gam ? c : gam;
+            team_sync<TEAM>();
+            const int nshort = __builtin_amdgcn_readfirstlane(cnts[0]);
+            const int nlong = __builtin_amdgcn_readfirstlane(cnts[1]);
+            if (MODE == MODE_BYTES) {
+                for (int i = tid; i < nshort; i += TEAM) rows_len += desc[i].y;
+                for (int i = tid; i < nlong; i += TEAM) rows_len += desc[DESC_CAP - 1 - i].y;
+                if (tid == 0) rows_cnt += nshort + nlong;
+            } else {
+                // (b) short rows: one 16-lane group per row, four rows per wave-instruction
+                constexpr int NG = TEAM / 16;
+                const int gid = tid >> 4, gl = tid & 15, gsh = (lane >> 4) << 4;
+                for (int b0 = 0; b0 < nshort; b0 += NG) {
+                    const int i = b0 + gid;
+                    int2 rk = i < nshort ? desc[i] : make_int2(0, 0);
+                    if (!row_ok(g, rk, 1, i, nshort)) rk = make_int2(0, 0);
+                    const int32_t *rowk = g.col + rk.x;
+                    int c = 0;
+                    for (int off = gl;; off += 16) {
+                        const bool act = off < rk.y;
+                        if (!__any(act)) break;
+                        bool hit = false;
+                        if (act) {
+                            const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[off]);
+                            hit = (e != EMPTY) && ((e >> 30) == other);
+                        }
+                        c += __popcll((__ballot(hit) >> gsh) & 0xFFFFull);
+                    }
+                    if (gl == 0 && c > 0) {
+                        ++scount;
+                        gam = c > gam ? c : gam;
+                    }
+                }
+                // (c) long rows: a whole wave per row, coalesced 256-byte reads
+                for (int i = wid; i < nlong; i += NW) {
+                    int2 rk = (i < DESC_CAP) ? desc[DESC_CAP - 1 - i] : make_int2(-1, -1);
+                    if (!row_ok(g, rk, 2, i, nlong)) rk = make_int2(0, 0);
+                    const int32_t *rowk = g.col + rk.x;
+                    int c = 0;
+                    for (int base = 0; base < rk.y; base += 64) {
+                        const int t = base + lane;
+                        bool hit = false;
+                        if (t < rk.y) {
+                            const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[t]);
+                            hit = (e != EMPTY) && ((e >> 30) == other);
+                        }
+                        c += __popcll(__ballot(hit));
+                    }
+                    if (lane == 0 && c > 0) {
+                        ++scount;
+                        gam = c > gam ? c : gam;
+                    }
+                }
+            }
+            team_sync<TEAM>();  // desc[] is rebuilt for the other side
+        } else {
+            // largest bin: no room in LDS for descriptors next to the 128 KiB table; one wave per row
+            for (int p = wid; p < deg; p += NW) {
+                const int k = row[p];
+                const unsigned ek = table_lookup<SLOTS>(tab, (unsigned)k);
+                if ((ek >> 30) != mine) continue;
+                const int2 rk = g.rowinfo[k];
+                const int32_t *rowk = g.col + rk.x;
+                if (MODE == MODE_BYTES) {
+                    if (lane == 0) {
+                        rows_len += rk.y;
+                        rows_cnt += 1;
+                    }
+                    continue;
+                }
+                int c = 0;
+                for (int base = 0; base < rk.y; base += 64) {
+                    const int i = base + lane;
+                    bool hit = false;
+                    if (i < rk.y) {
+                        const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[i]);
+                        hit = (e != EMPTY) && ((e >> 30) == other);
+                    }
+                    c += __popcll(__ballot(hit));
+                }
+                if (lane == 0 && c > 0) {
+                    ++scount;
+                    gam = c > gam ? c : gam;
+                }
             }
         }
         if (side == 0) s1 = scount; else s2 = scount;
+    }
+    // per-lane partials -> wave -> team
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+        const int og = __shfl_xor(gam, off);
+        gam = og > gam ? og : gam;
+        rows_cnt += __shfl_xor(rows_cnt, off);
+        rows_len += __shfl_xor(rows_len, off);
     }
     if (NW > 1) {
         if (lane == 0) {
@@ -223,35 +355,74 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
     return out;
 }
 
-template <int SLOTS, int TEAM, int MODE>
-__global__ void __launch_bounds__(TEAM) k_edge_pass(View g, const int32_t *work, const int32_t *work_count,
-                                                     int curv_type, double *curv, double *bytes_total) {
-    __shared__ unsigned tab[SLOTS];
-    __shared__ int red[6 * (TEAM / 64) + 2];
-    const int count = *work_count;
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const int s = work[item];
-        const int u = g.slot_row[s];
-        const int v = g.col[s];
-        Ingredients q = edge_ingredients<SLOTS, TEAM, MODE>(g, u, v, tab, red);
-        if (threadIdx.x == 0) {
-            if (MODE == MODE_BFC) {
-                curv[s] = bfc_formula(q.du, q.dv, q.T, q.s1, q.s2, q.gamma);
-            } else if (MODE == MODE_TRI) {
-                curv[s] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - q.du - q.dv + 3 * q.T) : (double)q.T;
-            } else {
-                atomicAdd(bytes_total, q.bytes);
-            }
+template <int SLOTS, int TEAM, int MODE, int DESC_CAP>
+__device__ inline void pass_item(const View &g, int item, int count, const int32_t *work, int curv_type, double *curv,
+                                 double *bytes_total, unsigned *tab, int *red, int2 *desc, int *cnts) {
+    const int s = work[item];
+    if (s < 0 || s >= g.cap_total) {  // cannot happen (classify writes valid slots); never chase a bad index
+        row_ok(g, make_int2(-1, s), 6, item, count);
+        return;
+    }
+    const int u = g.slot_row[s];
+    const int v = g.col[s];
+    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE, DESC_CAP>(g, u, v, tab, red, desc, cnts);
+    if (threadIdx.x == 0) {
+        if (MODE == MODE_BFC) {
+            curv[s] = bfc_formula(q.du, q.dv, q.T, q.s1, q.s2, q.gamma);
+        } else if (MODE == MODE_TRI) {
+            curv[s] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - q.du - q.dv + 3 * q.T) : (double)q.T;
+        } else {
+            atomicAdd(bytes_total, q.bytes);
         }
     }
 }
 
+// Persistent grid over one bin's work list.
+//   * single-wave teams (TEAM == 64) dequeue CHUNK items at a time with one atomic whose result is broadcast
+//     by readfirstlane: register-only, no LDS hand-off, no barrier;
+//   * multi-wave teams take items round-robin (item = block, block + grid, ...): every value that steers control
+//     flow around the team barriers is provably uniform.  (An LDS-broadcast dequeue for multi-wave teams hung /
+//     faulted on gfx950 in round 1 and was removed; see DESIGN.md.)
+template <int SLOTS, int TEAM, int MODE, int DESC_CAP, int CHUNK>
+__global__ void __launch_bounds__(TEAM) k_edge_pass(View g, const int32_t *work, const int32_t *work_count,
+                                                     int32_t *work_next, int curv_type, double *curv,
+                                                     double *bytes_total) {
+    __shared__ unsigned tab[SLOTS];
+    __shared__ int2 desc[DESC_CAP > 0 ? DESC_CAP : 1];
+    __shared__ int red[6 * (TEAM / 64) + 2];
+    __shared__ int cnts[2];
+    const int count = *work_count;
+    if (count < 0 || count > g.cap_total) {  // cannot happen; never walk a list with a corrupt length
+        row_ok(g, make_int2(-1, count), 7, 0, 0);
+        return;
+    }
+    if (TEAM == 64) {
+        const int max_rounds = count / CHUNK + 2;
+        for (int round = 0; round < max_rounds; ++round) {
+            int first = 0;
+            if (threadIdx.x == 0) first = atomicAdd(work_next, CHUNK);
+            first = __builtin_amdgcn_readfirstlane(first);
+            if (first >= count || first < 0) break;
+            const int last = first + CHUNK < count ? first + CHUNK : count;
+            for (int item = first; item < last; ++item)
+                pass_item<SLOTS, TEAM, MODE, DESC_CAP>(g, item, count, work, curv_type, curv, bytes_total, tab, red,
+                                                       desc, cnts);
+        }
+    } else {
+        for (int item = blockIdx.x; item < count; item += gridDim.x)
+            pass_item<SLOTS, TEAM, MODE, DESC_CAP>(g, item, count, work, curv_type, curv, bytes_total, tab, red, desc,
+                                                   cnts);
+    }
+}
+
 // one edge given directly (dcr_curvature_edge / dcr_bfc_ingredients)
-template <int SLOTS, int TEAM>
+template <int SLOTS, int TEAM, int DESC_CAP>
 __global__ void __launch_bounds__(TEAM) k_edge_single(View g, int u, int v, int64_t *out6) {
     __shared__ unsigned tab[SLOTS];
+    __shared__ int2 desc[DESC_CAP > 0 ? DESC_CAP : 1];
     __shared__ int red[6 * (TEAM / 64) + 2];
-    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE_BFC>(g, u, v, tab, red);
+    __shared__ int cnts[2];
+    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE_BFC, DESC_CAP>(g, u, v, tab, red, desc, cnts);
     if (threadIdx.x == 0) {
         out6[0] = q.du; out6[1] = q.dv; out6[2] = q.T; out6[3] = q.s1; out6[4] = q.s2; out6[5] = q.gamma;
     }
@@ -259,52 +430,92 @@ __global__ void __launch_bounds__(TEAM) k_edge_single(View g, int u, int v, int6
 
 // Classify every adjacency slot: undirected edges are the slots whose neighbour id exceeds the row id.
 // Trivial cases are finished here ('1d'; BFC with a degree-1 endpoint, bfc_naive.py:18-19); the rest go to
-// the work list of the bin that fits their neighbourhood.
+// the work list of the bin that fits their neighbourhood.  A block owns CLASSIFY_CHUNK consecutive slots:
+// it counts its items per bin, reserves list space with one global atomic per bin, then writes.
+constexpr int CLASSIFY_CHUNK = 4096;
+
+__device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total, int curv_type, int mode, double *curv,
+                                    DevResult *res, double *bytes_total, bool finish_trivial) {
+    if (s >= cap_total) return -1;
+    const int u = g.slot_row[s];
+    const int2 ru = g.rowinfo[u];
+    if ((int)(s - ru.x) >= ru.y) return -1;
+    const int v = g.col[s];
+    if (v <= u) return -1;
+    const int dv = g.rowinfo[v].y, du = ru.y;
+    if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
+        if (finish_trivial) curv[s] = (double)(4 - du - dv);
+        return -1;
+    }
+    if (curv_type == DCR_CURV_BFC && (du < dv ? du : dv) == 1) {
+        if (finish_trivial) {
+            if (mode == MODE_BYTES) atomicAdd(bytes_total, 24.0);
+            else curv[s] = 0.0;
+        }
+        return -1;
+    }
+    const int keys = du + dv + 2;
+    int bin = NBINS;
+    for (int b = NBINS - 1; b >= 0; --b)
+        if (keys <= bin_max_keys(b)) bin = b;
+    if (bin == NBINS) {
+        res->flag_too_big = 1;
+        return -1;
+    }
+    return bin;
+}
+
 __global__ void __launch_bounds__(256) k_classify(View g, int64_t cap_total, int curv_type, int mode, double *curv,
                                                    WorkLists wl, DevResult *res, double *bytes_total) {
+    __shared__ int cnt[NBINS];
+    __shared__ int base[NBINS];
     const int lane = threadIdx.x & 63;
-    for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x; s0 < cap_total; s0 += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = s0 + threadIdx.x;
-        int bin = -1;
-        if (s < cap_total) {
-            const int u = g.slot_row[s];
-            const int2 ru = g.rowinfo[u];
-            if ((int)(s - ru.x) < ru.y) {
-                const int v = g.col[s];
-                if (v > u) {
-                    const int dv = g.rowinfo[v].y, du = ru.y;
-                    if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
-                        curv[s] = (double)(4 - du - dv);
-                    } else if (curv_type == DCR_CURV_BFC && (du < dv ? du : dv) == 1) {
-                        if (mode == MODE_BYTES) atomicAdd(bytes_total, 24.0);
-                        else curv[s] = 0.0;
-                    } else {
-                        const int keys = du + dv + 2;
-                        bin = NBINS;
-                        for (int b = NBINS - 1; b >= 0; --b)
-                            if (keys <= bin_max_keys(b)) bin = b;
-                        if (bin == NBINS) {
-                            res->flag_too_big = 1;
-                            bin = -1;
-                        }
-                    }
-                }
-            }
-        }
+    const int64_t chunk0 = (int64_t)blockIdx.x * CLASSIFY_CHUNK;
+    if (threadIdx.x < NBINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // phase 1: count per bin (and finish the trivial edges)
+    int mycnt[NBINS] = {0, 0, 0, 0, 0};
+    for (int o = threadIdx.x; o < CLASSIFY_CHUNK; o += 256) {
+        const int bin = classify_slot(g, chunk0 + o, cap_total, curv_type, mode, curv, res, bytes_total, true);
+#pragma unroll
+        for (int b = 0; b < NBINS; ++b) mycnt[b] += (bin == b);
+    }
+#pragma unroll
+    for (int b = 0; b < NBINS; ++b) {
+        int t = mycnt[b];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0 && t) atomicAdd(&cnt[b], t);
+    }
+    __syncthreads();
+    if (threadIdx.x < NBINS) {
+        const int c = cnt[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(&res->work_count[threadIdx.x], c) : 0;
+        cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    // phase 2: write the items
+    for (int o = threadIdx.x; o < CLASSIFY_CHUNK; o += 256) {
+        const int64_t s = chunk0 + o;
+        const int bin = classify_slot(g, s, cap_total, curv_type, mode, curv, res, bytes_total, false);
+#pragma unroll
         for (int b = 0; b < NBINS; ++b) {
             const unsigned long long m = __ballot(bin == b);
             if (m == 0) continue;
-            int base = 0;
+            int off = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(&res->work_count[b], __popcll(m));
-            base = __shfl(base, leader);
-            if (bin == b) wl.w[b][base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+            if (lane == leader) off = atomicAdd(&cnt[b], __popcll(m));
+            off = __shfl(off, leader);
+            if (bin == b) wl.w[b][base[b] + off + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
         }
     }
 }
 
 __global__ void k_clear_counts(DevResult *res) {
-    if (threadIdx.x < NBINS) res->work_count[threadIdx.x] = 0;
+    if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
+    if (threadIdx.x < NBINS) {
+        res->work_count[threadIdx.x] = 0;
+        res->work_next[threadIdx.x] = 0;
+    }
     if (threadIdx.x == 0) res->flag_too_big = 0;
 }
 
@@ -320,39 +531,66 @@ static int ensure_work(dcr_graph *g) {
     return DCR_OK;
 }
 
+// descriptors per team: one per possible member of a difference set (<= keys of the bin); the largest bin has
+// no LDS left next to its 128 KiB table and streams rows one wave at a time instead
+__host__ __device__ constexpr int bin_desc_cap(int b) { return b == 4 ? 0 : bin_max_keys(b); }
+__host__ __device__ constexpr int bin_chunk(int b) { return b == 0 ? 16 : b == 1 ? 8 : b == 2 ? 2 : 1; }
+
 template <int B, int MODE>
-static void launch_bin(dcr_graph *g, const View &vw, int curv_type, double *bytes_total, int num_cu) {
+static void launch_bin(dcr_graph *g, const View &vw, int curv_type, double *bytes_total, int num_cu,
+                       hipStream_t st) {
     constexpr int SLOTS = BIN_SLOTS[B];
     constexpr int TEAM = BIN_TEAM[B];
-    // persistent grid: enough teams to fill every CU's wave slots / LDS, items dealt round-robin
-    int per_cu = TEAM == 64 ? 32 : TEAM == 256 ? (SLOTS * 4 <= 8192 ? 8 : 4) : 1;
-    int grid = num_cu * per_cu;
-    hipLaunchKernelGGL((k_edge_pass<SLOTS, TEAM, MODE>), dim3(grid), dim3(TEAM), 0, g->stream, vw, g->work[B],
-                       &g->dres->work_count[B], curv_type, g->curv, bytes_total);
+    constexpr int LDS = SLOTS * 4 + bin_desc_cap(B) * 8 + 256;
+    // persistent grid: as many teams as fit a CU (wave slots, LDS), items dequeued dynamically
+    int per_cu = (160 * 1024) / LDS;
+    const int by_waves = 32 / (TEAM / 64);
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = num_cu * per_cu;
+    hipLaunchKernelGGL((k_edge_pass<SLOTS, TEAM, MODE, bin_desc_cap(B), bin_chunk(B)>), dim3(grid), dim3(TEAM), 0, st,
+                       vw, g->work[B], &g->dres->work_count[B], &g->dres->work_next[B], curv_type, g->curv,
+                       bytes_total);
 }
 
 template <int MODE>
 static int run_pass(dcr_graph *g, int curv_type, double *bytes_total) {
     DCR_TRY(ensure_work(g));
-    View vw{g->rowinfo, g->col, g->slot_row};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc};
     WorkLists wl;
     for (int b = 0; b < NBINS; ++b) wl.w[b] = g->work[b];
-    int num_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0)
-        num_cu = prop.multiProcessorCount;
+    if (g->num_cu <= 0) {
+        g->num_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0)
+            g->num_cu = prop.multiProcessorCount;
+    }
+    const int num_cu = g->num_cu;
     hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, g->stream, g->dres);
-    int64_t blocks = (g->cap_total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    int64_t blocks = (g->cap_total + CLASSIFY_CHUNK - 1) / CLASSIFY_CHUNK;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_classify, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->cap_total, curv_type, MODE,
                        g->curv, wl, g->dres, bytes_total);
     if (curv_type != DCR_CURV_1D || MODE == MODE_BYTES) {
-        launch_bin<0, MODE>(g, vw, curv_type, bytes_total, num_cu);
-        launch_bin<1, MODE>(g, vw, curv_type, bytes_total, num_cu);
-        launch_bin<2, MODE>(g, vw, curv_type, bytes_total, num_cu);
-        launch_bin<3, MODE>(g, vw, curv_type, bytes_total, num_cu);
-        launch_bin<4, MODE>(g, vw, curv_type, bytes_total, num_cu);
+        // the bins are independent: fork them onto side streams so their tails overlap; heaviest first
+        static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;  // debugging aid: one stream
+        hipStream_t s0 = g->stream, s1 = g->stream, s2 = g->stream, s3 = g->stream;
+        if (!serial) {
+            DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
+            for (int b = 0; b < NBINS - 1; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
+            s0 = g->side[0]; s1 = g->side[1]; s2 = g->side[2]; s3 = g->side[3];
+        }
+        launch_bin<3, MODE>(g, vw, curv_type, bytes_total, num_cu, g->stream);
+        launch_bin<4, MODE>(g, vw, curv_type, bytes_total, num_cu, s0);
+        launch_bin<2, MODE>(g, vw, curv_type, bytes_total, num_cu, s1);
+        launch_bin<1, MODE>(g, vw, curv_type, bytes_total, num_cu, s2);
+        launch_bin<0, MODE>(g, vw, curv_type, bytes_total, num_cu, s3);
+        if (!serial) {
+            for (int b = 0; b < NBINS - 1; ++b) {
+                DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
+                DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[b], 0));
+            }
+        }
     }
     DCR_HIP(hipGetLastError());
     return DCR_OK;
@@ -365,8 +603,8 @@ int launch_curvature_pass(dcr_graph *g, int curv_type) {
 
 template <int B>
 static void launch_single(dcr_graph *g, const View &vw, int u, int v, int64_t *out6) {
-    hipLaunchKernelGGL((k_edge_single<BIN_SLOTS[B], BIN_TEAM[B]>), dim3(1), dim3(BIN_TEAM[B]), 0, g->stream, vw, u, v,
-                       out6);
+    hipLaunchKernelGGL((k_edge_single<BIN_SLOTS[B], BIN_TEAM[B], bin_desc_cap(B)>), dim3(1), dim3(BIN_TEAM[B]), 0,
+                       g->stream, vw, u, v, out6);
 }
 
 }  // namespace dcr
@@ -389,6 +627,13 @@ int dcr_curvature_pass(dcr_graph *g, int curv_type) {
         g->pass_ms_total += ms;
         g->pass_count += 1;
     }
+    if (g->hres->misc[0] != 0) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "curvature kernel invariant %d violated: row {%d,%d} a=%d b=%d block=%d thread=%d",
+                 g->hres->misc[0], g->hres->misc[1], g->hres->misc[2], g->hres->misc[3], g->hres->misc[4],
+                 g->hres->misc[5], g->hres->misc[6]);
+        DCR_FAIL(DCR_EHIP, buf);
+    }
     if (g->hres->flag_too_big)
         DCR_FAIL(DCR_ECAPACITY, "an edge has deg(u)+deg(v)+2 > 16384: beyond the LDS table of the largest bin");
     g->curv_type_last = curv_type;
@@ -406,7 +651,7 @@ int dcr_bfc_ingredients(dcr_graph *g, int32_t u, int32_t v, int64_t out6[6]) {
     const int keys = du + dv + 2;
     int64_t *d_out = nullptr;
     DCR_TRY(dev_alloc(&d_out, 6));
-    View vw{g->rowinfo, g->col, g->slot_row};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc};
     if (keys <= bin_max_keys(0)) launch_single<0>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(1)) launch_single<1>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(2)) launch_single<2>(g, vw, u, v, d_out);

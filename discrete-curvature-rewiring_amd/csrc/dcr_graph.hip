@@ -310,6 +310,11 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_HIP(hipStreamCreate(&g->stream));
     DCR_HIP(hipEventCreate(&g->ev0));
     DCR_HIP(hipEventCreate(&g->ev1));
+    DCR_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    for (int b = 0; b < NBINS - 1; ++b) {
+        DCR_HIP(hipStreamCreateWithFlags(&g->side[b], hipStreamNonBlocking));
+        DCR_HIP(hipEventCreateWithFlags(&g->ev_join[b], hipEventDisableTiming));
+    }
     DCR_TRY(dev_alloc(&g->rowinfo, n));
     DCR_TRY(dev_alloc(&g->rowcap, n));
     DCR_TRY(alloc_layout(g, tot));
@@ -348,6 +353,11 @@ int dcr_graph_destroy(dcr_graph *g) {
     if (g->imp_out_h) (void)hipHostFree(g->imp_out_h);
     if (g->imp_ci_h) (void)hipHostFree(g->imp_ci_h);
     if (g->imp_cj_h) (void)hipHostFree(g->imp_cj_h);
+    for (int b = 0; b < NBINS - 1; ++b) {
+        if (g->side[b]) (void)hipStreamDestroy(g->side[b]);
+        if (g->ev_join[b]) (void)hipEventDestroy(g->ev_join[b]);
+    }
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);

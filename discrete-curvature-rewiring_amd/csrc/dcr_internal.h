@@ -34,10 +34,10 @@ void set_error(const std::string &msg);
 
 // ---- curvature-pass work bins ----------------------------------------------
 // An undirected edge (u,v) needs an LDS hash set over N(u) ∪ N(v) ∪ {u,v}; the bin is chosen by
-// that size so the table keeps a load factor <= 1/2.  Threads per edge ("team") grow with the bin.
+// that size so the table keeps a load factor <= 1/4 (1/2 in the last bin).  Threads per edge ("team") grow with the bin.
 constexpr int NBINS = 5;
 constexpr int BIN_SLOTS[NBINS] = {128, 512, 2048, 8192, 32768};
-constexpr int BIN_TEAM[NBINS] = {64, 64, 256, 256, 1024};
+constexpr int BIN_TEAM[NBINS] = {64, 64, 256, 512, 1024};
 constexpr int MAX_TABLE_KEYS = BIN_SLOTS[NBINS - 1] / 2;  // du + dv + 2 must not exceed this
 constexpr int32_t MAX_NODES = (1 << 30) - 2;              // two tag bits live above the key
 
@@ -51,11 +51,12 @@ struct DevResult {
     int32_t overflow_row;
     int32_t max_keys;     // largest du+dv+2 seen by classify
     int32_t work_count[NBINS];
+    int32_t work_next[NBINS];  // dequeue cursors of the persistent bin kernels
     int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS
     int64_t n_cand;
     int64_t imp_argmax;
     int32_t cand_i, cand_j;
-    int32_t misc[4];
+    int32_t misc[8];  // scratch: has_edge/remove status, and the kernels' invariant guard record
 };
 
 struct ImpStats {  // per (x,y) statistics for the improvement kernels; lives in device memory
@@ -117,6 +118,12 @@ struct dcr_graph {
 
     dcr::DevResult *dres = nullptr;  // device
     dcr::DevResult *hres = nullptr;  // pinned host
+
+    // side streams: the work bins of a curvature pass run concurrently
+    hipStream_t side[dcr::NBINS - 1] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[dcr::NBINS - 1] = {nullptr, nullptr, nullptr, nullptr};
+    int num_cu = 0;
 
     // profiling
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
