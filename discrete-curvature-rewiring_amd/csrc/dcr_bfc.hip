@@ -97,6 +97,46 @@ __device__ inline unsigned table_lookup(const unsigned *tab, unsigned key) {
     }
 }
 
+// Rows are read in aligned 16-byte pieces: lane q of a row's lane set fetches col[a0 + 4q .. a0 + 4q + 3], a0 = row
+// start rounded down to a multiple of 4 (the col allocation is padded, so the last piece never leaves it).
+__device__ inline int4 load_piece(const int32_t *col, int a) {
+    return *reinterpret_cast<const int4 *>(col + a);
+}
+
+// Which of the (up to four) entries of a piece lie inside [lo, hi) and hit an entry whose tag pattern is `other`;
+// returned as a 4-bit mask.  The four first probes are issued together.  With `cnt`, every hit also bumps the
+// counter of the table slot it landed on (the 4-cycle seen from the other endpoint's side).
+template <int SLOTS>
+__device__ inline unsigned probe_piece(const unsigned *tab, unsigned *cnt, const int4 w, int a, int lo, int hi,
+                                       unsigned other) {
+    const unsigned k0 = (unsigned)w.x, k1 = (unsigned)w.y, k2 = (unsigned)w.z, k3 = (unsigned)w.w;
+    const bool v0 = a >= lo && a < hi, v1 = a + 1 >= lo && a + 1 < hi, v2 = a + 2 >= lo && a + 2 < hi,
+               v3 = a + 3 >= lo && a + 3 < hi;
+    unsigned h0 = hash_slot<SLOTS>(k0), h1 = hash_slot<SLOTS>(k1), h2 = hash_slot<SLOTS>(k2), h3 = hash_slot<SLOTS>(k3);
+    unsigned e0 = v0 ? tab[h0] : EMPTY, e1 = v1 ? tab[h1] : EMPTY, e2 = v2 ? tab[h2] : EMPTY, e3 = v3 ? tab[h3] : EMPTY;
+    while (e0 != EMPTY && (e0 & KEY_MASK) != k0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; }
+    while (e1 != EMPTY && (e1 & KEY_MASK) != k1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; }
+    while (e2 != EMPTY && (e2 & KEY_MASK) != k2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; }
+    while (e3 != EMPTY && (e3 & KEY_MASK) != k3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; }
+    const bool t0 = e0 != EMPTY && (e0 >> 30) == other, t1 = e1 != EMPTY && (e1 >> 30) == other,
+               t2 = e2 != EMPTY && (e2 >> 30) == other, t3 = e3 != EMPTY && (e3 >> 30) == other;
+    if (cnt) {
+        if (t0) atomicAdd(&cnt[h0], 1u);
+        if (t1) atomicAdd(&cnt[h1], 1u);
+        if (t2) atomicAdd(&cnt[h2], 1u);
+        if (t3) atomicAdd(&cnt[h3], 1u);
+    }
+    return (t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u) | (t3 ? 8u : 0u);
+}
+
+// popcount of the four per-element hit ballots, restricted to the lanes selected by `sel`
+__device__ inline int count_hits(unsigned m, unsigned long long sel, int shift) {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += __popcll((__ballot((m >> j) & 1u) >> shift) & sel);
+    return c;
+}
+
 template <int TEAM>
 __device__ inline void team_sync() {
     __syncthreads();  // single-wave teams: the compiler lowers this to a wait, no s_barrier
@@ -108,24 +148,35 @@ struct Ingredients {
 };
 
 // Whole team cooperates; the result is valid in thread 0.
-constexpr int LONG_ROW = 48;  // rows longer than this are streamed by a whole wave, shorter ones by 16 lanes
+//
+// 4-cycle counting is one-sided.  With DX = N(u) \ N(v) \ {v} and DY = N(v) \ N(u) \ {u}, the reference counts for
+// k in DX the neighbours of k inside DY (bfc_naive.py:26-27,36) and for k' in DY the neighbours inside DX (:28-29,37).
+// Both are degrees in the same bipartite graph between DX and DY, so only the rows of the cheaper side (smaller sum
+// of degrees) are streamed: a row's hit count is its own degree, and every hit bumps a counter on the table slot of the
+// node it landed on, which after the sweep is that node's degree seen from the other side.
+constexpr int LONG_ROW = 60;  // longer rows are streamed by a whole wave; shorter ones fit four 64-byte group steps
+constexpr int MAXR = 4;       // rows of one endpoint held per lane while both sides are sized (deg <= MAXR * TEAM)
 
 template <int SLOTS, int TEAM, int MODE, int DESC_CAP>
-__device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsigned *tab, int *red, int2 *desc,
-                                               int *cnts) {
+__device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsigned *tab, unsigned *cnt, int *red,
+                                               int2 *desc, int *cnts) {
     constexpr int NW = TEAM / 64;
+    constexpr bool ONE_SIDED = DESC_CAP > 0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int2 ru = g.rowinfo[u], rv = g.rowinfo[v];
     if (!row_ok(g, ru, 3, u, v)) ru = make_int2(0, 0);
     if (!row_ok(g, rv, 4, u, v)) rv = make_int2(0, 0);
-    if (ru.y + rv.y + 2 > (DESC_CAP > 0 ? DESC_CAP : SLOTS / 2)) {
+    if (ru.y + rv.y + 2 > (ONE_SIDED ? DESC_CAP : SLOTS / 2) || (ONE_SIDED && (ru.y > MAXR * TEAM || rv.y > MAXR * TEAM))) {
         row_ok(g, make_int2(-1, ru.y + rv.y), 5, u, v);
         ru.y = 0;
         rv.y = 0;
     }
     const int32_t *rowu = g.col + ru.x, *rowv = g.col + rv.x;
 
-    for (int i = tid; i < SLOTS; i += TEAM) tab[i] = EMPTY;
+    for (int i = tid; i < SLOTS; i += TEAM) {
+        tab[i] = EMPTY;
+        if (ONE_SIDED) cnt[i] = 0u;
+    }
     team_sync<TEAM>();
     if (tid == 0) {
         table_insert<SLOTS>(tab, (unsigned)u | TAG_U | TAG_V);
@@ -157,207 +208,297 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
     }
     team_sync<TEAM>();
 
-    // wave-level popcount of the triangle hits, then across waves through LDS
-    int T = 0;
-    {
-        int t = tcount;
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-        if (NW == 1) {
-            T = t;
-        } else {
-            if (lane == 0) red[wid] = t;
-            team_sync<TEAM>();
-            for (int w = 0; w < NW; ++w) T += red[w];
-            team_sync<TEAM>();
-        }
-    }
     Ingredients out;
     out.du = ru.y;
     out.dv = rv.y;
-    out.T = T;
     out.s1 = out.s2 = out.gamma = 0;
     out.bytes = 0.0;
-    if (MODE == MODE_TRI) return out;
+    int s_rows = 0, s_slots = 0, gam = 0;  // per-lane partials
+    long long len_u = 0, len_v = 0;        // sum of row lengths over DX / DY (per-lane partials, then totals)
+    int n_u = 0, n_v = 0;                  // |DX|, |DY|
+    int T = 0;
+    bool rows_are_u = true;                // which endpoint's side was streamed row by row
 
-    int s1 = 0, s2 = 0, gam = 0;
-    long long rows_len = 0;
-    int rows_cnt = 0;
-    // side 0: k in N(u) only, count neighbours that are in N(v) only; side 1 mirrored
-    for (int side = 0; side < 2; ++side) {
-        const int32_t *row = side == 0 ? rowu : rowv;
-        const int deg = side == 0 ? ru.y : rv.y;
-        const unsigned mine = side == 0 ? 1u : 2u;    // tag pattern (>>30) of "only this side"
-        const unsigned other = side == 0 ? 2u : 1u;
-        int scount = 0;  // per-lane partial: rows owned by this lane that close at least one 4-cycle
-        if (DESC_CAP > 0) {
-            // (a) descriptor build, lane-parallel: every member of this side's difference set gets its
-            //     {row start, row length} fetched at once; short rows are listed from the front of desc[],
-            //     long rows from the back.
+    if (ONE_SIDED) {
+        // ---- size both sides: fetch {start, length} of every member of DX and DY, lane-parallel ----------------
+        int2 ku[MAXR], kv[MAXR];
+        if (MODE != MODE_TRI) {
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                ku[r] = make_int2(0, -1);
+                kv[r] = make_int2(0, -1);
+                const int p = r * TEAM + tid;
+                if (p < ru.y) {
+                    const int k = rowu[p];
+                    if ((table_lookup<SLOTS>(tab, (unsigned)k) >> 30) == 1u) {  // in N(u) only
+                        ku[r] = g.rowinfo[k];
+                        if (!row_ok(g, ku[r], 1, k, p)) ku[r] = make_int2(0, 0);
+                        len_u += ku[r].y;
+                        ++n_u;
+                    }
+                }
+                if (p < rv.y) {
+                    const int k = rowv[p];
+                    if ((table_lookup<SLOTS>(tab, (unsigned)k) >> 30) == 2u) {  // in N(v) only
+                        kv[r] = g.rowinfo[k];
+                        if (!row_ok(g, kv[r], 2, k, p)) kv[r] = make_int2(0, 0);
+                        len_v += kv[r].y;
+                        ++n_v;
+                    }
+                }
+            }
+        }
+        // team totals: triangles, side sizes
+        int t = tcount;
+        for (int off = 32; off > 0; off >>= 1) {
+            t += __shfl_xor(t, off);
+            len_u += __shfl_xor(len_u, off);
+            len_v += __shfl_xor(len_v, off);
+            n_u += __shfl_xor(n_u, off);
+            n_v += __shfl_xor(n_v, off);
+        }
+        if (NW > 1) {
+            if (lane == 0) {
+                red[wid] = t;
+                red[NW + wid] = n_u;
+                red[2 * NW + wid] = n_v;
+                ((long long *)(red + 4 * NW))[wid] = len_u;
+                ((long long *)(red + 4 * NW))[NW + wid] = len_v;
+            }
             if (tid == 0) {
                 cnts[0] = 0;
                 cnts[1] = 0;
             }
             team_sync<TEAM>();
-            for (int p0 = 0; p0 < deg; p0 += TEAM) {
-                const int p = p0 + tid;
-                bool want = false;
-                int2 rk = make_int2(0, 0);
-                if (p < deg) {
-                    const int k = row[p];
-                    const unsigned ek = table_lookup<SLOTS>(tab, (unsigned)k);
-                    if ((ek >> 30) == mine) {  // not a triangle node, not the edge's own endpoint
-                        rk = g.rowinfo[k];
-                        want = true;
-                    }
-                }
-                const bool is_long = want && rk.y > LONG_ROW;
-                const bool is_short = want && !is_long;
-                const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (ms) {
-                    int base = 0;
-                    const int leader = __ffsll((long long)ms) - 1;
-                    if (lane == leader) base = atomicAdd(&cnts[0], __popcll(ms));
-                    base = __shfl(base, leader);
-                    if (is_short) desc[base + __popcll(ms & below)] = rk;
-                }
-                if (ml) {
-                    int base = 0;
-                    const int leader = __ffsll((long long)ml) - 1;
-                    if (lane == leader) base = atomicAdd(&cnts[1], __popcll(ml));
-                    base = __shfl(base, leader);
-                    if (is_long) desc[DESC_CAP - 1 - (base + __popcll(ml & below))] = rk;
-                }
+            t = n_u = n_v = 0;
+            len_u = len_v = 0;
+            for (int w = 0; w < NW; ++w) {
+                t += red[w];
+                n_u += red[NW + w];
+                n_v += red[2 * NW + w];
+                len_u += ((long long *)(red + 4 * NW))[w];
+                len_v += ((long long *)(red + 4 * NW))[NW + w];
             }
             team_sync<TEAM>();
-            const int nshort = __builtin_amdgcn_readfirstlane(cnts[0]);
-            const int nlong = __builtin_amdgcn_readfirstlane(cnts[1]);
-            if (MODE == MODE_BYTES) {
-                for (int i = tid; i < nshort; i += TEAM) rows_len += desc[i].y;
-                for (int i = tid; i < nlong; i += TEAM) rows_len += desc[DESC_CAP - 1 - i].y;
-                if (tid == 0) rows_cnt += nshort + nlong;
-            } else {
-                // (b) short rows: one 16-lane group per row, four rows per wave-instruction
-                constexpr int NG = TEAM / 16;
-                const int gid = tid >> 4, gl = tid & 15, gsh = (lane >> 4) << 4;
-                for (int b0 = 0; b0 < nshort; b0 += NG) {
-                    const int i = b0 + gid;
-                    int2 rk = i < nshort ? desc[i] : make_int2(0, 0);
-                    if (!row_ok(g, rk, 1, i, nshort)) rk = make_int2(0, 0);
-                    const int32_t *rowk = g.col + rk.x;
-                    int c = 0;
-                    for (int off = gl;; off += 16) {
-                        const bool act = off < rk.y;
-                        if (!__any(act)) break;
-                        bool hit = false;
-                        if (act) {
-                            const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[off]);
-                            hit = (e != EMPTY) && ((e >> 30) == other);
-                        }
-                        c += __popcll((__ballot(hit) >> gsh) & 0xFFFFull);
-                    }
-                    if (gl == 0 && c > 0) {
-                        ++scount;
-                        gam = c > gam ? c : gam;
-                    }
+        } else {
+            if (tid == 0) {
+                cnts[0] = 0;
+                cnts[1] = 0;
+            }
+            team_sync<TEAM>();
+        }
+        T = t;
+        out.T = T;
+        if (MODE == MODE_TRI) return out;
+        if (MODE == MODE_BYTES) {
+            // rows of u and v, the row of every non-triangle neighbour, row-pointer pairs, output
+            out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)(len_u + len_v) + 8.0 * (double)(2 + n_u + n_v) + 8.0;
+            return out;
+        }
+        // ---- stream the cheaper side ---------------------------------------------------------------------------
+        const bool scan_u = len_u <= len_v;  // identical in every lane (team totals)
+        rows_are_u = scan_u;
+        const unsigned other = scan_u ? 2u : 1u;
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int2 rk = scan_u ? ku[r] : kv[r];
+            const bool want = rk.y >= 0;
+            const bool is_long = want && rk.y > LONG_ROW;
+            const bool is_short = want && !is_long;
+            const unsigned long long ms = __ballot(is_short), ml = __ballot(is_long);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (ms) {
+                int base = 0;
+                const int leader = __ffsll((long long)ms) - 1;
+                if (lane == leader) base = atomicAdd(&cnts[0], __popcll(ms));
+                base = __shfl(base, leader);
+                if (is_short) desc[base + __popcll(ms & below)] = rk;
+            }
+            if (ml) {
+                int base = 0;
+                const int leader = __ffsll((long long)ml) - 1;
+                if (lane == leader) base = atomicAdd(&cnts[1], __popcll(ml));
+                base = __shfl(base, leader);
+                if (is_long) desc[DESC_CAP - 1 - (base + __popcll(ml & below))] = rk;
+            }
+        }
+        team_sync<TEAM>();
+        int nshort = __builtin_amdgcn_readfirstlane(cnts[0]);
+        int nlong = __builtin_amdgcn_readfirstlane(cnts[1]);
+        if (nshort < 0 || nlong < 0 || nshort + nlong > DESC_CAP) {
+            row_ok(g, make_int2(-1, nshort), 8, nlong, u);
+            nshort = nlong = 0;
+        }
+        // (b) short rows (<= LONG_ROW entries, i.e. at most four 64-byte steps): a 4-lane group per row, so one
+        //     wave-instruction works on 16 rows and each group reads 64 contiguous bytes per step.  All steps of a
+        //     row are loaded before the first probe (up to four 16-byte loads in flight per lane).
+        {
+            constexpr int NG = TEAM / 4;
+            const int gid = tid >> 2, gl = tid & 3, gsh = (lane >> 2) << 2;
+#ifdef DCR_ABLATE_SHORT
+            for (int b0 = 0; b0 < 0; b0 += NG) {
+#else
+            for (int b0 = 0; b0 < nshort; b0 += NG) {
+#endif
+                const int i = b0 + gid;
+                const int2 rk = i < nshort ? desc[i] : make_int2(0, 0);
+                const int hi = rk.x + rk.y;
+                const int a = (rk.x & ~3) + 4 * gl;
+                int4 w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w[q] = make_int4(0, 0, 0, 0);
+                    if (a + 16 * q < hi) w[q] = load_piece(g.col, a + 16 * q);
                 }
-                // (c) long rows: a whole wave per row, coalesced 256-byte reads
-                for (int i = wid; i < nlong; i += NW) {
-                    int2 rk = (i < DESC_CAP) ? desc[DESC_CAP - 1 - i] : make_int2(-1, -1);
-                    if (!row_ok(g, rk, 2, i, nlong)) rk = make_int2(0, 0);
-                    const int32_t *rowk = g.col + rk.x;
-                    int c = 0;
-                    for (int base = 0; base < rk.y; base += 64) {
-                        const int t = base + lane;
-                        bool hit = false;
-                        if (t < rk.y) {
-                            const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[t]);
-                            hit = (e != EMPTY) && ((e >> 30) == other);
-                        }
-                        c += __popcll(__ballot(hit));
-                    }
-                    if (lane == 0 && c > 0) {
-                        ++scount;
-                        gam = c > gam ? c : gam;
-                    }
+                int c = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool act = a + 16 * q < hi;
+                    if (!__any(act)) break;
+                    unsigned m = 0;
+                    if (act) m = probe_piece<SLOTS>(tab, cnt, w[q], a + 16 * q, rk.x, hi, other);
+                    c += count_hits(m, 0xFull, gsh);
+                }
+                if (gl == 0 && c > 0) {
+                    ++s_rows;
+                    gam = c > gam ? c : gam;
                 }
             }
-            team_sync<TEAM>();  // desc[] is rebuilt for the other side
-        } else {
-            // largest bin: no room in LDS for descriptors next to the 128 KiB table; one wave per row
+        }
+        // (c) long rows: a whole wave per row, 1 KiB per wave-instruction, next piece in flight while probing
+#ifdef DCR_ABLATE_LONG
+        for (int i = wid; i < 0; i += NW) {
+#else
+        for (int i = wid; i < nlong; i += NW) {
+#endif
+            const int2 rl = desc[DESC_CAP - 1 - i];
+            const int hi = rl.x + rl.y;
+            int al = (rl.x & ~3) + 4 * lane;
+            int4 wl = make_int4(0, 0, 0, 0);
+            if (al < hi) wl = load_piece(g.col, al);
+            int c = 0;
+            for (int a0 = rl.x & ~3; a0 < hi; a0 += 256) {
+                const int an = al + 256;
+                int4 wn = make_int4(0, 0, 0, 0);
+                if (an < hi) wn = load_piece(g.col, an);
+                unsigned m = 0;
+                if (al < hi) m = probe_piece<SLOTS>(tab, cnt, wl, al, rl.x, hi, other);
+                c += count_hits(m, ~0ull, 0);
+                al = an;
+                wl = wn;
+            }
+            if (lane == 0 && c > 0) {
+                ++s_rows;
+                gam = c > gam ? c : gam;
+            }
+        }
+        team_sync<TEAM>();
+        // (d) the other side, from the slot counters
+        for (int i = tid; i < SLOTS; i += TEAM) {
+            const unsigned e = tab[i];
+            if (e != EMPTY && (e >> 30) == other) {
+                const int c = (int)cnt[i];
+                if (c > 0) {
+                    ++s_slots;
+                    gam = c > gam ? c : gam;
+                }
+            }
+        }
+    } else {
+        // ---- largest bin: the 128 KiB table leaves no LDS for descriptors or counters; both sides are streamed,
+        //      one wave per row ---------------------------------------------------------------------------------
+        int t = tcount;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (NW > 1) {
+            if (lane == 0) red[wid] = t;
+            team_sync<TEAM>();
+            t = 0;
+            for (int w = 0; w < NW; ++w) t += red[w];
+            team_sync<TEAM>();
+        }
+        T = t;
+        out.T = T;
+        if (MODE == MODE_TRI) return out;
+        for (int side = 0; side < 2; ++side) {
+            const int32_t *row = side == 0 ? rowu : rowv;
+            const int deg = side == 0 ? ru.y : rv.y;
+            const unsigned mine = side == 0 ? 1u : 2u, other = side == 0 ? 2u : 1u;
+            int scount = 0;
             for (int p = wid; p < deg; p += NW) {
                 const int k = row[p];
-                const unsigned ek = table_lookup<SLOTS>(tab, (unsigned)k);
-                if ((ek >> 30) != mine) continue;
-                const int2 rk = g.rowinfo[k];
-                const int32_t *rowk = g.col + rk.x;
+                if ((table_lookup<SLOTS>(tab, (unsigned)k) >> 30) != mine) continue;
+                int2 rk = g.rowinfo[k];
+                if (!row_ok(g, rk, 9, k, p)) rk = make_int2(0, 0);
                 if (MODE == MODE_BYTES) {
                     if (lane == 0) {
-                        rows_len += rk.y;
-                        rows_cnt += 1;
+                        len_u += rk.y;
+                        n_u += 1;
                     }
                     continue;
                 }
+                const int hi = rk.x + rk.y;
                 int c = 0;
-                for (int base = 0; base < rk.y; base += 64) {
-                    const int i = base + lane;
-                    bool hit = false;
-                    if (i < rk.y) {
-                        const unsigned e = table_lookup<SLOTS>(tab, (unsigned)rowk[i]);
-                        hit = (e != EMPTY) && ((e >> 30) == other);
-                    }
-                    c += __popcll(__ballot(hit));
+                for (int al = (rk.x & ~3) + 4 * lane; __any(al < hi); al += 256) {
+                    unsigned m = 0;
+                    if (al < hi) m = probe_piece<SLOTS>(tab, nullptr, load_piece(g.col, al), al, rk.x, hi, other);
+                    c += count_hits(m, ~0ull, 0);
                 }
                 if (lane == 0 && c > 0) {
                     ++scount;
                     gam = c > gam ? c : gam;
                 }
             }
+            if (side == 0) s_rows = scount; else s_slots = scount;
         }
-        if (side == 0) s1 = scount; else s2 = scount;
     }
     // per-lane partials -> wave -> team
     for (int off = 32; off > 0; off >>= 1) {
-        s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off);
+        s_rows += __shfl_xor(s_rows, off);
+        s_slots += __shfl_xor(s_slots, off);
         const int og = __shfl_xor(gam, off);
         gam = og > gam ? og : gam;
-        rows_cnt += __shfl_xor(rows_cnt, off);
-        rows_len += __shfl_xor(rows_len, off);
+        if (!ONE_SIDED) {
+            n_u += __shfl_xor(n_u, off);
+            len_u += __shfl_xor(len_u, off);
+        }
     }
     if (NW > 1) {
         if (lane == 0) {
-            red[wid] = s1;
-            red[NW + wid] = s2;
+            red[wid] = s_rows;
+            red[NW + wid] = s_slots;
             red[2 * NW + wid] = gam;
-            red[3 * NW + wid] = rows_cnt;
-            ((long long *)(red + 4 * NW))[wid] = rows_len;
+            red[3 * NW + wid] = n_u;
+            ((long long *)(red + 4 * NW))[wid] = len_u;
         }
         team_sync<TEAM>();
-        s1 = s2 = gam = rows_cnt = 0;
-        rows_len = 0;
+        s_rows = s_slots = gam = 0;
+        int nn = 0;
+        long long ll = 0;
         for (int w = 0; w < NW; ++w) {
-            s1 += red[w];
-            s2 += red[NW + w];
+            s_rows += red[w];
+            s_slots += red[NW + w];
             gam = red[2 * NW + w] > gam ? red[2 * NW + w] : gam;
-            rows_cnt += red[3 * NW + w];
-            rows_len += ((long long *)(red + 4 * NW))[w];
+            nn += red[3 * NW + w];
+            ll += ((long long *)(red + 4 * NW))[w];
+        }
+        if (!ONE_SIDED) {
+            n_u = nn;
+            len_u = ll;
         }
         team_sync<TEAM>();
     }
-    out.s1 = s1;
-    out.s2 = s2;
+    out.s1 = rows_are_u ? s_rows : s_slots;  // |sq1| (u's side), |sq2| (v's side)
+    out.s2 = rows_are_u ? s_slots : s_rows;
     out.gamma = gam;
-    if (MODE == MODE_BYTES) {
-        // rows of u and v, the row of every non-triangle neighbour, row-pointer pairs, output
-        out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)rows_len + 8.0 * (double)(2 + rows_cnt) + 8.0;
-    }
+    if (!ONE_SIDED && MODE == MODE_BYTES)
+        out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)len_u + 8.0 * (double)(2 + n_u) + 8.0;
     return out;
 }
 
 template <int SLOTS, int TEAM, int MODE, int DESC_CAP>
 __device__ inline void pass_item(const View &g, int item, int count, const int32_t *work, int curv_type, double *curv,
-                                 double *bytes_total, unsigned *tab, int *red, int2 *desc, int *cnts) {
+                                 double *bytes_total, unsigned *tab, unsigned *cnt, int *red, int2 *desc,
+                                 int *cnts) {
     const int s = work[item];
     if (s < 0 || s >= g.cap_total) {  // cannot happen (classify writes valid slots); never chase a bad index
         row_ok(g, make_int2(-1, s), 6, item, count);
@@ -365,7 +506,7 @@ __device__ inline void pass_item(const View &g, int item, int count, const int32
     }
     const int u = g.slot_row[s];
     const int v = g.col[s];
-    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE, DESC_CAP>(g, u, v, tab, red, desc, cnts);
+    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE, DESC_CAP>(g, u, v, tab, cnt, red, desc, cnts);
     if (threadIdx.x == 0) {
         if (MODE == MODE_BFC) {
             curv[s] = bfc_formula(q.du, q.dv, q.T, q.s1, q.s2, q.gamma);
@@ -388,8 +529,9 @@ __global__ void __launch_bounds__(TEAM) k_edge_pass(View g, const int32_t *work,
                                                      int32_t *work_next, int curv_type, double *curv,
                                                      double *bytes_total) {
     __shared__ unsigned tab[SLOTS];
+    __shared__ unsigned cnt[DESC_CAP > 0 ? SLOTS : 1];
     __shared__ int2 desc[DESC_CAP > 0 ? DESC_CAP : 1];
-    __shared__ int red[6 * (TEAM / 64) + 2];
+    __shared__ int red[8 * (TEAM / 64) + 2];
     __shared__ int cnts[2];
     const int count = *work_count;
     if (count < 0 || count > g.cap_total) {  // cannot happen; never walk a list with a corrupt length
@@ -405,13 +547,13 @@ __global__ void __launch_bounds__(TEAM) k_edge_pass(View g, const int32_t *work,
             if (first >= count || first < 0) break;
             const int last = first + CHUNK < count ? first + CHUNK : count;
             for (int item = first; item < last; ++item)
-                pass_item<SLOTS, TEAM, MODE, DESC_CAP>(g, item, count, work, curv_type, curv, bytes_total, tab, red,
+                pass_item<SLOTS, TEAM, MODE, DESC_CAP>(g, item, count, work, curv_type, curv, bytes_total, tab, cnt, red,
                                                        desc, cnts);
         }
     } else {
         for (int item = blockIdx.x; item < count; item += gridDim.x)
-            pass_item<SLOTS, TEAM, MODE, DESC_CAP>(g, item, count, work, curv_type, curv, bytes_total, tab, red, desc,
-                                                   cnts);
+            pass_item<SLOTS, TEAM, MODE, DESC_CAP>(g, item, count, work, curv_type, curv, bytes_total, tab, cnt, red,
+                                                   desc, cnts);
     }
 }
 
@@ -419,10 +561,11 @@ __global__ void __launch_bounds__(TEAM) k_edge_pass(View g, const int32_t *work,
 template <int SLOTS, int TEAM, int DESC_CAP>
 __global__ void __launch_bounds__(TEAM) k_edge_single(View g, int u, int v, int64_t *out6) {
     __shared__ unsigned tab[SLOTS];
+    __shared__ unsigned cnt[DESC_CAP > 0 ? SLOTS : 1];
     __shared__ int2 desc[DESC_CAP > 0 ? DESC_CAP : 1];
-    __shared__ int red[6 * (TEAM / 64) + 2];
+    __shared__ int red[8 * (TEAM / 64) + 2];
     __shared__ int cnts[2];
-    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE_BFC, DESC_CAP>(g, u, v, tab, red, desc, cnts);
+    Ingredients q = edge_ingredients<SLOTS, TEAM, MODE_BFC, DESC_CAP>(g, u, v, tab, cnt, red, desc, cnts);
     if (threadIdx.x == 0) {
         out6[0] = q.du; out6[1] = q.dv; out6[2] = q.T; out6[3] = q.s1; out6[4] = q.s2; out6[5] = q.gamma;
     }
@@ -541,7 +684,7 @@ static void launch_bin(dcr_graph *g, const View &vw, int curv_type, double *byte
                        hipStream_t st) {
     constexpr int SLOTS = BIN_SLOTS[B];
     constexpr int TEAM = BIN_TEAM[B];
-    constexpr int LDS = SLOTS * 4 + bin_desc_cap(B) * 8 + 256;
+    constexpr int LDS = SLOTS * 4 * (bin_desc_cap(B) > 0 ? 2 : 1) + bin_desc_cap(B) * 8 + 512;
     // persistent grid: as many teams as fit a CU (wave slots, LDS), items dequeued dynamically
     int per_cu = (160 * 1024) / LDS;
     const int by_waves = 32 / (TEAM / 64);

@@ -173,7 +173,7 @@ int sync_result(dcr_graph *g) {
 }
 
 static int alloc_layout(dcr_graph *g, int64_t cap_total) {
-    DCR_TRY(dev_alloc(&g->col, cap_total));
+    DCR_TRY(dev_alloc(&g->col, cap_total + 64));  // padded: rows are read in aligned 16-byte pieces
     DCR_TRY(dev_alloc(&g->slot_row, cap_total));
     DCR_TRY(dev_alloc(&g->curv, cap_total));
     g->cap_total = cap_total;

@@ -36,7 +36,7 @@ void set_error(const std::string &msg);
 // An undirected edge (u,v) needs an LDS hash set over N(u) ∪ N(v) ∪ {u,v}; the bin is chosen by
 // that size so the table keeps a load factor <= 1/4 (1/2 in the last bin).  Threads per edge ("team") grow with the bin.
 constexpr int NBINS = 5;
-constexpr int BIN_SLOTS[NBINS] = {128, 512, 2048, 8192, 32768};
+constexpr int BIN_SLOTS[NBINS] = {128, 512, 2048, 4096, 32768};
 constexpr int BIN_TEAM[NBINS] = {64, 64, 256, 512, 1024};
 constexpr int MAX_TABLE_KEYS = BIN_SLOTS[NBINS - 1] / 2;  // du + dv + 2 must not exceed this
 constexpr int32_t MAX_NODES = (1 << 30) - 2;              // two tag bits live above the key
