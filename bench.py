@@ -155,6 +155,12 @@ def main():
                          'kernel': 'curvature pass = k_classify + k_edge_pass<bin 0..4>',
                          'algorithmic_bytes_per_launch': alg_bytes, 'launch_ms': pass_ms, 'launches': pass_count},
         }
+        pmc = os.path.join(REPO, 'profiles', 'r01_v3_pmc_traffic.json')
+        if os.path.exists(pmc) and args.nodes == 100000 and args.m == 10:
+            # HBM-side bytes per pass from a separate rocprofv3 --pmc run (counters cannot be read in-process)
+            with open(pmc) as f:
+                out['roofline']['traffic'] = json.load(f)['traffic_bytes_per_pass']
+            out['roofline']['traffic_source'] = 'profiles/r01_v3_pmc_traffic.json'
         ref_fix = os.path.join(REPO, 'tests', 'golden', 'reference_timing_s100k.json')
         if os.path.exists(ref_fix) and args.nodes == 100000 and args.m == 10:
             with open(ref_fix) as f:

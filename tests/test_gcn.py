@@ -1,0 +1,267 @@
+"""GCN path: call surface, normalisation, HIP SpMM numerics (fp32, tolerance 1e-5 as BASELINE.json's north_star
+states), autograd, the training driver and the 2-rank data-parallel path (gloo on CPU).
+
+The CPU tests select the plain-torch aggregation EXPLICITLY (models.gcn.set_aggregate_backend('torch')); the
+product default is the HIP kernel and refuses CPU tensors."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+TOL = 1e-5
+
+
+def _toy(n=60, f=12, c=4, seed=0):
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    ei, n = synthetic.powerlaw_graph(n, 3, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, f, generator=g)
+    y = torch.randint(0, c, (n,), generator=g)
+    perm = torch.randperm(n, generator=g)
+    masks = {}
+    for name, sl in (('train', slice(0, n // 2)), ('val', slice(n // 2, 3 * n // 4)), ('test', slice(3 * n // 4, n))):
+        m = torch.zeros(n, dtype=torch.bool)
+        m[perm[sl]] = True
+        masks[f'{name}_mask'] = m
+    data = Data(x=x, edge_index=torch.from_numpy(ei), y=y, num_nodes=n, **masks)
+    return data, Dataset(data, c)
+
+
+@pytest.fixture
+def torch_backend():
+    from models import gcn
+    gcn.set_aggregate_backend('torch')
+    yield
+    gcn.set_aggregate_backend('hip')
+
+
+def test_call_surface_and_state_dict_keys():
+    from models.gcn import GCN
+    data, ds = _toy()
+    m = GCN(ds, hidden=[16], dropout=0.3)
+    assert list(m.state_dict().keys()) == ['layers.0.bias', 'layers.0.lin.weight', 'layers.1.bias',
+                                           'layers.1.lin.weight']
+    assert m.state_dict()['layers.0.lin.weight'].shape == (16, 12)
+    assert m.state_dict()['layers.1.lin.weight'].shape == (4, 16)
+    assert {id(p) for p in m.reg_params} == {id(p) for p in m.layers[0].parameters()}
+    assert {id(p) for p in m.non_reg_params} == {id(p) for p in m.layers[1].parameters()}
+    assert float(m.layers[0].bias.abs().sum()) == 0.0
+    a = (6.0 / (12 + 16)) ** 0.5
+    assert float(m.layers[0].lin.weight.abs().max()) <= a
+    m2 = GCN(ds, hidden=[16], dropout=0.3)
+    m2.load_state_dict(m.state_dict())                                   # test_performance.py:72-73
+    m.reset_parameters()
+
+
+def test_gcn_norm_matches_dense():
+    from models.gcn import gcn_norm_csr
+    data, _ = _toy()
+    n = data.num_nodes
+    csr = gcn_norm_csr(data.edge_index, None, n)
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A[data.edge_index[1], data.edge_index[0]] = 1
+    A += torch.eye(n, dtype=torch.float64)
+    dinv = A.sum(1).pow(-0.5)
+    Ah = dinv[:, None] * A * dinv[None, :]
+    dense = torch.zeros(n, n, dtype=torch.float64)
+    rows = torch.repeat_interleave(torch.arange(n), csr.rowptr[1:] - csr.rowptr[:-1])
+    dense[rows, csr.col.long()] = csr.val.double()
+    assert (dense - Ah).abs().max() < 1e-6
+    dense_t = torch.zeros(n, n, dtype=torch.float64)
+    rows_t = torch.repeat_interleave(torch.arange(n), csr.rowptr_t[1:] - csr.rowptr_t[:-1])
+    dense_t[rows_t, csr.col_t.long()] = csr.val_t.double()
+    assert (dense_t - Ah.t()).abs().max() < 1e-6
+    # isolated node: its self loop has weight 1
+    ei = torch.tensor([[0, 1], [1, 0]])
+    c3 = gcn_norm_csr(ei, None, 3)
+    assert c3.val[c3.rowptr[2]:c3.rowptr[3]].tolist() == [1.0]
+
+
+def test_forward_backward_vs_dense_reference_cpu(torch_backend):
+    from models.gcn import GCN, dense_reference_logits
+    data, ds = _toy()
+    torch.manual_seed(1)
+    m = GCN(ds, hidden=[16], dropout=0.5)
+    with torch.no_grad():
+        for layer in m.layers:
+            layer.bias.uniform_(-0.1, 0.1)
+    m.eval()
+    got = m(data)
+    want = dense_reference_logits(m, data.x, data.edge_index, data.num_nodes)
+    assert (got.double() - want).abs().max() < TOL
+    loss = torch.nn.functional.nll_loss(got[data.train_mask], data.y[data.train_mask])
+    loss.backward()
+    g_got = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    want32 = dense_reference_logits(m, data.x, data.edge_index, data.num_nodes).float()
+    torch.nn.functional.nll_loss(want32[data.train_mask], data.y[data.train_mask]).backward()
+    for a, p in zip(g_got, m.parameters()):
+        assert (a - p.grad).abs().max() < 1e-5
+
+
+def test_training_loop_semantics(torch_backend):
+    from experiment.training_loop import evaluate, train, training_loop
+    from models.gcn import GCN
+    data, ds = _toy(n=80)
+    torch.manual_seed(3)
+    m = GCN(ds, hidden=[8], dropout=0.0)
+    opt = torch.optim.Adam([{'params': m.non_reg_params, 'weight_decay': 0}, {'params': m.reg_params, 'weight_decay': 5e-4}],
+                           lr=0.05)                                       # save_models.py:78-82
+    l0 = train(m, opt, data)
+    assert np.isfinite(l0)
+    r = evaluate(m, data, test=True)
+    assert set(r) == {'val_acc', 'test_acc'} and 0 <= r['val_acc'] <= 1
+    assert set(evaluate(m, data, test=False)) == {'val_acc'}
+
+    # early stopping: a model whose validation accuracy peaks at epoch 2 must come back with epoch-2 weights
+    class Scripted(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.step = 0
+            self.acc = [0.2, 0.5, 0.5, 0.4, 0.3, 0.3, 0.9]
+
+        def forward(self, d):
+            n = d.y.shape[0]
+            k = int(round(self.acc[min(self.step, len(self.acc) - 1)] * int(d.val_mask.sum())))
+            logp = torch.full((n, 2), -5.0) + self.w * 0
+            right = d.y.clone()
+            idx = d.val_mask.nonzero().flatten()
+            wrong = idx[k:]
+            right[wrong] = 1 - right[wrong]
+            logp[torch.arange(n), right] = 0.0
+            return logp
+
+    class Opt:
+        def __init__(self, m): self.m = m
+        def zero_grad(self): pass
+        def step(self):
+            self.m.step += 1
+            with torch.no_grad():
+                self.m.w += 1.0
+
+    from dcr.data import Data
+    y = torch.randint(0, 2, (40,))
+    tm = torch.zeros(40, dtype=torch.bool); tm[:10] = True
+    vm = torch.zeros(40, dtype=torch.bool); vm[10:30] = True
+    d = Data(y=y, train_mask=tm, val_mask=vm, num_nodes=40)
+    s = Scripted()
+    out = training_loop(s, Opt(s), d, epochs=50, patience=3)
+    # validation accuracies seen after each step: .5 .5 .4 .3 .3 -> best (ties move forward) is after step 2,
+    # three non-improving epochs follow, so training stops after step 5 and restores w == 2
+    assert out is s and float(s.w) == 2.0 and s.step == 5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from models import gcn
+    from models.gcn import GCN
+    from models.gcn_dp import ShardedGCN
+    gcn.set_aggregate_backend('torch')
+    data, ds = _toy(n=61, seed=4)                                         # 61: uneven blocks
+    torch.manual_seed(7)
+    base = GCN(ds, hidden=[8], dropout=0.0)
+    ref = GCN(ds, hidden=[8], dropout=0.0)
+    ref.load_state_dict(base.state_dict())
+    sh = ShardedGCN(base, data.edge_index, data.num_nodes)
+    xl, yl, tl = sh.shard(data.x), sh.shard(data.y), sh.shard(data.train_mask)
+    n_train = int(data.train_mask.sum())
+    ref.eval(); sh.eval()
+    full = ref(data)
+    local = sh(xl)
+    err_fwd = (local - full[sh.r0:sh.r1]).abs().max().item()
+    opt = torch.optim.SGD(base.parameters(), lr=0.1)
+    sh.train_step(opt, xl, yl, tl, n_train)
+    ref.train()
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    ropt.zero_grad()
+    torch.nn.functional.nll_loss(ref(data)[data.train_mask], data.y[data.train_mask]).backward()
+    ropt.step()
+    err_w = max((a - b).abs().max().item() for a, b in zip(base.parameters(), ref.parameters()))
+    acc = sh.eval_correct(xl, yl, sh.shard(data.val_mask))
+    ref.eval()
+    with torch.no_grad():
+        lp = ref(data)
+    acc_ref = (lp[data.val_mask].argmax(1) == data.y[data.val_mask]).float().mean().item()
+    ret[rank] = (err_fwd, err_w, abs(acc - acc_ref))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for rank, (err_fwd, err_w, dacc) in ret.items():
+        assert err_fwd < TOL and err_w < TOL and dacc < 1e-6, (rank, err_fwd, err_w, dacc)
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('feat', [1, 7, 16, 30, 64, 128, 130, 256])
+def test_spmm_hip_vs_torch(feat):
+    from models import gcn
+    from dcr import synthetic
+    ei, n = synthetic.powerlaw_graph(3000, 6, seed=2)
+    ei = torch.from_numpy(ei).cuda()
+    csr = gcn.gcn_norm_csr(ei, None, n)
+    torch.manual_seed(0)
+    B = torch.randn(n, feat, device='cuda')
+    bias = torch.randn(feat, device='cuda')
+    for b, relu in ((None, False), (bias, False), (bias, True)):
+        got = gcn._spmm_hip(csr.rowptr, csr.col, csr.val, B, n, b, relu)
+        want = gcn._spmm_torch(csr.rowptr, csr.col, csr.val, B.double(), n, None if b is None else b.double(), relu)
+        assert (got.double() - want).abs().max().item() < TOL, (feat, relu)
+    got_t = gcn._spmm_hip(csr.rowptr_t, csr.col_t, csr.val_t, B, n)
+    assert (got_t - gcn._spmm_hip(csr.rowptr, csr.col, csr.val, B, n)).abs().max().item() < TOL  # Â is symmetric here
+
+
+@pytest.mark.gpu
+def test_gcn_gpu_forward_backward_vs_dense_reference():
+    from models.gcn import GCN, dense_reference_logits
+    data, ds = _toy(n=500, f=40, c=6)
+    data = data.to('cuda')
+    torch.manual_seed(1)
+    m = GCN(ds, hidden=[32], dropout=0.5).cuda()
+    m.eval()
+    got = m(data)
+    want = dense_reference_logits(m, data.x, data.edge_index, data.num_nodes)
+    assert (got.double() - want).abs().max().item() < TOL
+    torch.nn.functional.nll_loss(got[data.train_mask], data.y[data.train_mask]).backward()
+    g_got = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    w64 = dense_reference_logits(m, data.x, data.edge_index, data.num_nodes)
+    torch.nn.functional.nll_loss(w64[data.train_mask], data.y[data.train_mask]).backward()
+    for a, p in zip(g_got, m.parameters()):
+        assert (a - p.grad).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_rewire_then_train_end_to_end_gpu():
+    """The reference's flow (save_models.py:46,74-85): rewire -> GCN -> Adam with two parameter groups -> training_loop."""
+    from experiment.training_loop import evaluate, training_loop
+    from models.gcn import GCN
+    from rewiring.rewire import rewire
+    data, ds = _toy(n=400, f=24, c=5, seed=9)
+    np.random.seed(0)
+    data.edge_index = rewire(data, 'bfc', 10, 0.95, 163)
+    data = data.to('cuda')
+    torch.manual_seed(0)
+    m = GCN(ds, hidden=[16], dropout=0.3).cuda()
+    opt = torch.optim.Adam([{'params': m.non_reg_params, 'weight_decay': 0},
+                            {'params': m.reg_params, 'weight_decay': 0.01}], lr=0.02)
+    m = training_loop(m, opt, data, epochs=30, patience=10)
+    r = evaluate(m, data, test=True)
+    assert 0.0 <= r['test_acc'] <= 1.0 and r['val_acc'] > 0.15

@@ -1,0 +1,98 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports every declared symbol, the product path
+refuses to run without a GPU, host-side helpers match the reference's semantics."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def test_library_exports_every_declared_symbol():
+    from dcr import _lib
+    header = open(os.path.join(REPO, 'include', 'dcr.h')).read()
+    declared = set(re.findall(r'\b(dcr_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f'{name} declared in include/dcr.h but not exported'
+    assert declared == set(_lib.SIGNATURES), 'ctypes signature table and header disagree'
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_path_fails_loudly_without_gpu():
+    from dcr import _lib
+    from dcr.graph import DcrGraph
+    with pytest.raises(_lib.DcrError):
+        DcrGraph(np.array([[1, 0], [0, 1]]), 2)
+    from dcr.data import Data
+    from rewiring.rewire import rewire
+    with pytest.raises(_lib.DcrError):
+        rewire(Data(edge_index=torch.tensor([[1, 0], [0, 1]]), num_nodes=2), 'bfc', 1, 0.5, 1.0)
+    from models.gcn import spmm
+    with pytest.raises(RuntimeError):
+        spmm(torch.zeros(2, dtype=torch.int64), torch.zeros(0, dtype=torch.int32), torch.zeros(0), torch.zeros(1, 4), 1)
+
+
+def test_bad_arguments_rejected_before_any_device_call():
+    from dcr.graph import DcrGraph
+    with pytest.raises(ValueError):
+        DcrGraph(np.array([[0, 1], [0, 0]]), 2)          # self-loop
+    with pytest.raises(ValueError):
+        DcrGraph(np.array([[5, 0], [0, 5]]), 3)          # id out of range
+    with pytest.raises(ValueError):
+        DcrGraph(np.zeros((3, 2), dtype=np.int64), 3)    # wrong shape
+    with pytest.raises(Exception):
+        from dcr.graph import curv_code
+        curv_code('ollivier')
+
+
+def test_softmax_semantics():
+    from utils.softmax import softmax
+    a = np.array([0.1, 0.7, 0.7, -0.2])
+    assert softmax(a, float('inf')).tolist() == [0.0, 1.0, 0.0, 0.0]      # first arg-max
+    p = softmax(a, 3.0)
+    e = np.exp(a * 3.0)
+    assert np.array_equal(p, e / e.sum())
+    with np.errstate(over='ignore', invalid='ignore'):
+        bad = softmax(np.array([1.0, 2.0]), 5000)
+    assert np.isnan(bad).any()
+    with pytest.raises(ValueError):
+        np.random.choice(2, p=bad)                                          # what the reference's loop raises
+
+
+def test_tau_inf_draw_consumes_one_uniform():
+    """sdrf_no_cuda's tau=inf shortcut replaces np.random.choice(p=one-hot) by one random_sample():
+    the legacy stream must stay aligned."""
+    onehot = np.zeros(7)
+    onehot[3] = 1
+    np.random.seed(5)
+    idx = np.random.choice(range(7), p=onehot)
+    after_choice = np.random.random_sample()
+    np.random.seed(5)
+    np.random.random_sample()
+    after_shortcut = np.random.random_sample()
+    assert idx == 3 and after_choice == after_shortcut
+
+
+def test_synthetic_generator_is_deterministic():
+    from dcr import synthetic
+    ei, n = synthetic.powerlaw_graph(500, 4, seed=12345)
+    assert n == 500 and ei.shape == (2, 2 * 4 * (500 - 4))
+    assert (ei[0] != ei[1]).all()
+    key = ei[0] * n + ei[1]
+    assert (np.diff(key) > 0).all()                                         # coalesced + sorted
+    assert np.array_equal(ei, synthetic.powerlaw_graph(500, 4, seed=12345)[0])
+    import hashlib
+    assert hashlib.sha1(ei.tobytes()).hexdigest() == hashlib.sha1(
+        synthetic.coalesced_edge_index(ei[0], ei[1], n).tobytes()).hexdigest()
+
+
+def test_data_duck_typing():
+    from dcr.data import Data
+    d = Data(x=torch.zeros(4, 3), edge_index=torch.zeros(2, 0, dtype=torch.long), val_mask=torch.ones(4, dtype=torch.bool))
+    assert d.num_nodes == 4 and d['val_mask'].all() and 'x' in d and d.edge_attr is None
