@@ -68,6 +68,89 @@ def cpu_baseline(ei, n, E, budget_s=12.0):
     }
 
 
+def gcn_bench(args, rank, world, local_rank, dist):
+    """GCN epochs/sec (BASELINE.json configs[4] shape): synthetic N=1M / E=10M graph, F=256, hidden 128, 16 classes,
+    dropout 0.5, Adam; epoch = one training step + one validation forward (experiment/training_loop.py:25-26).
+    N > 1: row-partitioned data parallel (models/gcn_dp.py), fixed problem size -> strong scaling."""
+    import torch
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from models.gcn import GCN, gcn_norm_csr, _spmm_hip
+    from models.gcn_dp import ShardedGCN
+    dev = torch.device('cuda', local_rank)
+    n, m, F, H, C = args.gcn_nodes, 10, 256, 128, 16
+    ei_np, n = synthetic.powerlaw_graph(n, m, seed=12345)
+    ei = torch.from_numpy(ei_np).to(dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(n, F, device=dev, generator=g)
+    y = torch.randint(0, C, (n,), device=dev, generator=g)
+    r = torch.rand(n, device=dev, generator=g)
+    train_mask, val_mask = r < 0.1, (r >= 0.1) & (r < 0.2)
+    torch.manual_seed(0)
+    data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=train_mask, val_mask=val_mask)
+    model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
+    opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                            {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        from experiment.training_loop import evaluate, train
+
+        def epoch():
+            train(model, opt, data)
+            evaluate(model, data, test=False)
+    else:
+        sh = ShardedGCN(model, ei, n)
+        xl, yl, tl, vl = sh.shard(x), sh.shard(y), sh.shard(train_mask), sh.shard(val_mask)
+        n_train = int(train_mask.sum())
+
+        def epoch():
+            sh.train_step(opt, xl, yl, tl, n_train)
+            sh.eval_correct(xl, yl, vl)
+
+    for _ in range(args.gcn_warmup):
+        epoch()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.gcn_epochs):
+        epoch()
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    res = {'metric': 'GCN epochs/sec', 'value': args.gcn_epochs / el, 'unit': 'epochs/sec', 'n_gpus': world,
+           'epochs': args.gcn_epochs, 'ms_per_epoch': el / args.gcn_epochs * 1e3, 'scaling': 'strong', 'dtype': 'f32',
+           'config': {'workload': f'synthetic preferential-attachment graph N={n} E={ei_np.shape[1] // 2}, F={F}, '
+                                  f'hidden={H}, classes={C}, dropout 0.5, Adam; epoch = train step + val forward',
+                      'parallelism': f'row-partitioned dp{world}' if world > 1 else 'single GPU'}}
+    if rank == 0:
+        # SpMM roofline on this rank's block of Â (hidden width), HIP events on torch's current stream
+        csr = gcn_norm_csr(ei, None, n) if world == 1 else sh.csr
+        z = torch.randn(n, H, device=dev)
+        for _ in range(3):
+            _spmm_hip(csr.rowptr, csr.col, csr.val, z, csr.n_rows)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            _spmm_hip(csr.rowptr, csr.col, csr.val, z, csr.n_rows)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nnz = int(csr.col.shape[0])
+        nbytes = nnz * 8 + (csr.n_rows + 1) * 8 + (n + csr.n_rows) * H * 4
+        res['spmm_roofline'] = {'bound': 'hbm', 'achieved': nbytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
+                                'unit': 'GB/s', 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'launch_ms': ms,
+                                'algorithmic_bytes_per_launch': nbytes, 'nnz': nnz, 'n_feat': H}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -78,6 +161,10 @@ def main():
     ap.add_argument('--tau', type=float, default=163.0)
     ap.add_argument('--removal-bound', type=float, default=0.95)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gcn', action='store_true')
+    ap.add_argument('--gcn-nodes', type=int, default=1000000)
+    ap.add_argument('--gcn-epochs', type=int, default=20)
+    ap.add_argument('--gcn-warmup', type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -134,6 +221,9 @@ def main():
     else:
         total_steps = steps_done
 
+    run = G = None  # release the SDRF graph before the GCN leg
+    gcn = None if args.no_gcn else gcn_bench(args, rank, world, local_rank, dist)
+
     if rank == 0:
         pass_ms = pass_ms_total / max(pass_count, 1)
         alg_bytes = 0.5 * (bytes0 + bytes1)
@@ -169,6 +259,8 @@ def main():
                 'bfc_edges_per_sec': r['edges_per_sec'], 'pass_seconds': r['extrapolated_pass_seconds'],
                 'note': 'reference bfc_naive.bfc_edge itself, timed in the build container on sampled edges of this '
                         'same graph (tools/make_golden.py); the Python reference cannot travel to the GPU box'}
+        if gcn is not None:
+            out['gcn'] = gcn
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(ei, n, E)
         print(json.dumps(out), flush=True)
