@@ -33,6 +33,25 @@ def _make_data(data, edge_index):
         return Data(x=getattr(data, 'x', None), edge_index=ei, num_nodes=data.num_nodes)
 
 
+_ATOL = float(np.sqrt(np.finfo(np.float64).eps))
+
+
+def choice_index(p):
+    """``np.random.choice(len(p), p=p)`` (sdrf_no_cuda.py:49-50) for a vector produced by ``utils.softmax``: the same
+    index and the same consumption of the legacy global stream.  ``RandomState.choice`` computes
+    ``cdf = p.cumsum(); cdf /= cdf[-1]; idx = cdf.searchsorted(random_sample(), side='right')`` after validating
+    ``p``; for ``exp(a*tau)/sum`` those checks can only trip on NaN (overflow) or an all-zero vector, which are
+    raised here with numpy's messages.  Pinned against numpy in tests/test_host_cpu.py."""
+    cdf = p.cumsum()
+    total = cdf[-1]
+    if np.isnan(total):
+        raise ValueError('probabilities contain NaN')
+    if abs(total - 1.0) > _ATOL:
+        raise ValueError('probabilities do not sum to 1')
+    cdf /= total
+    return int(cdf.searchsorted(np.random.random_sample(), side='right'))
+
+
 class SdrfRun:
     """One SDRF rewiring run, steppable: ``step()`` is one iteration of the loop body
     sdrf_no_cuda.py:22-66 and returns False when the reference loop would ``break``."""
@@ -73,7 +92,7 @@ class SdrfRun:
             imp, ci, cj = G.improvements(x, y, curv_type, want_candidates=want_trace)
             n_cand = imp.shape[0]
             if n_cand:
-                idx = int(np.random.choice(n_cand, p=softmax(np.array(imp), tau=tau)))
+                idx = choice_index(softmax(np.array(imp), tau=tau))
                 if want_trace:
                     k, l = int(ci[idx]), int(cj[idx])
                     rec['candidates'] = np.stack([ci, cj], 1).tolist()

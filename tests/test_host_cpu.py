@@ -96,3 +96,27 @@ def test_data_duck_typing():
     from dcr.data import Data
     d = Data(x=torch.zeros(4, 3), edge_index=torch.zeros(2, 0, dtype=torch.long), val_mask=torch.ones(4, dtype=torch.bool))
     assert d.num_nodes == 4 and d['val_mask'].all() and 'x' in d and d.edge_attr is None
+
+
+def test_choice_index_matches_numpy_choice():
+    from rewiring.sdrf_no_cuda import choice_index
+    from utils.softmax import softmax
+    rng = np.random.Generator(np.random.PCG64(3))
+    for trial in range(200):
+        n = int(rng.integers(1, 4000))
+        a = rng.choice(np.array([0.0, 0.0, 0.0, 1e-3, -2e-3, 0.01, 0.3, -0.4]), size=n) * rng.random()
+        tau = float(rng.choice([0.5, 20, 163, 1000, float('inf')]))
+        p = softmax(a, tau)
+        np.random.seed(trial)
+        want = int(np.random.choice(range(n), p=p))
+        after_want = np.random.random_sample()
+        np.random.seed(trial)
+        got = choice_index(p.copy())
+        after_got = np.random.random_sample()
+        assert got == want and after_got == after_want, (trial, n, tau)
+    with np.errstate(over='ignore', invalid='ignore'):
+        bad = softmax(np.array([1.0, 2.0, 3.0]), 5000)
+    with pytest.raises(ValueError, match='NaN'):
+        choice_index(bad)
+    with pytest.raises(ValueError):
+        np.random.choice(3, p=bad)
