@@ -97,7 +97,7 @@ def gcn_bench(args, rank, world, local_rank, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if dist is None:
         from experiment.training_loop import evaluate, train
 
         def epoch():
@@ -131,7 +131,7 @@ def gcn_bench(args, rank, world, local_rank, dist):
                       'parallelism': f'row-partitioned dp{world}' if world > 1 else 'single GPU'}}
     if rank == 0:
         # SpMM roofline on this rank's block of Â (hidden width), HIP events on torch's current stream
-        csr = gcn_norm_csr(ei, None, n) if world == 1 else sh.csr
+        csr = gcn_norm_csr(ei, None, n) if dist is None else sh.csr
         z = torch.randn(n, H, device=dev)
         for _ in range(3):
             _spmm_hip(csr.rowptr, csr.col, csr.val, z, csr.n_rows)
@@ -147,7 +147,9 @@ def gcn_bench(args, rank, world, local_rank, dist):
         nbytes = nnz * 8 + (csr.n_rows + 1) * 8 + (n + csr.n_rows) * H * 4
         res['spmm_roofline'] = {'bound': 'hbm', 'achieved': nbytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
                                 'unit': 'GB/s', 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'launch_ms': ms,
-                                'algorithmic_bytes_per_launch': nbytes, 'nnz': nnz, 'n_feat': H}
+                                'algorithmic_bytes_per_launch': nbytes, 'nnz': nnz, 'n_feat': H,
+                                # every non-zero gathers one row of Z: what the memory system actually serves
+                                'gathered_GBps': (nnz * (H * 4 + 8)) / (ms * 1e-3) / 1e9}
     return res
 
 
@@ -179,8 +181,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the measured path)')
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('DCR_BENCH_FORCE_DIST') == '1'  # exercise the N>1 code path on one GPU (testing aid)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     def barrier():

@@ -225,3 +225,143 @@ def test_unsorted_duplicate_input(dcr, oracle):
     eu, ev, cv = G.curvature_all('bfc')
     _, _, oc = C.curv_all('bfc')
     assert np.array_equal(cv, oc)
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_s100k_properties(dcr, oracle):
+    """BASELINE.json's north-star size.  The oracle cannot run a whole SDRF iteration here in seconds, so parity is
+    checked through sampled edges and size-independent properties."""
+    from dcr import synthetic
+    ei, nn = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    E = ei.shape[1] // 2
+    assert E == 999900
+    G = dcr(ei, nn)
+    C = oracle.CGraph(ei, nn)
+    eu, ev, cv = G.curvature_all('bfc')
+    ou, ov = C.edges()
+    assert np.array_equal(eu, ou) and np.array_equal(ev, ov)                  # G.edges order at 1M edges
+    rng = np.random.Generator(np.random.PCG64(42))
+    deg = np.bincount(ei[0], minlength=nn)
+    heavy = np.argsort(-(deg[eu].astype(np.int64) * deg[ev]))[:300]           # hub-hub edges: the big bins
+    pick = np.concatenate([rng.choice(E, size=5000, replace=False), heavy])
+    assert np.array_equal(cv[pick], C.curv_edges(eu[pick], ev[pick], 'bfc', nthreads=16))
+    # idempotence: a second pass writes the same bits; relabelling-free symmetry: (v,u) == (u,v)
+    _, _, cv2 = G.curvature_all('bfc')
+    assert np.array_equal(cv, cv2)
+    for e in heavy[:5].tolist() + pick[:5].tolist():
+        assert G.curvature_edge(int(ev[e]), int(eu[e])) == cv[e] == G.curvature_edge(int(eu[e]), int(ev[e]))
+    # arg-min / arg-max: first extremum in edge order
+    x, y, val = G.argext(False)
+    m = int(np.argmin(cv))
+    assert (x, y, val) == (int(eu[m]), int(ev[m]), cv[m])
+    x2, y2, val2 = G.argext(True)
+    m2 = int(np.argmax(cv))
+    assert (x2, y2, val2) == (int(eu[m2]), int(ev[m2]), cv[m2])
+    # improvements of the arg-min (hub) edge: candidate list exact, sampled values against literal recompute
+    imp, ci, cj = G.improvements(x, y, 'bfc', want_candidates=True)
+    oi, oj = C.candidates(x, y)
+    assert np.array_equal(ci, oi) and np.array_equal(cj, oj)
+    sel = np.sort(rng.choice(len(oi), size=400, replace=False))
+    assert np.array_equal(np.array(imp)[sel], C.improvements(x, y, oi[sel], oj[sel], 'bfc'))
+    assert G.improvements_argmax() == int(np.argmax(np.array(imp)))
+    # a few SDRF iterations: the rewired graph stays consistent with the oracle's view of the same operations
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import SdrfRun
+    import torch
+    np.random.seed(0)
+    trace = []
+    run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=nn), 'bfc', True, 0.95, 163, trace=trace)
+    for _ in range(3):
+        run.step()
+    for rec in trace:
+        assert rec['removed'] is None or C.has_edge(*rec['removed'])
+        if rec['added']:
+            assert not C.has_edge(*rec['added'])
+            C.add_edge(*rec['added'])
+        if rec['removed']:
+            C.remove_edge(*rec['removed'])
+    assert np.array_equal(run.G.to_edge_index(), C.to_edge_index())
+    eu3, ev3, cv3 = run.G.curvature_all('bfc')
+    pick3 = rng.choice(eu3.shape[0], size=3000, replace=False)
+    assert np.array_equal(cv3[pick3], C.curv_edges(eu3[pick3], ev3[pick3], 'bfc', nthreads=16))
+
+
+def test_edge_cases(dcr, oracle):
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import sdrf_no_cuda
+    import torch
+    # no edges at all: the reference's min() over an empty sequence raises ValueError
+    with pytest.raises(ValueError):
+        sdrf_no_cuda(Data(edge_index=torch.zeros(2, 0, dtype=torch.long), num_nodes=4), 'bfc', 3, True, 0.5, 10)
+    G = dcr(np.zeros((2, 0), dtype=np.int64), 4)
+    assert G.number_of_edges() == 0 and G.to_edge_index().shape == (2, 0)
+    G.curvature_pass('bfc')
+    assert G.curvature_read()[2].shape == (0,)
+    # one edge, isolated nodes: degree-1 rule, then candidates come only from the end points
+    ei = np.array([[1, 0], [0, 1]])
+    G = dcr(ei, 5)
+    assert G.curvature_all('bfc')[2].tolist() == [0.0]
+    imp, ci, cj = G.improvements(0, 1, 'bfc', want_candidates=True)
+    assert imp.shape[0] == 0
+    # star: all edges have a degree-1 end point -> curvature 0 everywhere; SDRF still matches the oracle
+    star = np.array([[1, 2, 3, 4, 5, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1, 2, 3, 4, 5]])
+    for ct in ('bfc', '1d', 'haantjes'):
+        np.random.seed(3)
+        want = oracle.sdrf(star, 6, ct, 6, True, 0.5, 7.0)
+        np.random.seed(3)
+        got = sdrf_no_cuda(Data(edge_index=torch.from_numpy(star), num_nodes=6), ct, 6, True, 0.5, 7.0)
+        assert np.array_equal(got.edge_index.numpy(), want), ct
+    # complete graph: no candidate can be added; with a high bound nothing is removed and the loop stops at once
+    k5 = np.array([[i for i in range(5) for j in range(5) if i != j], [j for i in range(5) for j in range(5) if i != j]])
+    trace = []
+    out = sdrf_no_cuda(Data(edge_index=torch.from_numpy(k5), num_nodes=5), 'bfc', 10, True, 99.0, 1.0, trace=trace)
+    assert len(trace) == 1 and out.edge_index.shape[1] == 20
+    # remove_edges=False stops when nothing can be added
+    trace = []
+    sdrf_no_cuda(Data(edge_index=torch.from_numpy(k5), num_nodes=5), 'bfc', 10, False, 0.5, 1.0, trace=trace)
+    assert len(trace) == 1
+
+
+@pytest.mark.parametrize('ct', ['1d', 'haantjes'])
+def test_classical_improvements_vs_oracle(dcr, oracle, ct):
+    from dcr import synthetic
+    ei, nn = synthetic.powerlaw_graph(300, 5, seed=8)
+    G = dcr(ei, nn)
+    C = oracle.CGraph(ei, nn)
+    eu, ev = G.edges()
+    for e in (0, 17, 400, len(eu) - 1):
+        x, y = int(eu[e]), int(ev[e])
+        imp, ci, cj = G.improvements(x, y, ct, want_candidates=True)
+        oi, oj = C.candidates(x, y)
+        assert np.array_equal(ci, oi) and np.array_equal(cj, oj)
+        assert np.array_equal(np.array(imp), C.improvements(x, y, oi, oj, ct))
+
+
+def test_bfc_cuda_call_surface(oracle):
+    """curvature/bfc_cuda.py's entry points: names, arguments, shapes, the -1000 sentinel; bfc_naive numerics."""
+    import torch
+    from curvature.bfc_cuda import balanced_forman_curvature, balanced_forman_post_delta
+    from dcr import synthetic
+    ei, nn = synthetic.powerlaw_graph(40, 3, seed=1)
+    A = torch.zeros(nn, nn, device='cuda')
+    A[ei[0], ei[1]] = 1
+    Cm = balanced_forman_curvature(A)
+    O = oracle.CGraph(ei, nn)
+    ou, ov, oc = O.curv_all('bfc')
+    assert Cm.shape == (nn, nn) and Cm.dtype == A.dtype
+    assert torch.equal(Cm, Cm.t())
+    assert np.allclose(Cm[ou, ov].cpu().numpy(), oc.astype(np.float32), rtol=0, atol=0)
+    assert float(Cm[A == 0].abs().sum()) == 0.0
+    x, y = int(ou[3]), int(ov[3])
+    xn = [int(v) for v in ei[1][ei[0] == x]] + [x]
+    yn = [int(v) for v in ei[1][ei[0] == y]] + [y]
+    D = balanced_forman_post_delta(A, x, y, xn, yn)
+    assert D.shape == (len(xn), len(yn))
+    before = O.curv_edge(x, y)
+    for I, i in enumerate(xn):
+        for J, j in enumerate(yn):
+            if i == j or O.has_edge(i, j):
+                assert float(D[I, J]) == -1000.0
+            else:
+                imp = O.improvements(x, y, np.array([min(i, j)]), np.array([max(i, j)]), 'bfc')[0]
+                assert abs(float(D[I, J]) - (before + imp)) < 1e-6
