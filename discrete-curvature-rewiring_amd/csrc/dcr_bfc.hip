@@ -35,6 +35,7 @@ struct View {
     const int32_t *slot_row;
     int64_t cap_total;
     int32_t *guard;  // [8] first violated invariant: code, block, item data (debug / safety net)
+    const uint8_t *dirty;  // incremental pass: only edges with a flagged endpoint are recomputed (nullptr: all)
 };
 
 __device__ inline bool row_ok(const View &g, const int2 rk, int code, int a, int b) {
@@ -585,6 +586,7 @@ __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total,
     if ((int)(s - ru.x) >= ru.y) return -1;
     const int v = g.col[s];
     if (v <= u) return -1;
+    if (g.dirty && !(g.dirty[u] | g.dirty[v])) return -1;  // untouched neighbourhood: the stored value is still exact
     const int dv = g.rowinfo[v].y, du = ru.y;
     if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
         if (finish_trivial) curv[s] = (double)(4 - du - dv);
@@ -697,9 +699,9 @@ static void launch_bin(dcr_graph *g, const View &vw, int curv_type, double *byte
 }
 
 template <int MODE>
-static int run_pass(dcr_graph *g, int curv_type, double *bytes_total) {
+static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incremental = false) {
     DCR_TRY(ensure_work(g));
-    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr};
     WorkLists wl;
     for (int b = 0; b < NBINS; ++b) wl.w[b] = g->work[b];
     if (g->num_cu <= 0) {
@@ -739,9 +741,10 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total) {
     return DCR_OK;
 }
 
-int launch_curvature_pass(dcr_graph *g, int curv_type) {
-    if (curv_type == DCR_CURV_BFC || curv_type == DCR_CURV_1D) return run_pass<MODE_BFC>(g, curv_type, nullptr);
-    return run_pass<MODE_TRI>(g, curv_type, nullptr);
+int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental) {
+    if (curv_type == DCR_CURV_BFC || curv_type == DCR_CURV_1D)
+        return run_pass<MODE_BFC>(g, curv_type, nullptr, incremental);
+    return run_pass<MODE_TRI>(g, curv_type, nullptr, incremental);
 }
 
 template <int B>
@@ -756,12 +759,23 @@ using namespace dcr;
 
 extern "C" {
 
-int dcr_curvature_pass(dcr_graph *g, int curv_type) {
+static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental);
+
+int dcr_curvature_pass(dcr_graph *g, int curv_type) { return curvature_pass_impl(g, curv_type, false); }
+
+int dcr_curvature_pass_incremental(dcr_graph *g, int curv_type) { return curvature_pass_impl(g, curv_type, true); }
+
+static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental) {
     if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
     DCR_HIP(hipSetDevice(g->device));
+    // incremental is only sound on top of a complete buffer of the same curvature kind whose later edits were all
+    // recorded in the dirty flags (dcr_graph_add_edge / _remove_edge / dcr_sdrf_tail do that)
+    const bool incremental = want_incremental && g->curv_valid && g->curv_type_last == curv_type && g->dirty_tracked;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev0, g->stream));
-    DCR_TRY(launch_curvature_pass(g, curv_type));
+    DCR_TRY(launch_curvature_pass(g, curv_type, incremental));
+    DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+    g->dirty_tracked = true;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
     DCR_TRY(sync_result(g));
     if (g->profile) {
@@ -794,7 +808,7 @@ int dcr_bfc_ingredients(dcr_graph *g, int32_t u, int32_t v, int64_t out6[6]) {
     const int keys = du + dv + 2;
     int64_t *d_out = nullptr;
     DCR_TRY(dev_alloc(&d_out, 6));
-    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, nullptr};
     if (keys <= bin_max_keys(0)) launch_single<0>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(1)) launch_single<1>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(2)) launch_single<2>(g, vw, u, v, d_out);

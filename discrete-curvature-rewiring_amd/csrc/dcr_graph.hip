@@ -124,6 +124,33 @@ __global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *
     }
 }
 
+// Incremental curvature: BFC(a,b) depends on N(a), N(b) and on the rows of their members, so an edit of edge
+// (u,v) can change exactly the edges that have an endpoint in {u,v} ∪ N(u) ∪ N(v).
+__device__ inline void dev_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u, int32_t v,
+                                      int tid, int nthreads) {
+    if (u < 0 || v < 0) return;
+    const int2 ru = rowinfo[u], rv = rowinfo[v];
+    for (int i = tid; i < ru.y; i += nthreads) dirty[col[ru.x + i]] = 1;
+    for (int i = tid; i < rv.y; i += nthreads) dirty[col[rv.x + i]] = 1;
+    if (tid == 0) {
+        dirty[u] = 1;
+        dirty[v] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u,
+                                                     int32_t v) {
+    dev_mark_dirty(rowinfo, col, dirty, u, v, threadIdx.x, blockDim.x);
+}
+
+// the edge the tail is about to remove (it is only known on the device)
+__global__ void __launch_bounds__(256) k_mark_dirty_ext(const int2 *rowinfo, const int32_t *col, uint8_t *dirty,
+                                                         const DevResult *res, double bound) {
+    if (res->add_status == 1) return;
+    if (res->ext_slot >= 0 && res->ext_val > bound)
+        dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, threadIdx.x, blockDim.x);
+}
+
 __global__ void __launch_bounds__(64) k_has_edge(const int2 *rowinfo, const int32_t *col, int32_t u, int32_t v,
                                                  DevResult *res) {
     int2 ru = rowinfo[u], rv = rowinfo[v];
@@ -163,7 +190,14 @@ void launch_add_edge(dcr_graph *g, int32_t u, int32_t v) {
 }
 
 void launch_remove_if_above(dcr_graph *g, double bound) {
+    // flag the neighbourhood while the edge is still there, then remove it
+    hipLaunchKernelGGL(k_mark_dirty_ext, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, g->dres, bound);
     hipLaunchKernelGGL(k_remove_if_above, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->dres, bound);
+}
+
+void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v) {
+    if (u < 0 || v < 0) return;
+    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v);
 }
 
 int sync_result(dcr_graph *g) {
@@ -320,6 +354,8 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_TRY(alloc_layout(g, tot));
     DCR_TRY(dev_alloc(&g->dres, 1));
     DCR_TRY(dev_alloc(&g->imp_stats, 1));
+    DCR_TRY(dev_alloc(&g->dirty, n));
+    DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(n > 0 ? n : 1), g->stream));
     DCR_HIP(hipHostMalloc((void **)&g->hres, sizeof(DevResult), hipHostMallocDefault));
     std::memset(g->hres, 0, sizeof(DevResult));
     DCR_HIP(hipMemsetAsync(g->dres, 0, sizeof(DevResult), g->stream));
@@ -344,7 +380,7 @@ int dcr_graph_destroy(dcr_graph *g) {
     void *dev_ptrs[] = {g->rowinfo, g->rowcap, g->col, g->slot_row, g->curv, g->red_scratch, g->scan_a, g->scan_b,
                         g->imp_table, g->imp_posx, g->imp_posy, g->imp_c1, g->imp_c2, g->imp_b, g->imp_c,
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
-                        g->imp_stats, g->dres};
+                        g->imp_stats, g->dres, g->dirty};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)
@@ -393,6 +429,7 @@ int dcr_graph_add_edge(dcr_graph *g, int32_t u, int32_t v) {
         DCR_TRY(sync_result(g));
         if (g->hres->add_status == 0) {
             g->n_edges++;
+            launch_mark_dirty(g, u, v);
             return DCR_OK;
         }
         if (g->hres->add_status == 2) return DCR_OK;  // networkx: adding an existing edge changes nothing
@@ -404,6 +441,7 @@ int dcr_graph_add_edge(dcr_graph *g, int32_t u, int32_t v) {
 int dcr_graph_remove_edge(dcr_graph *g, int32_t u, int32_t v) {
     DCR_TRY(check_pair(g, u, v));
     DCR_HIP(hipSetDevice(g->device));
+    launch_mark_dirty(g, u, v);
     hipLaunchKernelGGL(k_remove_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, u, v, g->dres);
     DCR_HIP(hipGetLastError());
     DCR_TRY(sync_result(g));

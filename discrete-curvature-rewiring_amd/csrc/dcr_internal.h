@@ -88,6 +88,8 @@ struct dcr_graph {
 
     int curv_type_last = -1;
     bool curv_valid = false;
+    uint8_t *dirty = nullptr;    // [n] node flags: an incident edge was added/removed at this node or a neighbour
+    bool dirty_tracked = false;  // flags cover every edit since the last pass
 
     // curvature-pass work lists
     int32_t *work[dcr::NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -141,9 +143,10 @@ int relayout(dcr_graph *g);
 int sync_result(dcr_graph *g);  // D2H of DevResult + stream sync
 void launch_add_edge(dcr_graph *g, int32_t u, int32_t v);          // u < 0: no-op that clears add_status
 void launch_remove_if_above(dcr_graph *g, double bound);           // acts on the last argext result
+void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v);         // flag {u,v} ∪ N(u) ∪ N(v)
 
 // dcr_bfc.hip
-int launch_curvature_pass(dcr_graph *g, int curv_type);
+int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental);
 
 template <typename T>
 int dev_alloc(T **p, int64_t count) {

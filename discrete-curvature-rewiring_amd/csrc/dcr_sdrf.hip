@@ -14,7 +14,7 @@
 
 namespace dcr {
 
-struct View {
+struct RowView {
     const int2 *rowinfo;
     const int32_t *col;
     const int32_t *slot_row;
@@ -83,7 +83,7 @@ __device__ inline Ext ext_block_reduce(Ext e, int want_max, Ext *sh) {
     return sh[0];
 }
 
-__global__ void __launch_bounds__(256) k_argext_edges(View g, int64_t cap_total, const double *curv, int want_max,
+__global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_total, const double *curv, int want_max,
                                                        int excl_u, int excl_v, Ext *partial) {
     __shared__ Ext sh[4];
     Ext best;
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) k_argext_edges(View g, int64_t cap_total,
     if (threadIdx.x == 0) partial[blockIdx.x] = best;
 }
 
-__global__ void __launch_bounds__(256) k_argext_final(View g, const Ext *partial, int nparts, int want_max,
+__global__ void __launch_bounds__(256) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
                                                        DevResult *res) {
     __shared__ Ext sh[4];
     Ext best;
@@ -158,7 +158,7 @@ static int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
         DCR_TRY(dev_alloc(&p, ARGEXT_BLOCKS));
         g->red_scratch = p;
     }
-    View vw{g->rowinfo, g->col, g->slot_row};
+    RowView vw{g->rowinfo, g->col, g->slot_row};
     int64_t blocks = (g->cap_total + 255) / 256;
     if (blocks > ARGEXT_BLOCKS) blocks = ARGEXT_BLOCKS;
     if (blocks < 1) blocks = 1;
@@ -199,7 +199,7 @@ struct ImpBuf {
 };
 
 // K1a: insert row x.  grid-stride, any grid.
-__global__ void k_imp_insert_x(View g, ImpBuf B, int x, int y, unsigned mask) {
+__global__ void k_imp_insert_x(RowView g, ImpBuf B, int x, int y, unsigned mask) {
     const int2 rx = g.rowinfo[x];
     for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < rx.y; a += gridDim.x * blockDim.x) {
         const int k = g.col[rx.x + a];
@@ -230,7 +230,7 @@ __global__ void k_imp_insert_x(View g, ImpBuf B, int x, int y, unsigned mask) {
 }
 
 // K1b: insert row y; a key already present came from row x: a triangle node.
-__global__ void k_imp_insert_y(View g, ImpBuf B, int x, int y, unsigned mask) {
+__global__ void k_imp_insert_y(RowView g, ImpBuf B, int x, int y, unsigned mask) {
     const int2 ry = g.rowinfo[y];
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < ry.y; b += gridDim.x * blockDim.x) {
         const int k = g.col[ry.x + b];
@@ -263,7 +263,7 @@ __global__ void k_imp_insert_y(View g, ImpBuf B, int x, int y, unsigned mask) {
 }
 
 // K2: c1[a] for a in DX by streaming row i_a; every hit also bumps c2 of the DY node it lands on.
-__global__ void __launch_bounds__(256) k_imp_count(View g, ImpBuf B, int x, unsigned mask) {
+__global__ void __launch_bounds__(256) k_imp_count(RowView g, ImpBuf B, int x, unsigned mask) {
     const int2 rx = g.rowinfo[x];
     const int lane = threadIdx.x & 63;
     const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(1024) k_imp_stats(ImpBuf B, int curv_type) {
 }
 
 // K4: class B (i == x, j = y_nb[b] in DY) for waves [0,dy), class C (j == y, i = x_nb[a] in DX) for waves [dy,dy+dx).
-__global__ void __launch_bounds__(256) k_imp_bc(View g, ImpBuf B, int x, int y, unsigned mask, int curv_type) {
+__global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int y, unsigned mask, int curv_type) {
     const ImpStats st = *B.st;
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) k_imp_bc(View g, ImpBuf B, int x, int y, 
 
 // K5: per candidate row a (i = x_nb[a], a == dx: i = x): which j in y_nb + [y] are ruled out
 // (i == j or has_edge(i,j), sdrf_no_cuda.py:35), as a bitmap, plus the count of admitted ones.
-__global__ void __launch_bounds__(256) k_imp_rows(View g, ImpBuf B, int x, int y, unsigned mask, int words) {
+__global__ void __launch_bounds__(256) k_imp_rows(RowView g, ImpBuf B, int x, int y, unsigned mask, int words) {
     extern __shared__ uint32_t bits[];
     __shared__ int cnt_sh;
     const ImpStats st = *B.st;
@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(1024) k_imp_scan(ImpBuf B, int rows, DevResult
 }
 
 // K7: write the admitted candidates of row a, in j order, with their improvements.
-__global__ void __launch_bounds__(256) k_imp_emit(View g, ImpBuf B, int x, int y, int words, int curv_type,
+__global__ void __launch_bounds__(256) k_imp_emit(RowView g, ImpBuf B, int x, int y, int words, int curv_type,
                                                    double *out, int32_t *ci, int32_t *cj) {
     __shared__ int wsum[4];
     __shared__ int carry_sh;
@@ -724,7 +724,7 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     B.rowoff = g->imp_rowoff;
     B.adjbits = g->imp_adjbits;
     B.st = g->imp_stats;
-    View vw{g->rowinfo, g->col, g->slot_row};
+    RowView vw{g->rowinfo, g->col, g->slot_row};
 
     DCR_HIP(hipMemsetAsync(B.keys, 0xff, sizeof(int32_t) * (size_t)ts, g->stream));
     DCR_HIP(hipMemsetAsync(B.posx, 0xff, sizeof(int32_t) * (size_t)ts, g->stream));
@@ -815,6 +815,7 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
     DCR_HIP(hipSetDevice(g->device));
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_add_edge(g, add_k, add_l);
+        launch_mark_dirty(g, add_k, add_l);  // after the append: the new neighbours are flagged too
         if (do_remove) {
             DCR_TRY(launch_argext(g, 1, add_k >= 0 ? add_k : -1, add_k >= 0 ? add_l : -1));
             launch_remove_if_above(g, removal_bound);

@@ -118,8 +118,9 @@ class DcrGraph:
         return out
 
     # ---- curvature -------------------------------------------------------------------
-    def curvature_pass(self, curv_type='bfc'):
-        check(lib().dcr_curvature_pass(self._h, curv_code(curv_type)))
+    def curvature_pass(self, curv_type='bfc', incremental=False):
+        fn = lib().dcr_curvature_pass_incremental if incremental else lib().dcr_curvature_pass
+        check(fn(self._h, curv_code(curv_type)))
 
     def curvature_read(self):
         ne = self.number_of_edges()

@@ -56,8 +56,11 @@ class SdrfRun:
     """One SDRF rewiring run, steppable: ``step()`` is one iteration of the loop body
     sdrf_no_cuda.py:22-66 and returns False when the reference loop would ``break``."""
 
-    def __init__(self, data, curv_type, remove_edges, removal_bound, tau, trace=None, device=0):
+    def __init__(self, data, curv_type, remove_edges, removal_bound, tau, trace=None, device=0, incremental=False):
         curv_code(curv_type)
+        # incremental=False recomputes every edge each iteration like the reference (sdrf_no_cuda.py:24);
+        # True only recomputes edges near the previous iteration's edits: same values, less work
+        self.incremental = incremental
         self.data = data
         self.curv_type = curv_type
         self.remove_edges = remove_edges
@@ -70,7 +73,7 @@ class SdrfRun:
         G, curv_type, tau, trace = self.G, self.curv_type, self.tau, self.trace
         want_trace = trace is not None
         can_add = True
-        G.curvature_pass(curv_type)
+        G.curvature_pass(curv_type, incremental=self.incremental)
 
         # Choose the edge with the lowest curvature (first minimum in G.edges order).
         try:
@@ -125,7 +128,7 @@ class SdrfRun:
         return _make_data(self.data, self.G.to_edge_index())
 
 
-def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0):
+def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0, incremental=False):
     """
     Perform SDRF graph rewiring using the given discrete curvature type.
     :param data: data to be rewired (undirected by default in this work).
@@ -136,7 +139,8 @@ def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace
     :param tau: softmax temperature for choosing the edge to add; if infinite, the max value is chosen.
     :return: rewired data.
     """
-    run = SdrfRun(data, curv_type, remove_edges, removal_bound, tau, trace=trace, device=device)
+    run = SdrfRun(data, curv_type, remove_edges, removal_bound, tau, trace=trace, device=device,
+                  incremental=incremental)
     for _ in range(loops):
         if not run.step():
             break

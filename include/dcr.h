@@ -78,6 +78,11 @@ int dcr_graph_export_edge_index(dcr_graph *g, int64_t *out2xM);
  * Values stay in HBM, keyed by adjacency slot; the stale-read semantics of
  * sdrf_no_cuda.py:57-61 follow from later calls reading that buffer. */
 int dcr_curvature_pass(dcr_graph *g, int curv_type);
+/* Same result, less work: recompute only the edges whose value can have changed since the previous pass of the same
+ * kind, i.e. those with an endpoint in {a,b} ∪ N(a) ∪ N(b) of an edge (a,b) added or removed meanwhile (every edit
+ * through this API is tracked).  Falls back to a full pass when there is no complete buffer to build on.  The
+ * reference recomputes everything each iteration (sdrf_no_cuda.py:24); this is an optional mode. */
+int dcr_curvature_pass_incremental(dcr_graph *g, int curv_type);
 /* Copy the last pass out in G.edges order (float64 per undirected edge). */
 int dcr_curvature_read(dcr_graph *g, double *out_curv, int32_t *out_u, int32_t *out_v);
 /* bfc_edge(G, v1, v2), bfc_naive.py:7-40 / compute_curvature_edge, classical_curvatures.py:6 */

@@ -365,3 +365,70 @@ def test_bfc_cuda_call_surface(oracle):
             else:
                 imp = O.improvements(x, y, np.array([min(i, j)]), np.array([max(i, j)]), 'bfc')[0]
                 assert abs(float(D[I, J]) - (before + imp)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ incremental mode
+def test_incremental_pass_equals_full(dcr, oracle):
+    """After arbitrary edits, an incremental pass leaves exactly the bits a full pass would."""
+    from dcr import synthetic
+    ei, nn = synthetic.powerlaw_graph(800, 5, seed=13)
+    G = dcr(ei, nn)
+    C = oracle.CGraph(ei, nn)
+    G.curvature_pass('bfc')
+    rng = np.random.Generator(np.random.PCG64(17))
+    for step in range(40):
+        u, v = (int(t) for t in rng.integers(0, nn, 2))
+        if u == v:
+            continue
+        if C.has_edge(u, v):
+            G.remove_edge(u, v); C.remove_edge(u, v)
+        else:
+            G.add_edge(u, v); C.add_edge(u, v)
+        if step % 3 == 0:
+            G.curvature_pass('bfc', incremental=True)
+            eu, ev, cv = G.curvature_read()
+            ou, ov, oc = C.curv_all('bfc', nthreads=8)
+            assert np.array_equal(eu, ou) and np.array_equal(ev, ov) and np.array_equal(cv, oc), step
+    # switching curvature kind must not reuse the old buffer
+    G.curvature_pass('augmented', incremental=True)
+    assert np.array_equal(G.curvature_read()[2], C.curv_all('augmented')[2])
+
+
+def test_sdrf_incremental_matches_golden_and_oracle(oracle):
+    from dcr import synthetic
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import sdrf_no_cuda
+    import torch
+    for fname in ('sdrf_traces_small.json', 'sdrf_traces_medium.json'):
+        for case in load_golden(fname)['cases']:
+            if case['error']:
+                continue
+            tau = float('inf') if case['tau'] == 'inf' else case['tau']
+            data = Data(edge_index=torch.tensor(case['edge_index']), num_nodes=case['num_nodes'])
+            np.random.seed(case['seed'])
+            out = sdrf_no_cuda(data, case['curv_type'], case['loops'], case.get('remove_edges', True),
+                               case['removal_bound'], tau, incremental=True)
+            assert out.edge_index.tolist() == case['final_edge_index'], (case['graph'], case['curv_type'])
+    ei, nn = synthetic.powerlaw_graph(1500, 6, seed=5)
+    np.random.seed(4)
+    want = oracle.sdrf(ei, nn, 'bfc', 40, True, 0.6, 120, nthreads=8)
+    np.random.seed(4)
+    got = sdrf_no_cuda(Data(edge_index=torch.from_numpy(ei), num_nodes=nn), 'bfc', 40, True, 0.6, 120, incremental=True)
+    assert np.array_equal(got.edge_index.numpy(), want)
+
+
+def test_s100k_incremental_equals_full():
+    from dcr import synthetic
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import SdrfRun
+    import torch
+    ei, nn = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    outs = []
+    for inc in (False, True):
+        np.random.seed(0)
+        run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=nn), 'bfc', True, 0.95, 163, incremental=inc)
+        for _ in range(25):
+            run.step()
+        run.G.curvature_pass('bfc', incremental=inc)
+        outs.append((run.G.to_edge_index(), run.G.curvature_read()[2]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
