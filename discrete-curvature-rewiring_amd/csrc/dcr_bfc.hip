@@ -18,34 +18,13 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "dcr_internal.h"
+#include "dcr_bfc_common.h"
 
 namespace dcr {
 
 constexpr unsigned TAG_U = 1u << 30;
 constexpr unsigned TAG_V = 1u << 31;
 constexpr unsigned KEY_MASK = (1u << 30) - 1u;
-constexpr unsigned EMPTY = 0xFFFFFFFFu;
-
-enum { MODE_BFC = 0, MODE_TRI = 1, MODE_BYTES = 2 };
-
-struct View {
-    const int2 *rowinfo;
-    const int32_t *col;
-    const int32_t *slot_row;
-    int64_t cap_total;
-    int32_t *guard;  // [8] first violated invariant: code, block, item data (debug / safety net)
-    const uint8_t *dirty;  // incremental pass: only edges with a flagged endpoint are recomputed (nullptr: all)
-};
-
-__device__ inline bool row_ok(const View &g, const int2 rk, int code, int a, int b) {
-    const bool ok = rk.x >= 0 && rk.y >= 0 && (int64_t)rk.x + rk.y <= g.cap_total;
-    if (!ok && atomicCAS(&g.guard[0], 0, code) == 0) {
-        g.guard[1] = rk.x; g.guard[2] = rk.y; g.guard[3] = a; g.guard[4] = b; g.guard[5] = blockIdx.x;
-        g.guard[6] = threadIdx.x;
-    }
-    return ok;
-}
 
 struct WorkLists {
     int32_t *w[NBINS];
@@ -54,27 +33,6 @@ struct WorkLists {
 // keys (= du + dv + 2) admitted per bin: load factor <= 1/4 except the last bin (<= 1/2)
 __host__ __device__ constexpr int bin_max_keys(int b) {
     return b == 0 ? 32 : b == 1 ? 128 : b == 2 ? 512 : b == 3 ? 2048 : 16384;
-}
-
-// bfc_naive.py:31-32 / 39-40, left to right in float64; compiled with -ffp-contract=off
-__device__ __host__ inline double bfc_formula(int d1, int d2, int T, int s1, int s2, int gamma) {
-    int dmax = d1 > d2 ? d1 : d2, dmin = d1 < d2 ? d1 : d2;
-    double r = 2.0 / (double)d1;
-    r = r + 2.0 / (double)d2;
-    r = r - 2.0;
-    r = r + (double)(2 * (int64_t)T) / (double)dmax;
-    r = r + (double)T / (double)dmin;
-    if (s1 == 0 || s2 == 0) return r;
-    double q = 1.0 / (double)gamma;
-    q = q / (double)dmax;
-    q = q * (double)(s1 + s2);
-    return r + q;
-}
-
-template <int SLOTS>
-__device__ inline unsigned hash_slot(unsigned key) {
-    constexpr int BITS = __builtin_ctz(SLOTS);
-    return (key * 0x9E3779B1u) >> (32 - BITS);
 }
 
 template <int SLOTS>
@@ -96,12 +54,6 @@ __device__ inline unsigned table_lookup(const unsigned *tab, unsigned key) {
         if (e == EMPTY || (e & KEY_MASK) == key) return e;
         h = (h + 1) & (SLOTS - 1);
     }
-}
-
-// Rows are read in aligned 16-byte pieces: lane q of a row's lane set fetches col[a0 + 4q .. a0 + 4q + 3], a0 = row
-// start rounded down to a multiple of 4 (the col allocation is padded, so the last piece never leaves it).
-__device__ inline int4 load_piece(const int32_t *col, int a) {
-    return *reinterpret_cast<const int4 *>(col + a);
 }
 
 // Which of the (up to four) entries of a piece lie inside [lo, hi) and hit an entry whose tag pattern is `other`;
@@ -130,14 +82,6 @@ __device__ inline unsigned probe_piece(const unsigned *tab, unsigned *cnt, const
     return (t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u) | (t3 ? 8u : 0u);
 }
 
-// popcount of the four per-element hit ballots, restricted to the lanes selected by `sel`
-__device__ inline int count_hits(unsigned m, unsigned long long sel, int shift) {
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c += __popcll((__ballot((m >> j) & 1u) >> shift) & sel);
-    return c;
-}
-
 template <int TEAM>
 __device__ inline void team_sync() {
     __syncthreads();  // single-wave teams: the compiler lowers this to a wait, no s_barrier
@@ -155,7 +99,6 @@ struct Ingredients {
 // Both are degrees in the same bipartite graph between DX and DY, so only the rows of the cheaper side (smaller sum
 // of degrees) are streamed: a row's hit count is its own degree, and every hit bumps a counter on the table slot of the
 // node it landed on, which after the sweep is that node's degree seen from the other side.
-constexpr int LONG_ROW = 60;  // longer rows are streamed by a whole wave; shorter ones fit four 64-byte group steps
 constexpr int MAXR = 4;       // rows of one endpoint held per lane while both sides are sized (deg <= MAXR * TEAM)
 
 template <int SLOTS, int TEAM, int MODE, int DESC_CAP>
@@ -588,6 +531,7 @@ __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total,
     if (v <= u) return -1;
     if (g.dirty && !(g.dirty[u] | g.dirty[v])) return -1;  // untouched neighbourhood: the stored value is still exact
     const int dv = g.rowinfo[v].y, du = ru.y;
+    if (g.nc_handles && nc_takes(du, dv)) return -1;  // the node-centric kernels own this edge
     if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
         if (finish_trivial) curv[s] = (double)(4 - du - dv);
         return -1;
@@ -655,8 +599,8 @@ __global__ void __launch_bounds__(256) k_classify(View g, int64_t cap_total, int
     }
 }
 
-__global__ void k_clear_counts(DevResult *res) {
-    if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
+__global__ void k_clear_counts(DevResult *res, int keep_guard) {
+    if (threadIdx.x < 8 && !keep_guard) res->misc[threadIdx.x] = 0;
     if (threadIdx.x < NBINS) {
         res->work_count[threadIdx.x] = 0;
         res->work_next[threadIdx.x] = 0;
@@ -699,9 +643,10 @@ static void launch_bin(dcr_graph *g, const View &vw, int curv_type, double *byte
 }
 
 template <int MODE>
-static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incremental = false) {
+static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incremental = false, bool nc_rest = false) {
     DCR_TRY(ensure_work(g));
-    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr,
+            (int32_t)g->n, nc_rest ? 1 : 0, nullptr};
     WorkLists wl;
     for (int b = 0; b < NBINS; ++b) wl.w[b] = g->work[b];
     if (g->num_cu <= 0) {
@@ -711,7 +656,7 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incre
             g->num_cu = prop.multiProcessorCount;
     }
     const int num_cu = g->num_cu;
-    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, g->stream, g->dres);
+    hipLaunchKernelGGL(k_clear_counts, dim3(1), dim3(64), 0, g->stream, g->dres, nc_rest ? 1 : 0);
     int64_t blocks = (g->cap_total + CLASSIFY_CHUNK - 1) / CLASSIFY_CHUNK;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_classify, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->cap_total, curv_type, MODE,
@@ -742,9 +687,19 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incre
 }
 
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental) {
-    if (curv_type == DCR_CURV_BFC || curv_type == DCR_CURV_1D)
-        return run_pass<MODE_BFC>(g, curv_type, nullptr, incremental);
-    return run_pass<MODE_TRI>(g, curv_type, nullptr, incremental);
+    if (curv_type == DCR_CURV_1D || g->pass_impl == 1) {
+        if (curv_type == DCR_CURV_BFC || curv_type == DCR_CURV_1D)
+            return run_pass<MODE_BFC>(g, curv_type, nullptr, incremental);
+        return run_pass<MODE_TRI>(g, curv_type, nullptr, incremental);
+    }
+    // node-centric kernels; the edge-centric ones only for edges beyond their degree limits (two hubs with more
+    // than NC_MAXD neighbours each), which cannot exist while the largest degree is within the limit
+    DCR_TRY(launch_curvature_pass_nc(g, curv_type, incremental));
+    if (g->max_deg_bound > NC_MAXD) {
+        if (curv_type == DCR_CURV_BFC) return run_pass<MODE_BFC>(g, curv_type, nullptr, incremental, true);
+        return run_pass<MODE_TRI>(g, curv_type, nullptr, incremental, true);
+    }
+    return DCR_OK;
 }
 
 template <int B>
@@ -808,7 +763,7 @@ int dcr_bfc_ingredients(dcr_graph *g, int32_t u, int32_t v, int64_t out6[6]) {
     const int keys = du + dv + 2;
     int64_t *d_out = nullptr;
     DCR_TRY(dev_alloc(&d_out, 6));
-    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, nullptr};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, nullptr, (int32_t)g->n, 0, nullptr};
     if (keys <= bin_max_keys(0)) launch_single<0>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(1)) launch_single<1>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(2)) launch_single<2>(g, vw, u, v, d_out);

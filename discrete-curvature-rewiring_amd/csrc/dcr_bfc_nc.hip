@@ -1,0 +1,614 @@
+// Node-centric curvature pass of libdcr_hip.so (the default implementation of dcr_curvature_pass).
+//
+// Replaces compute_curvature_graph(G, curv_type) at rewiring/sdrf_no_cuda.py:24, i.e. E calls of
+// bfc_naive.bfc_edge (curvature/bfc_naive.py:7-40) or compute_curvature_edge (classical_curvatures.py:14-28).
+//
+// Every undirected edge {u,v} is owned by its higher-degree endpoint u (ties: smaller id).  The neighbour set N(u) is
+// staged ONCE as a hash set in LDS and reused for all edges u owns; per edge one wave then only has to
+//   1. look the members of N(v) up in that set: hits are the triangles T (bfc_naive.py:25) and get a per-edge flag,
+//      misses are DY = N(v) \ N(u) \ {u};
+//   2. stream the rows of the members of DY from HBM (aligned 16-byte pieces; short rows by 4-lane groups, long rows
+//      by the whole wave) and probe every entry against the set: an unflagged hit z is a 4-cycle u-z-w-v.  The hits
+//      of one row are |N(w) ∩ DX| (ballot + popcount), and every hit bumps a 15-bit counter on z's table slot, which
+//      after the sweep is |N(z) ∩ DY|.  sq1, sq2 and gamma (bfc_naive.py:26-29,36-37) are degree statistics of that
+//      one bipartite graph between DX = N(u) \ N(v) \ {v} and DY, so nothing else has to be read;
+//   3. keep the integers (T, |sq1|, |sq2|, gamma) in the lane that stands for the edge; after up to 64 edges all
+//      lanes evaluate the float64 closing expression together (bfc_naive.py:31-40, reference operation order).
+// Compared with the edge-centric kernels in dcr_bfc.hip there is no per-edge table build, no sizing of both sides,
+// no descriptor list of the unstreamed side, no final table scan and, for hubs, no workgroup barrier per edge.
+//
+// Nodes are grouped by degree: up to 254 neighbours a wave owns a node and its private table ("wave classes");
+// above, a workgroup builds one table and each wave takes a 64-neighbour chunk of the row ("block classes").
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "dcr_bfc_common.h"
+
+namespace dcr {
+
+__host__ __device__ constexpr int nc_slots(int c) { return c == 0 ? 128 : c == 1 ? 512 : c == 2 ? 2048 : 8192; }
+__host__ __device__ constexpr int nc_maxdeg(int c) { return c == 0 ? 62 : c == 1 ? 254 : c == 2 ? 1022 : NC_MAXD; }
+__host__ __device__ constexpr int nc_waves(int c) { return c == 2 ? 8 : 4; }  // waves per workgroup
+
+__device__ inline int nc_class_of(int d) {
+    return d <= nc_maxdeg(0) ? 0 : d <= nc_maxdeg(1) ? 1 : d <= nc_maxdeg(2) ? 2 : d <= nc_maxdeg(3) ? 3 : -1;
+}
+
+// compiler-level ordering of one wave's LDS traffic (the hardware executes a wave's DS instructions in order)
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the higher-degree endpoint owns an edge (its table is the big one, the rows streamed are those of the
+// lower-degree endpoint's neighbours); degree-1 edges are finished by the smaller id without any lookup
+__device__ inline bool nc_owns(int a, int da, int b, int db, bool trivial_rule) {
+    if (!nc_takes(da, db)) return false;  // left to the edge-centric kernels
+    if (trivial_rule && (da < db ? da : db) == 1) return a < b;
+    if (da > NC_MAXD) return false;
+    if (db > NC_MAXD) return true;
+    return da > db || (da == db && a < b);
+}
+
+template <int SLOTS>
+__device__ inline void nc_insert(unsigned *tab, unsigned key) {
+    unsigned h = hash_slot<SLOTS>(key);
+    while (true) {
+        const unsigned old = atomicCAS(&tab[h], EMPTY, key);
+        if (old == EMPTY || old == key) return;
+        h = (h + 1) & (SLOTS - 1);
+    }
+}
+
+// slot of key, or -1 (the table is at most half full, so the walk always meets an empty slot)
+template <int SLOTS>
+__device__ inline int nc_find(const unsigned *tab, unsigned key) {
+    unsigned h = hash_slot<SLOTS>(key);
+    while (true) {
+        const unsigned e = tab[h];
+        if (e == key) return (int)h;
+        if (e == EMPTY) return -1;
+        h = (h + 1) & (SLOTS - 1);
+    }
+}
+
+// per-edge slot state, two 16-bit halves per word: bit 15 = "member of N(v) or v itself", bits 0-14 = hits
+__device__ inline void cnt_flag(unsigned *cnt, int h) { atomicOr(&cnt[h >> 1], 0x8000u << ((h & 1) * 16)); }
+__device__ inline unsigned cnt_add(unsigned *cnt, int h) {
+    const unsigned sh = (unsigned)(h & 1) * 16u;
+    return (atomicAdd(&cnt[h >> 1], 1u << sh) >> sh) & 0xFFFFu;
+}
+
+// One aligned piece of a streamed row: which of its (up to four) entries inside [lo, hi) are unflagged members of the
+// table, as a 4-bit mask; s1 / gam pick up what the slot counters say about the node that was hit.
+template <int SLOTS>
+__device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, const int4 w, int a, int lo, int hi,
+                                          int &s1, int &gam) {
+    const unsigned k0 = (unsigned)w.x, k1 = (unsigned)w.y, k2 = (unsigned)w.z, k3 = (unsigned)w.w;
+    const bool v0 = a >= lo && a < hi, v1 = a + 1 >= lo && a + 1 < hi, v2 = a + 2 >= lo && a + 2 < hi,
+               v3 = a + 3 >= lo && a + 3 < hi;
+    unsigned h0 = hash_slot<SLOTS>(k0), h1 = hash_slot<SLOTS>(k1), h2 = hash_slot<SLOTS>(k2), h3 = hash_slot<SLOTS>(k3);
+    unsigned e0 = v0 ? tab[h0] : EMPTY, e1 = v1 ? tab[h1] : EMPTY, e2 = v2 ? tab[h2] : EMPTY, e3 = v3 ? tab[h3] : EMPTY;
+    while (e0 != EMPTY && e0 != k0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; }
+    while (e1 != EMPTY && e1 != k1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; }
+    while (e2 != EMPTY && e2 != k2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; }
+    while (e3 != EMPTY && e3 != k3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; }
+    unsigned m = 0;
+#define DCR_NC_HIT(E, H, BIT)                          \
+    if ((E) != EMPTY) {                                \
+        const unsigned old = cnt_add(cnt, (int)(H));   \
+        if (!(old & 0x8000u)) {                        \
+            m |= (BIT);                                \
+            s1 += (old == 0u);                         \
+            gam = (int)old + 1 > gam ? (int)old + 1 : gam; \
+        }                                              \
+    }
+    DCR_NC_HIT(e0, h0, 1u)
+    DCR_NC_HIT(e1, h1, 2u)
+    DCR_NC_HIT(e2, h2, 4u)
+    DCR_NC_HIT(e3, h3, 8u)
+#undef DCR_NC_HIT
+    return m;
+}
+
+struct NcEdge {
+    int T, s1, s2, gam, posu;
+};
+
+// per-wave scratch in LDS
+struct NcScratch {
+    int2 desc[64];   // {start, length} of the DY rows of the current batch
+    int poff[66];    // exclusive prefix of their piece counts; poff[64] = total
+    int rowcnt[64];  // hits per row
+    int acc[2];      // wave totals: |sq| on the table side, gamma
+};
+
+// One edge {u,v} owned by u, by one wave.  `tab` holds N(u); cnt and sc are this wave's scratch.
+template <int SLOTS, int MODE>
+__device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const unsigned *tab, unsigned *cnt,
+                                 NcScratch *sc) {
+    const int lane = threadIdx.x & 63;
+    const int32_t *rowv = g.col + rv.x;
+    NcEdge out;
+    out.T = out.s1 = out.s2 = out.gam = 0;
+    out.posu = -1;
+    if (MODE == MODE_BFC) {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = lane; i < SLOTS / 8; i += 64) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane == 0) {
+            sc->acc[0] = 0;
+            sc->acc[1] = 0;
+        }
+        wave_sync();
+        const int hv = nc_find<SLOTS>(tab, (unsigned)v);  // v is a neighbour of u: never counted as a hit
+        if (lane == 0 && hv >= 0) cnt_flag(cnt, hv);
+    }
+    // sweep 1 over N(v): triangles (flagged), where u sits in row v
+    int T = 0, posu = -1;
+    for (int base = 0; base < rv.y; base += 64) {
+        const int i = base + lane;
+        const int k = i < rv.y ? rowv[i] : -1;
+        const bool isu = k == u;
+        const unsigned long long mu = __ballot(isu);
+        if (mu) posu = base + __ffsll((long long)mu) - 1;
+        const int h = (k >= 0 && !isu) ? nc_find<SLOTS>(tab, (unsigned)k) : -1;
+        if (MODE == MODE_BFC && h >= 0) cnt_flag(cnt, h);
+        T += __popcll(__ballot(h >= 0));
+    }
+    out.T = T;
+    out.posu = posu;
+    if (MODE != MODE_BFC) return out;
+    wave_sync();
+    // sweep 2 over N(v): the rows of DY, 64 members at a time.  Their aligned 16-byte pieces form one flat list that
+    // the lanes share evenly, whatever the row lengths: lane t takes pieces t, t + 64, ... and keeps four loads in
+    // flight; the row of a piece is found by bisection of the prefix sums of the rows' piece counts.
+    int s1 = 0, gam = 0, s2 = 0;
+    for (int base = 0; base < rv.y; base += 64) {
+        const int i = base + lane;
+        const int k = i < rv.y ? rowv[i] : -1;
+        const bool member = k >= 0 && k < g.n && k != u && nc_find<SLOTS>(tab, (unsigned)k) < 0;
+        int2 rk = make_int2(0, 0);
+        if (member) {
+            rk = g.rowinfo[k];
+            if (!row_ok(g, rk, 11, k, v)) rk = make_int2(0, 0);
+        }
+        const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
+        int incl = np;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int P = __shfl(incl, 63);
+        sc->desc[lane] = rk;
+        sc->poff[lane] = incl - np;
+        sc->rowcnt[lane] = 0;
+        if (lane == 0) sc->poff[64] = P;
+        wave_sync();
+        for (int j0 = 0; j0 < P; j0 += 256) {
+            int4 w[4];
+            int rr[4], aa[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + 64 * q + lane;
+                rr[q] = -1;
+                aa[q] = 0;
+                w[q] = make_int4(0, 0, 0, 0);
+                if (j < P) {
+                    int r = 0;
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (sc->poff[r + step] <= j) r += step;
+                    const int2 d = sc->desc[r];
+                    const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
+                    w[q] = load_piece(g.col, a);
+                    rr[q] = r;
+                    aa[q] = a;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (rr[q] >= 0) {
+                    const int2 d = sc->desc[rr[q]];
+                    const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], aa[q], d.x, d.x + d.y, s1, gam);
+                    if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
+                }
+            }
+        }
+        wave_sync();
+        const int c = sc->rowcnt[lane];
+        s2 += __popcll(__ballot(c > 0));
+        gam = c > gam ? c : gam;
+        wave_sync();  // the scratch is rewritten by the next batch
+    }
+    // lane partials -> wave totals through two LDS words (hits are rare: few lanes have anything to add)
+    if (s1 > 0) atomicAdd(&sc->acc[0], s1);
+    if (gam > 0) atomicMax(&sc->acc[1], gam);
+    wave_sync();
+    out.s1 = sc->acc[0];
+    out.gam = sc->acc[1];
+    out.s2 = s2;
+    wave_sync();
+    return out;
+}
+
+// One sub-unit of row u: NC_LANES positions, strided by the number of sub-units of the row (p = sub + l * nsub), so
+// that the expensive edges of a hub (those to other hubs sit next to each other at the front of its row) spread over
+// all of its sub-units.  Lane l stands for the edge to the neighbour at its position.
+constexpr int NC_LANES = 16;
+
+template <int SLOTS, int MODE>
+__device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub, const unsigned *tab, unsigned *cnt,
+                                NcScratch *sc, int curv_type, double *curv) {
+    const int lane = threadIdx.x & 63;
+    const int p = sub + lane * nsub;
+    int v = -1;
+    int2 rv = make_int2(0, 0);
+    bool own = false;
+    if (lane < NC_LANES && p < ru.y) {
+        v = g.col[ru.x + p];
+        if (v >= 0 && v < g.n && v != u) {
+            rv = g.rowinfo[v];
+            if (!row_ok(g, rv, 12, v, u)) rv = make_int2(0, 0);
+            own = rv.y > 0 && nc_owns(u, ru.y, v, rv.y, curv_type == DCR_CURV_BFC);
+            if (own && g.dirty) own = (g.dirty[u] | g.dirty[v]) != 0;
+        }
+    }
+    if (own && curv_type == DCR_CURV_BFC && (ru.y < rv.y ? ru.y : rv.y) == 1) {  // bfc_naive.py:18-19
+        curv[ru.x + p] = 0.0;  // the owner of a degree-1 edge is the smaller id: the slot is in its own row
+        own = false;
+    }
+    int my_T = 0, my_s1 = 0, my_s2 = 0, my_gam = 0, my_posu = -1;
+    unsigned long long todo = __ballot(own);
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ve = __shfl(v, l);
+        const int2 rve = make_int2(__shfl(rv.x, l), __shfl(rv.y, l));
+        const NcEdge r = nc_edge<SLOTS, MODE>(g, u, ve, rve, tab, cnt, sc);
+        if (lane == l) {
+            my_T = r.T; my_s1 = r.s1; my_s2 = r.s2; my_gam = r.gam; my_posu = r.posu;
+        }
+    }
+    if (own) {
+        int64_t slot = -1;
+        if (u < v) slot = (int64_t)ru.x + p;
+        else if (my_posu >= 0) slot = (int64_t)rv.x + my_posu;
+        if (slot < 0 || slot >= g.cap_total) {
+            row_ok(g, make_int2(-1, my_posu), 13, u, v);  // adjacency not symmetric: report, never write
+        } else if (MODE == MODE_BFC) {
+            curv[slot] = bfc_formula(ru.y, rv.y, my_T, my_s1, my_s2, my_gam);
+        } else {
+            curv[slot] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - ru.y - rv.y + 3 * my_T) : (double)my_T;
+        }
+    }
+}
+
+// ---- wave classes: a wave owns a node; persistent waves pull CHUNK nodes at a time ----------------------------
+template <int SLOTS, int MODE, int CHUNK>
+__global__ void __launch_bounds__(256) k_nc_wave(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+                                                  int32_t *next, int curv_type, double *curv) {
+    constexpr int WPB = 4;
+    __shared__ __attribute__((aligned(16))) unsigned tab_all[WPB][SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned cnt_all[WPB][SLOTS / 2];
+    __shared__ NcScratch sc_all[WPB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned *tab = tab_all[wid], *cnt = cnt_all[wid];
+    NcScratch *sc = &sc_all[wid];
+    const int total = *count;
+    if (total < 0 || total > unit_cap) {  // cannot happen; never walk a list with a corrupt length
+        row_ok(g, make_int2(-1, total), 14, 0, 0);
+        return;
+    }
+    const int max_rounds = total / CHUNK + 2;
+    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == 128 ? 0 : 16384) + (int)(blockIdx.x * WPB + wid) % 16384) : nullptr;
+    if (tr && lane == 0) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
+    for (int round = 0; round < max_rounds; ++round) {
+        int first = 0;
+        if (lane == 0) first = atomicAdd(next, CHUNK);
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (first >= total || first < 0) break;
+        const int last = first + CHUNK < total ? first + CHUNK : total;
+        for (int it = first; it < last; ++it) {
+            const int2 un = units[it];
+            const int u = un.x, sub = un.y;
+            if (u < 0 || u >= g.n || sub < 0) {
+                row_ok(g, make_int2(-1, u), 15, it, total);
+                continue;
+            }
+            int2 ru = g.rowinfo[u];
+            if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;
+            const int nsub = (ru.y + NC_LANES - 1) / NC_LANES;
+            if (sub >= nsub) continue;
+            for (int i = lane; i < SLOTS; i += 64) tab[i] = EMPTY;
+            wave_sync();
+            for (int i = lane; i < ru.y; i += 64) {
+                const int k = g.col[ru.x + i];
+                if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k);
+            }
+            wave_sync();
+            nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt, sc, curv_type, curv);
+        }
+        if (tr && lane == 0) tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ---- block classes: one table per workgroup, wave w takes sub-unit sub0 + w of the row --------------------------
+template <int SLOTS, int W, int MODE>
+__global__ void __launch_bounds__(64 * W) k_nc_block(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+                                                      int32_t *next, int curv_type, double *curv) {
+    __shared__ __attribute__((aligned(16))) unsigned tab[SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned cnt_all[W][SLOTS / 2];
+    __shared__ NcScratch sc_all[W];
+    const int wid = threadIdx.x >> 6;
+    const int total = *count;
+    if (total < 0 || total > unit_cap) {
+        row_ok(g, make_int2(-1, total), 17, 0, 0);
+        return;
+    }
+    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == 2048 ? 32768 : 49152) + (int)(blockIdx.x * W + wid) % 16384) : nullptr;
+    if (tr && (threadIdx.x & 63) == 0) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
+    // dynamic dequeue: thread 0 pulls the next unit and publishes it through LDS between two barriers, so every value
+    // that steers control flow around the barriers is uniform in the workgroup
+    __shared__ int it_sh;
+    for (int round = 0; round <= total; ++round) {
+        if (threadIdx.x == 0) it_sh = atomicAdd(next, 1);
+        __syncthreads();
+        const int it = it_sh;
+        if (it >= total || it < 0) break;
+        const int2 un = units[it];
+        const int u = un.x, sub0 = un.y;
+        bool ok = u >= 0 && u < g.n && sub0 >= 0;
+        int2 ru = make_int2(0, 0);
+        if (ok) {
+            ru = g.rowinfo[u];
+            ok = row_ok(g, ru, 18, u, it) && ru.y <= SLOTS / 2 - 2;
+        }
+        if (!ok) {  // uniform
+            __syncthreads();
+            continue;
+        }
+        for (int i = threadIdx.x; i < SLOTS; i += 64 * W) tab[i] = EMPTY;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ru.y; i += 64 * W) {
+            const int k = g.col[ru.x + i];
+            if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k);
+        }
+        __syncthreads();
+        const int nsub = (ru.y + NC_LANES - 1) / NC_LANES;
+        const int sub = sub0 + wid;
+        if (sub < nsub)
+            nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_all[wid], &sc_all[wid], curv_type, curv);
+        if (tr && (threadIdx.x & 63) == 0) tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        __syncthreads();  // the table and the unit index are rewritten by the next round
+    }
+}
+
+// ---- plan: one thread per node appends its units to the list of its degree class -----------------------------
+struct NcLists {
+    int2 *units[NC_CLASSES];
+    int64_t cap[NC_CLASSES];
+};
+
+// Units are laid out heaviest first inside each class (by degree bucket of the owning node), so that with dynamic
+// dequeue the long-running units start at once and the cheap ones fill the tail.
+constexpr int NC_BUCKETS = 15;
+__device__ inline int nc_bucket_lo(int b) {
+    constexpr int lo[NC_BUCKETS] = {1, 13, 17, 25, 33, 49, 63, 97, 129, 193, 255, 511, 767, 1023, 2047};
+    return lo[b];
+}
+__device__ inline int nc_bucket_of(int d) {
+    int b = 0;
+#pragma unroll
+    for (int i = 1; i < NC_BUCKETS; ++i) b += (d >= nc_bucket_lo(i));
+    return b;
+}
+__device__ inline int nc_bucket_class(int b) { return b < 6 ? 0 : b < 10 ? 1 : b < 13 ? 2 : 3; }
+
+// PHASE 0 counts the units per bucket; PHASE 1 places them (class list = its buckets, heaviest first)
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_nc_plan(View g, NcLists L, const uint8_t *touch, DevResult *res) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int bkt = -1, d = 0;
+    if (u < g.n) {
+        d = g.rowinfo[u].y;
+        if (d > 0 && d <= NC_MAXD && (!g.dirty || g.dirty[u] || touch[u])) bkt = nc_bucket_of(d);
+    }
+    const int cls = bkt < 0 ? -1 : nc_bucket_class(bkt);
+    const int nsub = (d + NC_LANES - 1) / NC_LANES;
+    // wave classes: one unit per sub-unit; block classes: one unit per group of W sub-units
+    const int W = cls >= 2 ? nc_waves(cls) : 1;
+    const int nunits = cls < 0 ? 0 : (nsub + W - 1) / W;
+    if (PHASE == 1 && blockIdx.x == 0 && threadIdx.x < NC_CLASSES) {
+        int tot = 0;
+        for (int b = 0; b < NC_BUCKETS; ++b)
+            if (nc_bucket_class(b) == (int)threadIdx.x) tot += res->nc_bucket[b];
+        res->nc_count[threadIdx.x] = tot;
+    }
+    for (int b = 0; b < NC_BUCKETS; ++b) {
+        const unsigned long long m = __ballot(bkt == b);
+        if (m == 0) continue;
+        // wave-aggregated reservation: exclusive prefix of nunits over the lanes of this bucket
+        int incl = bkt == b ? nunits : 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int tot = __shfl(incl, 63);
+        if (PHASE == 0) {
+            if (lane == 0) atomicAdd(&res->nc_bucket[b], tot);
+            continue;
+        }
+        int base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&res->nc_fill[b], tot);
+            for (int h = b + 1; h < NC_BUCKETS; ++h)  // heavier buckets of the same class come first
+                if (nc_bucket_class(h) == nc_bucket_class(b)) base += res->nc_bucket[h];
+        }
+        base = __shfl(base, 0);
+        if (bkt == b) {
+            const int first = base + incl - nunits;
+            if (first < 0 || (int64_t)first + nunits > L.cap[cls]) {
+                row_ok(g, make_int2(-1, first), 19, u, nunits);
+            } else {
+                for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int2(u, j * W);
+            }
+        }
+    }
+}
+
+// incremental pass: nodes with a flagged neighbour own edges that must be recomputed too
+__global__ void __launch_bounds__(256) k_nc_touch(View g, uint8_t *touch) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= g.cap_total) return;
+    const int u = g.slot_row[s];
+    const int2 ru = g.rowinfo[u];
+    if ((int)(s - ru.x) >= ru.y) return;
+    const int v = g.col[s];
+    if (v >= 0 && v < g.n && g.dirty[v]) touch[u] = 1;
+}
+
+__global__ void k_nc_clear(DevResult *res) {
+    if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
+    if (threadIdx.x < 16) {
+        res->nc_bucket[threadIdx.x] = 0;
+        res->nc_fill[threadIdx.x] = 0;
+    }
+    if (threadIdx.x < NC_CLASSES) res->nc_next[threadIdx.x] = 0;
+    if (threadIdx.x == 0) res->flag_too_big = 0;
+    if (threadIdx.x < NC_CLASSES) res->nc_count[threadIdx.x] = 0;
+}
+
+static int ensure_nc(dcr_graph *g) {
+    // units per class, from the smallest degree a member node can have and its sub-units (16 positions each)
+    const int64_t need[NC_CLASSES] = {g->n * 4 + 64, g->cap_total / 3 + 64, g->cap_total / 24 + 64,
+                                      g->cap_total / 12 + 64};
+    for (int c = 0; c < NC_CLASSES; ++c) {
+        if (g->nc_cap[c] < need[c]) {
+            if (g->nc_units[c]) (void)hipFree(g->nc_units[c]);
+            g->nc_units[c] = nullptr;
+            DCR_TRY(dev_alloc(&g->nc_units[c], need[c]));
+            g->nc_cap[c] = need[c];
+        }
+    }
+    if (g->nc_touch_cap < g->n + 64) {
+        if (g->nc_touch) (void)hipFree(g->nc_touch);
+        g->nc_touch = nullptr;
+        DCR_TRY(dev_alloc(&g->nc_touch, g->n + 64));
+        g->nc_touch_cap = g->n + 64;
+    }
+    return DCR_OK;
+}
+
+template <int C, int MODE>
+static void launch_nc_wave(dcr_graph *g, const View &vw, int curv_type, hipStream_t st) {
+    constexpr int SLOTS = nc_slots(C);
+    constexpr int CHUNK = C == 0 ? 2 : 1;
+    constexpr int LDS = 4 * (SLOTS * 4 + SLOTS * 2 + (int)sizeof(NcScratch));
+    int per_cu = (160 * 1024) / LDS;
+    if (per_cu > 8) per_cu = 8;  // 32 wave slots per CU, 4 waves per workgroup
+    if (per_cu < 1) per_cu = 1;
+    hipLaunchKernelGGL((k_nc_wave<SLOTS, MODE, CHUNK>), dim3(g->num_cu * per_cu), dim3(256), 0, st, vw, g->nc_units[C],
+                       &g->dres->nc_count[C], g->nc_cap[C], &g->dres->nc_next[C], curv_type, g->curv);
+}
+
+template <int C, int MODE>
+static void launch_nc_block(dcr_graph *g, const View &vw, int curv_type, hipStream_t st) {
+    constexpr int SLOTS = nc_slots(C);
+    constexpr int W = nc_waves(C);
+    constexpr int LDS = SLOTS * 4 + W * (SLOTS * 2 + (int)sizeof(NcScratch));
+    int per_cu = (160 * 1024) / LDS;
+    if (per_cu > 32 / W) per_cu = 32 / W;
+    if (per_cu < 1) per_cu = 1;
+    hipLaunchKernelGGL((k_nc_block<SLOTS, W, MODE>), dim3(g->num_cu * per_cu), dim3(64 * W), 0, st, vw, g->nc_units[C],
+                       &g->dres->nc_count[C], g->nc_cap[C], &g->dres->nc_next[C], curv_type, g->curv);
+}
+
+template <int MODE>
+static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
+    DCR_TRY(ensure_nc(g));
+    if (g->num_cu <= 0) {
+        g->num_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0)
+            g->num_cu = prop.multiProcessorCount;
+    }
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr,
+            (int32_t)g->n, 1, nullptr};
+    static const bool want_trace = getenv("DCR_NC_TRACE") != nullptr;
+    if (want_trace) {
+        if (!g->nc_trace) DCR_TRY(dev_alloc(&g->nc_trace, 4 * 16384 * 2));
+        DCR_HIP(hipMemsetAsync(g->nc_trace, 0, sizeof(long long) * 4 * 16384 * 2, g->stream));
+        vw.trace = g->nc_trace;
+    }
+    NcLists L;
+    for (int c = 0; c < NC_CLASSES; ++c) {
+        L.units[c] = g->nc_units[c];
+        L.cap[c] = g->nc_cap[c];
+    }
+    hipLaunchKernelGGL(k_nc_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
+    if (incremental) {
+        DCR_HIP(hipMemsetAsync(g->nc_touch, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+        const int64_t blocks = (g->cap_total + 255) / 256;
+        if (blocks > 0) hipLaunchKernelGGL(k_nc_touch, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->nc_touch);
+    }
+    const int64_t pblocks = (g->n + 255) / 256;
+    if (pblocks > 0) {
+        hipLaunchKernelGGL(k_nc_plan<0>, dim3((unsigned)pblocks), dim3(256), 0, g->stream, vw, L, g->nc_touch, g->dres);
+        hipLaunchKernelGGL(k_nc_plan<1>, dim3((unsigned)pblocks), dim3(256), 0, g->stream, vw, L, g->nc_touch, g->dres);
+    }
+    // the four classes are independent: fork them onto side streams; the rarest, longest-running units first
+    static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;  // debugging aid: one stream
+    hipStream_t s1 = g->stream, s2 = g->stream, s3 = g->stream;
+    if (!serial) {
+        DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
+        for (int b = 0; b < 3; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
+        s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2];
+    }
+    launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
+    launch_nc_block<2, MODE>(g, vw, curv_type, s1);
+    launch_nc_wave<1, MODE>(g, vw, curv_type, s2);
+    launch_nc_wave<0, MODE>(g, vw, curv_type, s3);
+    if (!serial) {
+        for (int b = 0; b < 3; ++b) {
+            DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
+            DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[b], 0));
+        }
+    }
+    DCR_HIP(hipGetLastError());
+    if (want_trace) {  // per class: when did the waves start / make their last progress (100 MHz ticks -> microseconds)
+        std::vector<long long> h(4 * 16384 * 2);
+        DCR_HIP(hipStreamSynchronize(g->stream));
+        DCR_HIP(hipMemcpy(h.data(), g->nc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long long t0 = 0;
+        for (size_t i = 0; i < h.size(); i += 2)
+            if (h[i] && (!t0 || h[i] < t0)) t0 = h[i];
+        for (int c = 0; c < 4; ++c) {
+            std::vector<double> st, en;
+            for (int w = 0; w < 16384; ++w) {
+                const long long a = h[2 * (c * 16384 + w)], b = h[2 * (c * 16384 + w) + 1];
+                if (!a) continue;
+                st.push_back((a - t0) * 0.01);
+                en.push_back(((b ? b : a) - t0) * 0.01);
+            }
+            if (st.empty()) continue;
+            std::sort(st.begin(), st.end());
+            std::sort(en.begin(), en.end());
+            auto q = [](const std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+            fprintf(stderr, "[nc trace] class %d: %zu waves; start p0 %.0f p50 %.0f p100 %.0f us; last progress p10 %.0f p50 %.0f p90 %.0f p99 %.0f p100 %.0f us\n",
+                    c, st.size(), st.front(), q(st, 0.5), st.back(), q(en, 0.1), q(en, 0.5), q(en, 0.9), q(en, 0.99), en.back());
+        }
+    }
+    return DCR_OK;
+}
+
+int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental) {
+    if (curv_type == DCR_CURV_BFC) return run_nc<MODE_BFC>(g, curv_type, incremental);
+    return run_nc<MODE_TRI>(g, curv_type, incremental);
+}
+
+}  // namespace dcr

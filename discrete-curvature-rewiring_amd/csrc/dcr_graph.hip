@@ -6,6 +6,7 @@
 //     (shift-left), so "position in row" reproduces dict order;
 //   * G.edges order == increasing slot index over slots whose neighbour id exceeds the row id.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_set>
 
@@ -222,8 +223,10 @@ int relayout(dcr_graph *g) {
     DCR_HIP(hipStreamSynchronize(g->stream));
     std::vector<int32_t> start((size_t)g->n), cap((size_t)g->n);
     int64_t tot = 0;
+    int32_t maxd = 0;
     for (int64_t u = 0; u < g->n; ++u) {
         int32_t d = info[(size_t)u].y;
+        if (d > maxd) maxd = d;
         cap[(size_t)u] = d + slack_for(d) * 2;
         start[(size_t)u] = (int32_t)tot;
         tot += cap[(size_t)u];
@@ -258,6 +261,7 @@ int relayout(dcr_graph *g) {
         g->work[b] = nullptr;
     }
     g->work_cap = 0;
+    g->max_deg_bound = maxd;
     return DCR_OK;
 }
 
@@ -340,6 +344,9 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     g->device = device;
     g->n = n;
     g->n_edges = (int64_t)keep.size();
+    for (int64_t u = 0; u < n; ++u)
+        if (deg[(size_t)u] > g->max_deg_bound) g->max_deg_bound = deg[(size_t)u];
+    if (const char *impl = getenv("DCR_PASS")) g->pass_impl = (std::string(impl) == "edge") ? 1 : 0;
     *out = g;  // caller destroys on failure
     DCR_HIP(hipStreamCreate(&g->stream));
     DCR_HIP(hipEventCreate(&g->ev0));
@@ -380,7 +387,8 @@ int dcr_graph_destroy(dcr_graph *g) {
     void *dev_ptrs[] = {g->rowinfo, g->rowcap, g->col, g->slot_row, g->curv, g->red_scratch, g->scan_a, g->scan_b,
                         g->imp_table, g->imp_posx, g->imp_posy, g->imp_c1, g->imp_c2, g->imp_b, g->imp_c,
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
-                        g->imp_stats, g->dres, g->dirty};
+                        g->imp_stats, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
+                        g->nc_units[3], g->nc_touch, g->nc_trace};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)
@@ -429,6 +437,7 @@ int dcr_graph_add_edge(dcr_graph *g, int32_t u, int32_t v) {
         DCR_TRY(sync_result(g));
         if (g->hres->add_status == 0) {
             g->n_edges++;
+            g->max_deg_bound++;
             launch_mark_dirty(g, u, v);
             return DCR_OK;
         }

@@ -52,6 +52,10 @@ struct DevResult {
     int32_t max_keys;     // largest du+dv+2 seen by classify
     int32_t work_count[NBINS];
     int32_t work_next[NBINS];  // dequeue cursors of the persistent bin kernels
+    int32_t nc_count[4];       // node-centric pass: units per degree class
+    int32_t nc_next[4];        // dequeue cursors of its kernels
+    int32_t nc_bucket[16];     // units per degree bucket (plan phase 0)
+    int32_t nc_fill[16];       // placement cursors per bucket (plan phase 1)
     int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS
     int64_t n_cand;
     int64_t imp_argmax;
@@ -91,7 +95,16 @@ struct dcr_graph {
     uint8_t *dirty = nullptr;    // [n] node flags: an incident edge was added/removed at this node or a neighbour
     bool dirty_tracked = false;  // flags cover every edit since the last pass
 
-    // curvature-pass work lists
+    // node-centric pass (dcr_bfc_nc.hip): unit lists per degree class
+    int2 *nc_units[4] = {nullptr, nullptr, nullptr, nullptr};  // {node, first sub-unit}
+    int64_t nc_cap[4] = {0, 0, 0, 0};
+    long long *nc_trace = nullptr;  // DCR_NC_TRACE diagnostic: [4 classes][16384 waves][2]
+    uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
+    int64_t nc_touch_cap = 0;
+    int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
+    int pass_impl = 0;            // 0: node-centric (default), 1: edge-centric kernels only (DCR_PASS=edge)
+
+    // curvature-pass work lists (edge-centric kernels)
     int32_t *work[dcr::NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t work_cap = 0;
 
@@ -147,6 +160,8 @@ void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v);         // flag {u,v
 
 // dcr_bfc.hip
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental);
+// dcr_bfc_nc.hip
+int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental);
 
 template <typename T>
 int dev_alloc(T **p, int64_t count) {

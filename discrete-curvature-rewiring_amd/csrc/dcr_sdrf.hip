@@ -826,7 +826,10 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
         if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
         DCR_TRY(relayout(g));
     }
-    if (add_k >= 0 && g->hres->add_status == 0) g->n_edges++;
+    if (add_k >= 0 && g->hres->add_status == 0) {
+        g->n_edges++;
+        g->max_deg_bound++;
+    }
     int32_t ru = -1, rv = -1;
     if (do_remove) {
         ru = g->hres->removed_u;
