@@ -28,7 +28,7 @@
 
 namespace dcr {
 
-__host__ __device__ constexpr int nc_slots(int c) { return c == 0 ? 128 : c == 1 ? 512 : c == 2 ? 2048 : 8192; }
+__host__ __device__ constexpr int nc_slots(int c) { return c == 0 ? 256 : c == 1 ? 512 : c == 2 ? 2048 : 8192; }
 __host__ __device__ constexpr int nc_maxdeg(int c) { return c == 0 ? 62 : c == 1 ? 254 : c == 2 ? 1022 : NC_MAXD; }
 __host__ __device__ constexpr int nc_waves(int c) { return c == 2 ? 8 : 4; }  // waves per workgroup
 
@@ -82,36 +82,49 @@ __device__ inline unsigned cnt_add(unsigned *cnt, int h) {
     return (atomicAdd(&cnt[h >> 1], 1u << sh) >> sh) & 0xFFFFu;
 }
 
-// One aligned piece of a streamed row: which of its (up to four) entries inside [lo, hi) are unflagged members of the
-// table, as a 4-bit mask; s1 / gam pick up what the slot counters say about the node that was hit.
+// One aligned piece of a streamed row: which of its four entries (those selected by `vmask`) are unflagged members of
+// the table, as a 4-bit mask; s1 / gam pick up what the slot counters say about the node that was hit.  Entries
+// outside the row are replaced by a key no table holds, so the probe sequence needs no per-entry validity tests; the
+// (rare) hits of a lane are handled one at a time in a loop instead of four predicated copies of that code.
+constexpr unsigned NOKEY = 0xFFFFFFFEu;
+
 template <int SLOTS>
-__device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, const int4 w, int a, int lo, int hi,
-                                          int &s1, int &gam) {
-    const unsigned k0 = (unsigned)w.x, k1 = (unsigned)w.y, k2 = (unsigned)w.z, k3 = (unsigned)w.w;
-    const bool v0 = a >= lo && a < hi, v1 = a + 1 >= lo && a + 1 < hi, v2 = a + 2 >= lo && a + 2 < hi,
-               v3 = a + 3 >= lo && a + 3 < hi;
+__device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, const int4 w, unsigned vmask, int &s1,
+                                          int &gam) {
+    const unsigned k0 = (vmask & 1u) ? (unsigned)w.x : NOKEY, k1 = (vmask & 2u) ? (unsigned)w.y : NOKEY,
+                   k2 = (vmask & 4u) ? (unsigned)w.z : NOKEY, k3 = (vmask & 8u) ? (unsigned)w.w : NOKEY;
     unsigned h0 = hash_slot<SLOTS>(k0), h1 = hash_slot<SLOTS>(k1), h2 = hash_slot<SLOTS>(k2), h3 = hash_slot<SLOTS>(k3);
-    unsigned e0 = v0 ? tab[h0] : EMPTY, e1 = v1 ? tab[h1] : EMPTY, e2 = v2 ? tab[h2] : EMPTY, e3 = v3 ? tab[h3] : EMPTY;
-    while (e0 != EMPTY && e0 != k0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; }
-    while (e1 != EMPTY && e1 != k1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; }
-    while (e2 != EMPTY && e2 != k2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; }
-    while (e3 != EMPTY && e3 != k3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; }
-    unsigned m = 0;
-#define DCR_NC_HIT(E, H, BIT)                          \
-    if ((E) != EMPTY) {                                \
-        const unsigned old = cnt_add(cnt, (int)(H));   \
-        if (!(old & 0x8000u)) {                        \
-            m |= (BIT);                                \
-            s1 += (old == 0u);                         \
-            gam = (int)old + 1 > gam ? (int)old + 1 : gam; \
-        }                                              \
+    unsigned e0 = tab[h0], e1 = tab[h1], e2 = tab[h2], e3 = tab[h3];
+    bool p0 = e0 != EMPTY && e0 != k0, p1 = e1 != EMPTY && e1 != k1, p2 = e2 != EMPTY && e2 != k2,
+         p3 = e3 != EMPTY && e3 != k3;
+    while (p0 | p1 | p2 | p3) {
+        if (p0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; p0 = e0 != EMPTY && e0 != k0; }
+        if (p1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; p1 = e1 != EMPTY && e1 != k1; }
+        if (p2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; p2 = e2 != EMPTY && e2 != k2; }
+        if (p3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; p3 = e3 != EMPTY && e3 != k3; }
     }
-    DCR_NC_HIT(e0, h0, 1u)
-    DCR_NC_HIT(e1, h1, 2u)
-    DCR_NC_HIT(e2, h2, 4u)
-    DCR_NC_HIT(e3, h3, 8u)
-#undef DCR_NC_HIT
+    unsigned found = (e0 != EMPTY ? 1u : 0u) | (e1 != EMPTY ? 2u : 0u) | (e2 != EMPTY ? 4u : 0u) | (e3 != EMPTY ? 8u : 0u);
+    unsigned m = 0;
+    while (found) {
+        const unsigned bit = found & (0u - found);
+        found ^= bit;
+        const unsigned h = bit == 1u ? h0 : bit == 2u ? h1 : bit == 4u ? h2 : h3;
+        const unsigned old = cnt_add(cnt, (int)h);
+        if (!(old & 0x8000u)) {
+            m |= bit;
+            s1 += (old == 0u);
+            gam = (int)old + 1 > gam ? (int)old + 1 : gam;
+        }
+    }
     return m;
+}
+
+// which of the four entries of the piece at slot a lie inside the row [lo, hi)
+__device__ inline unsigned piece_mask(int a, int lo, int hi) {
+    const int s = lo - a, t = hi - a;  // t >= 1 for every piece of the row
+    const unsigned head = s > 0 ? (0xFu << s) & 0xFu : 0xFu;
+    const unsigned tail = t < 4 ? (1u << t) - 1u : 0xFu;
+    return head & tail;
 }
 
 struct NcEdge {
@@ -148,6 +161,8 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
     }
     // sweep 1 over N(v): triangles (flagged), where u sits in row v
     int T = 0, posu = -1;
+    int k_first = -1;         // first 64 members of N(v) and whether they are in N(u): reused by sweep 2
+    bool in_first = false;
     for (int base = 0; base < rv.y; base += 64) {
         const int i = base + lane;
         const int k = i < rv.y ? rowv[i] : -1;
@@ -157,6 +172,10 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
         const int h = (k >= 0 && !isu) ? nc_find<SLOTS>(tab, (unsigned)k) : -1;
         if (MODE == MODE_BFC && h >= 0) cnt_flag(cnt, h);
         T += __popcll(__ballot(h >= 0));
+        if (base == 0) {
+            k_first = k;
+            in_first = h >= 0;
+        }
     }
     out.T = T;
     out.posu = posu;
@@ -168,8 +187,13 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
     int s1 = 0, gam = 0, s2 = 0;
     for (int base = 0; base < rv.y; base += 64) {
         const int i = base + lane;
-        const int k = i < rv.y ? rowv[i] : -1;
-        const bool member = k >= 0 && k < g.n && k != u && nc_find<SLOTS>(tab, (unsigned)k) < 0;
+        int k = k_first;
+        bool in_nu = in_first;
+        if (base > 0) {
+            k = i < rv.y ? rowv[i] : -1;
+            in_nu = k >= 0 && nc_find<SLOTS>(tab, (unsigned)k) >= 0;
+        }
+        const bool member = k >= 0 && k < g.n && k != u && !in_nu;
         int2 rk = make_int2(0, 0);
         if (member) {
             rk = g.rowinfo[k];
@@ -188,6 +212,8 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
         sc->rowcnt[lane] = 0;
         if (lane == 0) sc->poff[64] = P;
         wave_sync();
+        const int nb = rv.y - base < 64 ? rv.y - base : 64;  // rows in this batch: bounds the bisection depth
+        const int step0 = nb > 32 ? 32 : nb > 16 ? 16 : nb > 8 ? 8 : nb > 4 ? 4 : nb > 2 ? 2 : 1;
         for (int j0 = 0; j0 < P; j0 += 256) {
             int4 w[4];
             int rr[4], aa[4];
@@ -199,8 +225,7 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
                 w[q] = make_int4(0, 0, 0, 0);
                 if (j < P) {
                     int r = 0;
-#pragma unroll
-                    for (int step = 32; step > 0; step >>= 1)
+                    for (int step = step0; step > 0; step >>= 1)
                         if (sc->poff[r + step] <= j) r += step;
                     const int2 d = sc->desc[r];
                     const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
@@ -213,7 +238,7 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
             for (int q = 0; q < 4; ++q) {
                 if (rr[q] >= 0) {
                     const int2 d = sc->desc[rr[q]];
-                    const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], aa[q], d.x, d.x + d.y, s1, gam);
+                    const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], piece_mask(aa[q], d.x, d.x + d.y), s1, gam);
                     if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
                 }
             }
@@ -304,7 +329,7 @@ __global__ void __launch_bounds__(256) k_nc_wave(View g, const int2 *units, cons
         return;
     }
     const int max_rounds = total / CHUNK + 2;
-    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == 128 ? 0 : 16384) + (int)(blockIdx.x * WPB + wid) % 16384) : nullptr;
+    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == nc_slots(0) ? 0 : 16384) + (int)(blockIdx.x * WPB + wid) % 16384) : nullptr;
     if (tr && lane == 0) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
     for (int round = 0; round < max_rounds; ++round) {
         int first = 0;
@@ -320,7 +345,7 @@ __global__ void __launch_bounds__(256) k_nc_wave(View g, const int2 *units, cons
                 continue;
             }
             int2 ru = g.rowinfo[u];
-            if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;
+            if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;  // the plan's classes keep the load <= 1/2
             const int nsub = (ru.y + NC_LANES - 1) / NC_LANES;
             if (sub >= nsub) continue;
             for (int i = lane; i < SLOTS; i += 64) tab[i] = EMPTY;

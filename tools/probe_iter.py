@@ -18,7 +18,7 @@ for it in range(60):
     t = time.perf_counter(); imp, _, _ = G.improvements(x, y, 'bfc'); T['imp'] += time.perf_counter() - t
     ncs.append(imp.shape[0])
     t = time.perf_counter(); p = softmax(np.array(imp), tau=163); T['softmax'] += time.perf_counter() - t
-    t = time.perf_counter(); idx = int(np.random.choice(imp.shape[0], p=p)); T['choice'] += time.perf_counter() - t
+    t = time.perf_counter(); from rewiring.sdrf_no_cuda import choice_index; idx = choice_index(p); T['choice'] += time.perf_counter() - t
     t = time.perf_counter(); k, l = G.candidate_at(idx); T['cand'] += time.perf_counter() - t
     t = time.perf_counter(); G.sdrf_tail((k, l), True, 0.95); T['tail'] += time.perf_counter() - t
 for k, v in T.items(): print(f'{k:8s} {v / 60 * 1e3:8.3f} ms/iter')
