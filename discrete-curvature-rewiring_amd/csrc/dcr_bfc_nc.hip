@@ -448,11 +448,22 @@ __global__ void __launch_bounds__(256) k_nc_plan(View g, NcLists L, const uint8_
     // wave classes: one unit per sub-unit; block classes: one unit per group of W sub-units
     const int W = cls >= 2 ? nc_waves(cls) : 1;
     const int nunits = cls < 0 ? 0 : (nsub + W - 1) / W;
-    if (PHASE == 1 && blockIdx.x == 0 && threadIdx.x < NC_CLASSES) {
-        int tot = 0;
-        for (int b = 0; b < NC_BUCKETS; ++b)
-            if (nc_bucket_class(b) == (int)threadIdx.x) tot += res->nc_bucket[b];
-        res->nc_count[threadIdx.x] = tot;
+    __shared__ int bucket_base[NC_BUCKETS];  // PHASE 1: where each bucket starts inside its class list
+    if (PHASE == 1) {
+        if (threadIdx.x < NC_BUCKETS) {
+            const int b = threadIdx.x;
+            int before = 0;
+            for (int h = b + 1; h < NC_BUCKETS; ++h)  // heavier buckets of the same class come first
+                if (nc_bucket_class(h) == nc_bucket_class(b)) before += res->nc_bucket[h];
+            bucket_base[b] = before;
+        }
+        if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + NC_CLASSES) {
+            int tot = 0;
+            for (int b = 0; b < NC_BUCKETS; ++b)
+                if (nc_bucket_class(b) == (int)threadIdx.x - 64) tot += res->nc_bucket[b];
+            res->nc_count[threadIdx.x - 64] = tot;
+        }
+        __syncthreads();
     }
     for (int b = 0; b < NC_BUCKETS; ++b) {
         const unsigned long long m = __ballot(bkt == b);
@@ -469,11 +480,7 @@ __global__ void __launch_bounds__(256) k_nc_plan(View g, NcLists L, const uint8_
             continue;
         }
         int base = 0;
-        if (lane == 0) {
-            base = atomicAdd(&res->nc_fill[b], tot);
-            for (int h = b + 1; h < NC_BUCKETS; ++h)  // heavier buckets of the same class come first
-                if (nc_bucket_class(h) == nc_bucket_class(b)) base += res->nc_bucket[h];
-        }
+        if (lane == 0) base = atomicAdd(&res->nc_fill[b], tot) + bucket_base[b];
         base = __shfl(base, 0);
         if (bkt == b) {
             const int first = base + incl - nunits;

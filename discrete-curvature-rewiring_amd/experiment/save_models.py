@@ -1,0 +1,125 @@
+"""Rewire, split, train — call surface of the reference's experiment/save_models.py:21-88.
+
+``save_models(dname, curv_type, patience=10, redo_rewiring=False)`` runs the reference's pipeline for one dataset and
+one curvature kind and returns the list of best ``state_dict``s, one per validation seed:
+
+  save_models.py:43   DataLoader(dname, undirected=True)            experiment/data_loader.py (no PyG)
+  save_models.py:46   rewire(data, curv_type, iterations, bound, tau) SDRF on the MI355X (rewiring/rewire.py)
+  save_models.py:48   pickle of the rewired edge_index              same file names, CPU int64 tensor
+  save_models.py:67   seeded split per validation seed              experiment/data_splits.py
+  save_models.py:74   GCN(dataset, [hidden_dim] * depth, dropout)   models/gcn.py (HIP aggregation)
+  save_models.py:78   Adam, weight decay on the first layer only    unchanged
+  save_models.py:85   training_loop(..., epochs=1000, patience)     experiment/training_loop.py
+
+The pickles interoperate with the reference's experiment/test_performance.py: edge indices are CPU LongTensors and the
+state dicts hold CPU tensors under the keys ``layers.{i}.bias`` / ``layers.{i}.lin.weight``.  Extra keyword arguments
+(data_dir, out_dir, seeds, epochs, device) default to the reference's hard-coded values.
+"""
+import os
+import pickle
+import random
+
+import torch
+
+from experiment.data_loader import DataLoader
+from experiment.data_splits import set_train_val_test_split, set_train_val_test_split_frac
+from experiment.training_loop import training_loop
+from models.gcn import GCN
+from rewiring.rewire import rewire
+from utils.hyperparams import hyperparams
+from utils.seeds import val_seeds
+
+PLANETOID_STYLE_SPLIT = ('Cora', 'Citeseer', 'Pubmed', 'Computers', 'Photo', 'CoauthorCS')
+
+
+def split_for(dname, seed, data):
+    """save_models.py:67-71 / test_performance.py:65-69: which split a dataset gets."""
+    if dname in PLANETOID_STYLE_SPLIT:
+        return set_train_val_test_split(seed, data)
+    return set_train_val_test_split_frac(seed, data, val_frac=0.2, test_frac=0.2)
+
+
+def hyperparams_for(dname):
+    """Synthetic bench datasets ('synthetic:N:m:F:C') train with Cora's values."""
+    return hyperparams[dname if dname in hyperparams else 'Cora']
+
+
+def build_model_and_optimizer(dataset, hp, device):
+    model = GCN(dataset=dataset, hidden=[hp['hidden_dim']] * hp['hidden_depth'], dropout=hp['dropout']).to(device)
+    # weight decay on the first layer's parameters only (save_models.py:78-82)
+    optimizer = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                                  {'params': model.reg_params, 'weight_decay': hp['weight_decay']}],
+                                 lr=hp['learning_rate'])
+    return model, optimizer
+
+
+def _dump(obj, path):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'wb') as f:
+        pickle.dump(obj, f)
+
+
+def _rewired(dname, curv_type, hp, data_dir):
+    dataset = DataLoader(dname, undirected=True, data_dir=data_dir)
+    ei = rewire(dataset.data, curv_type, hp['max_iterations'], hp['removal_bound'], hp['tau'])
+    dataset.data.edge_index = ei.cpu() if hasattr(ei, 'cpu') else torch.as_tensor(ei)
+    return dataset
+
+
+def save_models(dname, curv_type, patience=10, redo_rewiring=False, data_dir='dt', out_dir='.', seeds=None,
+                epochs=1000, device='cuda:0', verbose=True):
+    hp = hyperparams_for(dname)
+    seeds = val_seeds if seeds is None else seeds
+    dataset = DataLoader(dname, undirected=True, data_dir=data_dir)
+
+    if not redo_rewiring or curv_type is None:
+        if verbose:
+            print(f'Rewiring for {curv_type} curvature...')
+        dataset = _rewired(dname, curv_type, hp, data_dir)
+        _dump(dataset.data.edge_index, os.path.join(out_dir, 'edge_indices', dname, f'edge_index_{curv_type}.pk'))
+
+    state_dicts = []
+    if verbose:
+        print('Training...')
+    for i, seed in enumerate(seeds):
+        random.seed(seed)
+        if redo_rewiring and curv_type is not None:
+            dataset = _rewired(dname, curv_type, hp, data_dir)
+            _dump(dataset.data.edge_index, os.path.join(out_dir, 'edge_indices', f'{dname}_redo_rewiring', str(curv_type),
+                                                        f'edge_index_{curv_type}_{i:02d}.pk'))
+        dataset.data = split_for(dname, seed, dataset.data.to('cpu'))
+        dataset.data = dataset.data.to(device)
+        model, optimizer = build_model_and_optimizer(dataset, hp, device)
+        model = training_loop(model, optimizer, dataset.data, epochs=epochs, patience=patience)
+        state_dicts.append({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    return state_dicts
+
+
+def run(datasets, curvatures, **kwargs):
+    """The reference's ``__main__`` loop (save_models.py:91-106): every dataset x curvature, failures reported and
+    skipped, one pickle of state dicts per pair."""
+    out_dir = kwargs.get('out_dir', '.')
+    for name in datasets:
+        print(f'{name}:')
+        for curvature in curvatures:
+            try:
+                sd = save_models(name, curvature, **kwargs)
+                _dump(sd, os.path.join(out_dir, 'state_dicts', name, f'state_dicts_{curvature}.pk'))
+            except Exception as e:  # the reference prints and carries on
+                print(str(name), str(curvature), str(e))
+            print()
+        print()
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    ap.add_argument('--datasets', nargs='+', default=['Cornell', 'Texas', 'Wisconsin'])
+    ap.add_argument('--curvatures', nargs='+', default=['None', '1d', 'augmented', 'haantjes', 'bfc'])
+    ap.add_argument('--data-dir', default='dt')
+    ap.add_argument('--out-dir', default='.')
+    ap.add_argument('--patience', type=int, default=10)
+    ap.add_argument('--seeds', type=int, default=None, help='use only the first K validation seeds')
+    a = ap.parse_args()
+    run(a.datasets, [None if c == 'None' else c for c in a.curvatures], data_dir=a.data_dir, out_dir=a.out_dir,
+        patience=a.patience, seeds=None if a.seeds is None else val_seeds[:a.seeds])
