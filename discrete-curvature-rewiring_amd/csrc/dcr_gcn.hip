@@ -1,7 +1,7 @@
 // GCN sparse aggregation of libdcr_hip.so: C = Â · B (+ bias, ReLU) on CSR, fp32.
 //
 // Replaces the propagate/scatter-add of torch_geometric GCNConv (third-party; call site models/gcn.py:36).
-// HBM-bound: every non-zero pulls one row of B (n_feat floats).  A row of Â is owned by a group of LPR lanes,
+// HBM / Infinity-Cache gather-bound: every non-zero pulls one row of B (n_feat floats).  A row of Â is owned by a group of LPR lanes,
 // each lane holding VEC consecutive features, so one wave-instruction reads (64/LPR) rows of B in 16-byte
 // pieces (full 128-B lines for n_feat >= 32) and a wave covers 64/LPR output rows.  MFMA has nothing to do here:
 // the dense contraction (X·Wᵀ) is done before this kernel on the matrix cores by the GEMM library.
@@ -9,64 +9,117 @@
 
 namespace dcr {
 
+// accumulate non-zeros e0, e0 + stride, ... < e1 of one row into acc (four gathers of B in flight)
+template <int VEC>
+__device__ inline void spmm_accumulate(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                       const float *__restrict__ B, int64_t ldb, int f0, int64_t e0, int64_t e1,
+                                       int64_t stride, float (&acc)[VEC]) {
+    int64_t e = e0;
+    for (; e + 3 * stride < e1; e += 4 * stride) {
+        int c[4];
+        float w[4];
+        float b[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = col[e + u * stride];
+            w[u] = val[e + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *src = B + (int64_t)c[u] * ldb + f0;
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(src);
+                b[u][0] = t.x; b[u][1 % VEC] = t.y; b[u][2 % VEC] = t.z; b[u][3 % VEC] = t.w;
+            } else if (VEC == 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(src);
+                b[u][0] = t.x; b[u][1 % VEC] = t.y;
+            } else {
+                b[u][0] = src[0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w[u], b[u][q], acc[q]);
+    }
+    for (; e < e1; e += stride) {
+        const int c = col[e];
+        const float w = val[e];
+        const float *src = B + (int64_t)c * ldb + f0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, src[q], acc[q]);
+    }
+}
+
+// Rows up to SPMM_LONG non-zeros: one LPR-lane group per row, non-zeros in order.  Longer rows (the hubs of a
+// power-law graph: thousands of non-zeros, which one group would chew through long after the rest of the grid has
+// finished) are parked in LDS and then taken by the whole workgroup: group g accumulates non-zeros g, g + G, ... and
+// the partial sums are added in group order, so the result is deterministic.
+constexpr int SPMM_LONG = 96;
+
 template <int LPR, int VEC>
 __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const float *__restrict__ val, const float *__restrict__ B,
                                                    float *__restrict__ C, int64_t n_rows, int n_feat, int64_t ldb,
                                                    int64_t ldc, const float *__restrict__ bias, int relu) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
-    const int sub = threadIdx.x / LPR;       // which row of the block
-    const int sl = threadIdx.x % LPR;        // lane inside the row group
-    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + sub;
-    if (row >= n_rows) return;
-    const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-    for (int f0 = sl * VEC; f0 < n_feat; f0 += LPR * VEC) {
-        float acc[VEC];
+    constexpr int G = ROWS_PER_BLOCK;        // lane groups per workgroup
+    __shared__ int long_rows[ROWS_PER_BLOCK];
+    __shared__ int n_long;
+    __shared__ float red[256 * VEC];
+    const int sub = threadIdx.x / LPR;       // which row of the block / which group
+    const int sl = threadIdx.x % LPR;        // lane inside the group
+    // group `sub` of workgroup b owns row sub * gridDim + b: consecutive (hub) rows land in different workgroups
+    const int64_t row = (int64_t)sub * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    if (row < n_rows) {
+        const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+        if (e1 - e0 > SPMM_LONG) {
+            if (sl == 0) long_rows[atomicAdd(&n_long, 1)] = sub;
+        } else {
+            for (int f0 = sl * VEC; f0 < n_feat; f0 += LPR * VEC) {
+                float acc[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-        int64_t e = e0;
-        // four non-zeros in flight per lane group
-        for (; e + 4 <= e1; e += 4) {
-            int c[4];
-            float w[4];
-            float b[4][VEC];
+                for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+                spmm_accumulate<VEC>(col, val, B, ldb, f0, e0, e1, 1, acc);
+                float *dst = C + row * ldc + f0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                c[u] = col[e + u];
-                w[u] = val[e + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float *src = B + (int64_t)c[u] * ldb + f0;
-                if (VEC == 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(src);
-                    b[u][0] = t.x; b[u][1 % VEC] = t.y; b[u][2 % VEC] = t.z; b[u][3 % VEC] = t.w;
-                } else if (VEC == 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(src);
-                    b[u][0] = t.x; b[u][1 % VEC] = t.y;
-                } else {
-                    b[u][0] = src[0];
+                for (int q = 0; q < VEC; ++q) {
+                    float r = acc[q];
+                    if (bias) r += bias[f0 + q];
+                    if (relu) r = r > 0.f ? r : 0.f;
+                    dst[q] = r;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w[u], b[u][q], acc[q]);
         }
-        for (; e < e1; ++e) {
-            const int c = col[e];
-            const float w = val[e];
-            const float *src = B + (int64_t)c * ldb + f0;
+    }
+    __syncthreads();
+    const int nl = n_long;  // uniform
+    for (int li = 0; li < nl; ++li) {
+        const int64_t lrow = (int64_t)long_rows[li] * gridDim.x + blockIdx.x;
+        const int64_t e0 = rowptr[lrow], e1 = rowptr[lrow + 1];
+        for (int fb = 0; fb < n_feat; fb += LPR * VEC) {  // uniform trip count
+            const int f0 = fb + sl * VEC;
+            float acc[VEC];
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, src[q], acc[q]);
-        }
-        float *dst = C + row * ldc + f0;
+            for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+            if (f0 < n_feat) spmm_accumulate<VEC>(col, val, B, ldb, f0, e0 + sub, e1, G, acc);
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            float r = acc[q];
-            if (bias) r += bias[f0 + q];
-            if (relu) r = r > 0.f ? r : 0.f;
-            dst[q] = r;
+            for (int q = 0; q < VEC; ++q) red[threadIdx.x * VEC + q] = acc[q];
+            __syncthreads();
+            if (sub == 0 && f0 < n_feat) {
+                float *dst = C + lrow * ldc + f0;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    float r = 0.f;
+                    for (int g = 0; g < G; ++g) r += red[(g * LPR + sl) * VEC + q];
+                    if (bias) r += bias[f0 + q];
+                    if (relu) r = r > 0.f ? r : 0.f;
+                    dst[q] = r;
+                }
+            }
+            __syncthreads();
         }
     }
 }
