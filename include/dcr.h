@@ -127,11 +127,23 @@ int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes);
  * Replaces the propagate/scatter step of torch_geometric GCNConv (third-party,
  * call site models/gcn.py:36): C[i,:] = (bias ? bias : 0) + sum_e val[e] * B[col[e],:]
  * over CSR row i, optionally followed by ReLU.  fp32, row-major; ldb/ldc in
- * elements.  Rows are accumulated in CSR order with fused multiply-adds, so the
- * result is deterministic for a given CSR.  Asynchronous on hip_stream. */
+ * elements.  Rows are accumulated with fused multiply-adds in CSR order (rows
+ * above 96 non-zeros: in a fixed strided order), so the result is deterministic
+ * for a given CSR.  Asynchronous on hip_stream. */
 int dcr_spmm_csr_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev,
                          const float *B_dev, float *C_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
                          const float *bias_dev, int relu, void *hip_stream);
+
+/* ---- GCN weight gradient on the matrix cores (device pointers, caller's stream)
+ * C[M x N] = A^T * B with A [K x M] and B [K x N] row-major fp32 (lda/ldb/ldc in
+ * elements), K = number of nodes: the backward of GCNConv's bias-free Linear,
+ * dW = dZ^T * X (third-party torch_geometric; call site models/gcn.py:36 through
+ * autograd).  Exact f32 MFMA (v_mfma_f32_32x32x2_f32), K split across workgroups,
+ * partial tiles summed in a fixed order: deterministic.  The caller provides a
+ * scratch buffer of dcr_atb_f32_workspace() floats.  Asynchronous on hip_stream. */
+int dcr_atb_f32_workspace(int64_t K, int64_t M, int64_t N, int64_t *out_floats);
+int dcr_atb_f32_dev(const float *A_dev, const float *B_dev, float *C_dev, int64_t K, int64_t M, int64_t N, int64_t lda,
+                    int64_t ldb, int64_t ldc, float *workspace_dev, int64_t workspace_floats, void *hip_stream);
 
 #ifdef __cplusplus
 }
