@@ -47,9 +47,10 @@ __device__ inline void wave_sync() {
 // lower-degree endpoint's neighbours); degree-1 edges are finished by the smaller id without any lookup
 __device__ inline bool nc_owns(int a, int da, int b, int db, bool trivial_rule) {
     if (!nc_takes(da, db)) return false;  // left to the edge-centric kernels
+    const bool a_can = da <= NC_MAXD, b_can = db <= NC_MAXD;  // only nodes within the table sizes get units
+    if (!a_can) return false;
+    if (!b_can) return true;
     if (trivial_rule && (da < db ? da : db) == 1) return a < b;
-    if (da > NC_MAXD) return false;
-    if (db > NC_MAXD) return true;
     return da > db || (da == db && a < b);
 }
 
@@ -282,10 +283,13 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
             if (own && g.dirty) own = (g.dirty[u] | g.dirty[v]) != 0;
         }
     }
-    if (own && curv_type == DCR_CURV_BFC && (ru.y < rv.y ? ru.y : rv.y) == 1) {  // bfc_naive.py:18-19
-        curv[ru.x + p] = 0.0;  // the owner of a degree-1 edge is the smaller id: the slot is in its own row
+    const bool trivial = curv_type == DCR_CURV_BFC && (ru.y < rv.y ? ru.y : rv.y) == 1;  // bfc_naive.py:18-19
+    if (own && trivial && u < v) {
+        curv[ru.x + p] = 0.0;  // the slot is in the owner's own row: nothing to look up
         own = false;
     }
+    // (a degree-1 edge whose smaller endpoint is too big to own units takes the general path below, which finds
+    //  the slot in the other row; its value is forced to 0 at the end)
     int my_T = 0, my_s1 = 0, my_s2 = 0, my_gam = 0, my_posu = -1;
     unsigned long long todo = __ballot(own);
     while (todo) {
@@ -305,7 +309,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
         if (slot < 0 || slot >= g.cap_total) {
             row_ok(g, make_int2(-1, my_posu), 13, u, v);  // adjacency not symmetric: report, never write
         } else if (MODE == MODE_BFC) {
-            curv[slot] = bfc_formula(ru.y, rv.y, my_T, my_s1, my_s2, my_gam);
+            curv[slot] = trivial ? 0.0 : bfc_formula(ru.y, rv.y, my_T, my_s1, my_s2, my_gam);
         } else {
             curv[slot] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - ru.y - rv.y + 3 * my_T) : (double)my_T;
         }
