@@ -164,6 +164,7 @@ def main():
     ap.add_argument('--removal-bound', type=float, default=0.95)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gcn', action='store_true')
+    ap.add_argument('--no-incremental', action='store_true')
     ap.add_argument('--gcn-nodes', type=int, default=1000000)
     ap.add_argument('--gcn-epochs', type=int, default=20)
     ap.add_argument('--gcn-warmup', type=int, default=3)
@@ -226,6 +227,29 @@ def main():
     else:
         total_steps = steps_done
 
+    # optional mode, reported separately (never `value`): the same iterations with the incremental curvature pass, which
+    # recomputes only edges near the previous iteration's edits and leaves the same bits in the buffer
+    inc = None
+    if rank == 0 and not args.no_incremental:
+        run_i = SdrfRun(data, 'bfc', True, args.removal_bound, args.tau, device=local_rank, incremental=True)
+        np.random.seed(0)
+        for _ in range(args.warmup + 1):
+            run_i.step()
+        run_i.G.profile_reset()
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        n_i = 0
+        for _ in range(args.steps):
+            n_i += 1
+            if not run_i.step():
+                break
+        torch.cuda.synchronize()
+        ti = time.perf_counter() - ti
+        ms_i, cnt_i = run_i.G.profile_read()
+        inc = {'value': n_i / ti, 'unit': 'iterations/sec', 'ms_per_step': ti / n_i * 1e3,
+               'bfc_pass_ms': ms_i / max(cnt_i, 1), 'steps': n_i,
+               'note': 'dcr_curvature_pass_incremental: bit-identical results (tests), not the headline metric'}
+        run_i = None
     run = G = None  # release the SDRF graph before the GCN leg
     gcn = None if args.no_gcn else gcn_bench(args, rank, world, local_rank, dist)
 
@@ -266,6 +290,8 @@ def main():
                 'bfc_edges_per_sec': r['edges_per_sec'], 'pass_seconds': r['extrapolated_pass_seconds'],
                 'note': 'reference bfc_naive.bfc_edge itself, timed in the build container on sampled edges of this '
                         'same graph (tools/make_golden.py); the Python reference cannot travel to the GPU box'}
+        if inc is not None:
+            out['incremental_mode'] = inc
         if gcn is not None:
             out['gcn'] = gcn
         if world == 1 and not args.no_cpu_baseline:
