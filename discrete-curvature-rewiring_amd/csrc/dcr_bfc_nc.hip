@@ -261,10 +261,13 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
     return out;
 }
 
-// One sub-unit of row u: NC_LANES positions, strided by the number of sub-units of the row (p = sub + l * nsub), so
+// One sub-unit of row u: nc_lanes positions, strided by the number of sub-units of the row (p = sub + l * nsub), so
 // that the expensive edges of a hub (those to other hubs sit next to each other at the front of its row) spread over
 // all of its sub-units.  Lane l stands for the edge to the neighbour at its position.
-constexpr int NC_LANES = 16;
+// positions per sub-unit: 16 where edges are cheap (amortises the table build and the closing expression), 4 for the
+// block classes, whose edges cost thousands of entries each (more, smaller units: shorter tails)
+__host__ __device__ constexpr int nc_lanes(int c) { return c < 2 ? 16 : 4; }
+__host__ __device__ constexpr int nc_lanes_for_slots(int slots) { return slots <= 512 ? 16 : 4; }
 
 template <int SLOTS, int MODE>
 __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub, const unsigned *tab, unsigned *cnt,
@@ -274,7 +277,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
     int v = -1;
     int2 rv = make_int2(0, 0);
     bool own = false;
-    if (lane < NC_LANES && p < ru.y) {
+    if (lane < nc_lanes_for_slots(SLOTS) && p < ru.y) {
         v = g.col[ru.x + p];
         if (v >= 0 && v < g.n && v != u) {
             rv = g.rowinfo[v];
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(256) k_nc_wave(View g, const int2 *units, cons
             }
             int2 ru = g.rowinfo[u];
             if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;  // the plan's classes keep the load <= 1/2
-            const int nsub = (ru.y + NC_LANES - 1) / NC_LANES;
+            const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
             if (sub >= nsub) continue;
             for (int i = lane; i < SLOTS; i += 64) tab[i] = EMPTY;
             wave_sync();
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(64 * W) k_nc_block(View g, const int2 *units, 
             if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k);
         }
         __syncthreads();
-        const int nsub = (ru.y + NC_LANES - 1) / NC_LANES;
+        const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
         const int sub = sub0 + wid;
         if (sub < nsub)
             nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_all[wid], &sc_all[wid], curv_type, curv);
@@ -448,7 +451,8 @@ __global__ void __launch_bounds__(256) k_nc_plan(View g, NcLists L, const uint8_
         if (d > 0 && d <= NC_MAXD && (!g.dirty || g.dirty[u] || touch[u])) bkt = nc_bucket_of(d);
     }
     const int cls = bkt < 0 ? -1 : nc_bucket_class(bkt);
-    const int nsub = (d + NC_LANES - 1) / NC_LANES;
+    const int L_ = cls < 0 ? 16 : nc_lanes(cls);
+    const int nsub = (d + L_ - 1) / L_;
     // wave classes: one unit per sub-unit; block classes: one unit per group of W sub-units
     const int W = cls >= 2 ? nc_waves(cls) : 1;
     const int nunits = cls < 0 ? 0 : (nsub + W - 1) / W;
@@ -520,9 +524,9 @@ __global__ void k_nc_clear(DevResult *res) {
 }
 
 static int ensure_nc(dcr_graph *g) {
-    // units per class, from the smallest degree a member node can have and its sub-units (16 positions each)
-    const int64_t need[NC_CLASSES] = {g->n * 4 + 64, g->cap_total / 3 + 64, g->cap_total / 24 + 64,
-                                      g->cap_total / 12 + 64};
+    // units per class, from the smallest degree a member node can have and its sub-units (16 or 4 positions each)
+    const int64_t need[NC_CLASSES] = {g->n * 4 + 64, g->cap_total / 3 + 64, g->cap_total / 6 + 64,
+                                      g->cap_total / 3 + 64};
     for (int c = 0; c < NC_CLASSES; ++c) {
         if (g->nc_cap[c] < need[c]) {
             if (g->nc_units[c]) (void)hipFree(g->nc_units[c]);

@@ -48,8 +48,17 @@ def choice_index(p):
         raise ValueError('probabilities contain NaN')
     if abs(total - 1.0) > _ATOL:
         raise ValueError('probabilities do not sum to 1')
-    cdf /= total
-    return int(cdf.searchsorted(np.random.random_sample(), side='right'))
+    # searchsorted(cdf / total, u, side='right') without dividing the whole vector: x -> x / total is monotone in
+    # floating point, so the first index whose quotient exceeds u is found by bisection on the fly
+    u = np.random.random_sample()
+    lo, hi = 0, cdf.shape[0]
+    while lo < hi:
+        mid = (lo + hi) >> 1
+        if cdf[mid] / total > u:
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
 
 
 class SdrfRun:
