@@ -440,11 +440,19 @@ __device__ inline int nc_bucket_of(int d) {
 }
 __device__ inline int nc_bucket_class(int b) { return b < 6 ? 0 : b < 10 ? 1 : b < 13 ? 2 : 3; }
 
-// PHASE 0 counts the units per bucket; PHASE 1 places them (class list = its buckets, heaviest first)
+// PHASE 0 counts the units per bucket; PHASE 1 places them (class list = its buckets, heaviest first).  Reservations
+// are aggregated wave -> workgroup (LDS) -> one global atomic per bucket and workgroup: the few bucket counters are
+// shared by every node, and one atomic per wave on them made the plan cost as much as 3 % of the pass.
+constexpr int PLAN_THREADS = 1024;
+
 template <int PHASE>
-__global__ void __launch_bounds__(256) k_nc_plan(View g, NcLists L, const uint8_t *touch, DevResult *res) {
-    const int u = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, const uint8_t *touch, DevResult *res) {
+    __shared__ int blk_count[NC_BUCKETS];   // units of this workgroup per bucket
+    __shared__ int blk_base[NC_BUCKETS];    // PHASE 1: where this workgroup's units of a bucket start in the class list
+    const int u = blockIdx.x * PLAN_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x < NC_BUCKETS) blk_count[threadIdx.x] = 0;
+    __syncthreads();
     int bkt = -1, d = 0;
     if (u < g.n) {
         d = g.rowinfo[u].y;
@@ -456,47 +464,47 @@ __global__ void __launch_bounds__(256) k_nc_plan(View g, NcLists L, const uint8_
     // wave classes: one unit per sub-unit; block classes: one unit per group of W sub-units
     const int W = cls >= 2 ? nc_waves(cls) : 1;
     const int nunits = cls < 0 ? 0 : (nsub + W - 1) / W;
-    __shared__ int bucket_base[NC_BUCKETS];  // PHASE 1: where each bucket starts inside its class list
-    if (PHASE == 1) {
-        if (threadIdx.x < NC_BUCKETS) {
-            const int b = threadIdx.x;
-            int before = 0;
-            for (int h = b + 1; h < NC_BUCKETS; ++h)  // heavier buckets of the same class come first
-                if (nc_bucket_class(h) == nc_bucket_class(b)) before += res->nc_bucket[h];
-            bucket_base[b] = before;
-        }
-        if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + NC_CLASSES) {
-            int tot = 0;
-            for (int b = 0; b < NC_BUCKETS; ++b)
-                if (nc_bucket_class(b) == (int)threadIdx.x - 64) tot += res->nc_bucket[b];
-            res->nc_count[threadIdx.x - 64] = tot;
-        }
-        __syncthreads();
-    }
+    int my_off = 0;  // offset of this node's units inside its workgroup's share of the bucket
     for (int b = 0; b < NC_BUCKETS; ++b) {
         const unsigned long long m = __ballot(bkt == b);
         if (m == 0) continue;
-        // wave-aggregated reservation: exclusive prefix of nunits over the lanes of this bucket
         int incl = bkt == b ? nunits : 0;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
         const int tot = __shfl(incl, 63);
+        int wave_off = 0;
+        if (lane == 0) wave_off = atomicAdd(&blk_count[b], tot);
+        wave_off = __shfl(wave_off, 0);
+        if (bkt == b) my_off = wave_off + incl - nunits;
+    }
+    __syncthreads();
+    if (threadIdx.x < NC_BUCKETS) {
+        const int b = threadIdx.x, c = blk_count[b];
         if (PHASE == 0) {
-            if (lane == 0) atomicAdd(&res->nc_bucket[b], tot);
-            continue;
+            if (c) atomicAdd(&res->nc_bucket[b], c);
+        } else {
+            int before = 0;
+            for (int h = b + 1; h < NC_BUCKETS; ++h)  // heavier buckets of the same class come first
+                if (nc_bucket_class(h) == nc_bucket_class(b)) before += res->nc_bucket[h];
+            blk_base[b] = before + (c ? atomicAdd(&res->nc_fill[b], c) : 0);
         }
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&res->nc_fill[b], tot) + bucket_base[b];
-        base = __shfl(base, 0);
-        if (bkt == b) {
-            const int first = base + incl - nunits;
-            if (first < 0 || (int64_t)first + nunits > L.cap[cls]) {
-                row_ok(g, make_int2(-1, first), 19, u, nunits);
-            } else {
-                for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int2(u, j * W);
-            }
+    }
+    if (PHASE == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + NC_CLASSES) {
+        int tot = 0;
+        for (int b = 0; b < NC_BUCKETS; ++b)
+            if (nc_bucket_class(b) == (int)threadIdx.x - 64) tot += res->nc_bucket[b];
+        res->nc_count[threadIdx.x - 64] = tot;
+    }
+    __syncthreads();
+    if (bkt >= 0) {
+        const int first = blk_base[bkt] + my_off;
+        if (first < 0 || (int64_t)first + nunits > L.cap[cls]) {
+            row_ok(g, make_int2(-1, first), 19, u, nunits);
+        } else {
+            for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int2(u, j * W);
         }
     }
 }
@@ -596,10 +604,12 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         const int64_t blocks = (g->cap_total + 255) / 256;
         if (blocks > 0) hipLaunchKernelGGL(k_nc_touch, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->nc_touch);
     }
-    const int64_t pblocks = (g->n + 255) / 256;
+    const int64_t pblocks = (g->n + PLAN_THREADS - 1) / PLAN_THREADS;
     if (pblocks > 0) {
-        hipLaunchKernelGGL(k_nc_plan<0>, dim3((unsigned)pblocks), dim3(256), 0, g->stream, vw, L, g->nc_touch, g->dres);
-        hipLaunchKernelGGL(k_nc_plan<1>, dim3((unsigned)pblocks), dim3(256), 0, g->stream, vw, L, g->nc_touch, g->dres);
+        hipLaunchKernelGGL(k_nc_plan<0>, dim3((unsigned)pblocks), dim3(PLAN_THREADS), 0, g->stream, vw, L, g->nc_touch,
+                           g->dres);
+        hipLaunchKernelGGL(k_nc_plan<1>, dim3((unsigned)pblocks), dim3(PLAN_THREADS), 0, g->stream, vw, L, g->nc_touch,
+                           g->dres);
     }
     // the four classes are independent: fork them onto side streams; the rarest, longest-running units first
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;  // debugging aid: one stream

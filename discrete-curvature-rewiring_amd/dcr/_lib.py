@@ -71,6 +71,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DcrError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                            f'(there is no CPU fallback for the curvature / SDRF path)')
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if this library pulled in the system
+        # one first, torch.cuda would later report "No HIP GPUs are available".  Let torch load and initialise its
+        # runtime first, so libdcr_hip.so binds to the copy that is already in the process.
+        try:
+            import torch
+            if getattr(torch.version, 'hip', None):
+                torch.cuda.is_available()
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
