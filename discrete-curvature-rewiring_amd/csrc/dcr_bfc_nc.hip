@@ -138,6 +138,9 @@ struct NcScratch {
     int poff[66];    // exclusive prefix of their piece counts; poff[64] = total
     int rowcnt[64];  // hits per row
     int acc[2];      // wave totals: |sq| on the table side, gamma
+    int acc4[4][2];  // the same per edge of a batch
+    int res[4][5];   // batch results per edge: T, |sq| table side, |sq| row side, gamma, position of u in row v
+    int fin[16][5];  // the same per position of the unit, read back when the closing expressions are evaluated
 };
 
 // One edge {u,v} owned by u, by one wave.  `tab` holds N(u); cnt and sc are this wave's scratch.
@@ -242,6 +245,7 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
                     const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], piece_mask(aa[q], d.x, d.x + d.y), s1, gam);
                     if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
                 }
+                __builtin_amdgcn_sched_barrier(0);  // one probe sequence live at a time: keeps the wave at 8 per SIMD
             }
         }
         wave_sync();
@@ -264,6 +268,138 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
 // One sub-unit of row u: nc_lanes positions, strided by the number of sub-units of the row (p = sub + l * nsub), so
 // that the expensive edges of a hub (those to other hubs sit next to each other at the front of its row) spread over
 // all of its sub-units.  Lane l stands for the edge to the neighbour at its position.
+// edges processed side by side by one wave (their neighbour rows share the 64 lanes): 4 for the smallest class,
+// 2 for the next, 1 (no batching) for the block classes
+__host__ __device__ constexpr int nc_batch_for_slots(int slots) { return slots <= 256 ? 4 : slots <= 512 ? 2 : 1; }
+
+// nc_probe_piece for a batch: the lanes of one wave-instruction work on rows of different edges, so the slot counters
+// (cnt) and the per-edge totals (acc: LDS atomics, hits are rare) are passed per lane
+template <int SLOTS>
+__device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt, int *acc, const int4 w, unsigned vmask) {
+    const unsigned k0 = (vmask & 1u) ? (unsigned)w.x : NOKEY, k1 = (vmask & 2u) ? (unsigned)w.y : NOKEY,
+                   k2 = (vmask & 4u) ? (unsigned)w.z : NOKEY, k3 = (vmask & 8u) ? (unsigned)w.w : NOKEY;
+    unsigned h0 = hash_slot<SLOTS>(k0), h1 = hash_slot<SLOTS>(k1), h2 = hash_slot<SLOTS>(k2), h3 = hash_slot<SLOTS>(k3);
+    unsigned e0 = tab[h0], e1 = tab[h1], e2 = tab[h2], e3 = tab[h3];
+    bool p0 = e0 != EMPTY && e0 != k0, p1 = e1 != EMPTY && e1 != k1, p2 = e2 != EMPTY && e2 != k2,
+         p3 = e3 != EMPTY && e3 != k3;
+    while (p0 | p1 | p2 | p3) {
+        if (p0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; p0 = e0 != EMPTY && e0 != k0; }
+        if (p1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; p1 = e1 != EMPTY && e1 != k1; }
+        if (p2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; p2 = e2 != EMPTY && e2 != k2; }
+        if (p3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; p3 = e3 != EMPTY && e3 != k3; }
+    }
+    unsigned found = (e0 != EMPTY ? 1u : 0u) | (e1 != EMPTY ? 2u : 0u) | (e2 != EMPTY ? 4u : 0u) | (e3 != EMPTY ? 8u : 0u);
+    unsigned m = 0;
+    while (found) {
+        const unsigned bit = found & (0u - found);
+        found ^= bit;
+        const unsigned h = bit == 1u ? h0 : bit == 2u ? h1 : bit == 4u ? h2 : h3;
+        const unsigned old = cnt_add(cnt, (int)h);
+        if (!(old & 0x8000u)) {
+            m |= bit;
+            if (old == 0u) atomicAdd(&acc[0], 1);          // a new member of sq on the table side
+            else atomicMax(&acc[1], (int)old + 1);         // (a first hit's 1 is covered by the row-side maximum)
+        }
+    }
+    return m;
+}
+
+// B edges {u, v_b} owned by u, by one wave: lane group b (64 / B lanes) sweeps N(v_b); the rows of all the DY sets form
+// one flat piece list.  `v`, `rv` are those of the lane's group (rv.y == 0: the group has no edge; every rv.y <= 64 / B).
+// Results go to sc->res[b].
+template <int SLOTS, int B>
+__device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const unsigned *tab, unsigned *cnt,
+                                     NcScratch *sc) {
+    constexpr int G = 64 / B;
+    const int lane = threadIdx.x & 63, grp = lane / G, gl = lane % G;
+    const unsigned long long gmask = ((1ull << G) - 1ull) << (grp * G);
+    unsigned *cntg = cnt + grp * (SLOTS / 2);
+    uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+    for (int i = lane; i < B * SLOTS / 8; i += 64) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < B) {
+        sc->acc4[lane][0] = 0;
+        sc->acc4[lane][1] = 0;
+    }
+    wave_sync();
+    const bool act = rv.y > 0;
+    if (act && gl == 0) {
+        const int hv = nc_find<SLOTS>(tab, (unsigned)v);  // v is a neighbour of u: never counted as a hit
+        if (hv >= 0) cnt_flag(cntg, hv);
+    }
+    // sweep over N(v_b): triangles (flagged), where u sits in row v_b, the members of DY
+    const int k = (act && gl < rv.y) ? g.col[rv.x + gl] : -1;
+    const bool isu = k == u;
+    const unsigned long long mu = __ballot(isu) & gmask;
+    const int posu = mu ? __ffsll((long long)mu) - 1 - grp * G : -1;
+    const int h = (k >= 0 && !isu) ? nc_find<SLOTS>(tab, (unsigned)k) : -1;
+    if (h >= 0) cnt_flag(cntg, h);
+    const int T = __popcll(__ballot(h >= 0) & gmask);
+    const bool member = k >= 0 && k < g.n && !isu && h < 0;
+    int2 rk = make_int2(0, 0);
+    if (member) {
+        rk = g.rowinfo[k];
+        if (!row_ok(g, rk, 11, k, v)) rk = make_int2(0, 0);
+    }
+    const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
+    int incl = np;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const int P = __shfl(incl, 63);
+    sc->desc[lane] = rk;
+    sc->poff[lane] = incl - np;
+    sc->rowcnt[lane] = 0;
+    if (lane == 0) sc->poff[64] = P;
+    wave_sync();
+    for (int j0 = 0; j0 < P; j0 += 256) {
+        int4 w[4];
+        int rr[4], aa[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + 64 * q + lane;
+            rr[q] = -1;
+            aa[q] = 0;
+            w[q] = make_int4(0, 0, 0, 0);
+            if (j < P) {
+                int r = 0;
+                for (int step = 32; step > 0; step >>= 1)
+                    if (sc->poff[r + step] <= j) r += step;
+                const int2 d = sc->desc[r];
+                const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
+                w[q] = load_piece(g.col, a);
+                rr[q] = r;
+                aa[q] = a;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (rr[q] >= 0) {
+                const int2 d = sc->desc[rr[q]];
+                const int gr = rr[q] / G;
+                const unsigned m = nc_probe_piece_acc<SLOTS>(tab, cnt + gr * (SLOTS / 2), sc->acc4[gr], w[q],
+                                                             piece_mask(aa[q], d.x, d.x + d.y));
+                if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one probe sequence live at a time
+        }
+    }
+    wave_sync();
+    const int c = sc->rowcnt[lane];
+    const int s2 = __popcll(__ballot(c > 0) & gmask);
+    if (c > 0) atomicMax(&sc->acc4[grp][1], c);
+    wave_sync();
+    if (gl == 0) {
+        sc->res[grp][0] = T;
+        sc->res[grp][1] = sc->acc4[grp][0];
+        sc->res[grp][2] = s2;
+        sc->res[grp][3] = sc->acc4[grp][1];
+        sc->res[grp][4] = posu;
+    }
+    wave_sync();
+}
+
 // positions per sub-unit: 16 where edges are cheap (amortises the table build and the closing expression), 4 for the
 // block classes, whose edges cost thousands of entries each (more, smaller units: shorter tails)
 __host__ __device__ constexpr int nc_lanes(int c) { return c < 2 ? 16 : 4; }
@@ -293,8 +429,40 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
     }
     // (a degree-1 edge whose smaller endpoint is too big to own units takes the general path below, which finds
     //  the slot in the other row; its value is forced to 0 at the end)
-    int my_T = 0, my_s1 = 0, my_s2 = 0, my_gam = 0, my_posu = -1;
-    unsigned long long todo = __ballot(own);
+    bool done = false;
+    constexpr int B = nc_batch_for_slots(SLOTS);
+    if constexpr (B > 1 && MODE == MODE_BFC) {
+        // edges whose other endpoint has at most 64 / B neighbours are processed B at a time: the per-edge set-up
+        // (sweeps, prefix sums, LDS round trips, the chain of dependent loads) is paid once per batch
+        constexpr int G = 64 / B;
+        const int grp = lane / G;
+        unsigned long long small = __ballot(own && !trivial && rv.y <= G);
+        while (small) {
+            int lsel[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                lsel[b] = small ? __ffsll((long long)small) - 1 : -1;
+                small &= small - 1;  // (0 & anything stays 0)
+            }
+            int src = -1;
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                if (grp == b) src = lsel[b];
+            const int vg = __shfl(v, src < 0 ? 0 : src);
+            int2 rvg = make_int2(__shfl(rv.x, src < 0 ? 0 : src), __shfl(rv.y, src < 0 ? 0 : src));
+            if (src < 0) rvg.y = 0;
+            nc_edge_batch<SLOTS, B>(g, u, vg, rvg, tab, cnt, sc);
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+                if (lane == lsel[b]) {
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) sc->fin[lane][t] = sc->res[b][t];
+                    done = true;
+                }
+            wave_sync();
+        }
+    }
+    unsigned long long todo = __ballot(own && !done);
     while (todo) {
         const int l = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -302,10 +470,14 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
         const int2 rve = make_int2(__shfl(rv.x, l), __shfl(rv.y, l));
         const NcEdge r = nc_edge<SLOTS, MODE>(g, u, ve, rve, tab, cnt, sc);
         if (lane == l) {
-            my_T = r.T; my_s1 = r.s1; my_s2 = r.s2; my_gam = r.gam; my_posu = r.posu;
+            sc->fin[lane][0] = r.T; sc->fin[lane][1] = r.s1; sc->fin[lane][2] = r.s2; sc->fin[lane][3] = r.gam;
+            sc->fin[lane][4] = r.posu;
         }
     }
+    wave_sync();
     if (own) {
+        const int my_T = sc->fin[lane][0], my_s1 = sc->fin[lane][1], my_s2 = sc->fin[lane][2], my_gam = sc->fin[lane][3],
+                  my_posu = sc->fin[lane][4];
         int64_t slot = -1;
         if (u < v) slot = (int64_t)ru.x + p;
         else if (my_posu >= 0) slot = (int64_t)rv.x + my_posu;
@@ -321,11 +493,11 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
 
 // ---- wave classes: a wave owns a node; persistent waves pull CHUNK nodes at a time ----------------------------
 template <int SLOTS, int MODE, int CHUNK>
-__global__ void __launch_bounds__(256) k_nc_wave(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+__global__ void __launch_bounds__(256, 6) k_nc_wave(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
                                                   int32_t *next, int curv_type, double *curv) {
     constexpr int WPB = 4;
     __shared__ __attribute__((aligned(16))) unsigned tab_all[WPB][SLOTS];
-    __shared__ __attribute__((aligned(16))) unsigned cnt_all[WPB][SLOTS / 2];
+    __shared__ __attribute__((aligned(16))) unsigned cnt_all[WPB][nc_batch_for_slots(SLOTS) * SLOTS / 2];
     __shared__ NcScratch sc_all[WPB];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     unsigned *tab = tab_all[wid], *cnt = cnt_all[wid];
@@ -556,7 +728,7 @@ template <int C, int MODE>
 static void launch_nc_wave(dcr_graph *g, const View &vw, int curv_type, hipStream_t st) {
     constexpr int SLOTS = nc_slots(C);
     constexpr int CHUNK = C == 0 ? 2 : 1;
-    constexpr int LDS = 4 * (SLOTS * 4 + SLOTS * 2 + (int)sizeof(NcScratch));
+    constexpr int LDS = 4 * (SLOTS * 4 + nc_batch_for_slots(SLOTS) * SLOTS * 2 + (int)sizeof(NcScratch));
     int per_cu = (160 * 1024) / LDS;
     if (per_cu > 8) per_cu = 8;  // 32 wave slots per CU, 4 waves per workgroup
     if (per_cu < 1) per_cu = 1;
