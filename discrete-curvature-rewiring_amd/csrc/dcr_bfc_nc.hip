@@ -128,6 +128,23 @@ __device__ inline unsigned piece_mask(int a, int lo, int hi) {
     return head & tail;
 }
 
+// Row of piece j in the flat piece list.  Lane r still holds poff[r] of "its" row in a register, so the rows of the
+// first and the last piece of a 64-piece step come from two ballots.  A few row starts in between: a lane counts how
+// many are at or below its own j; many: bisection over that range only (poff mirrors the prefix sums in LDS).
+__device__ inline int piece_row(const int *poff, int poff_lane, int j, int j_first, int j_last) {
+    const int rf = __popcll(__ballot(poff_lane <= j_first)) - 1;
+    const int rl = __popcll(__ballot(poff_lane <= j_last)) - 1;
+    int r = rf;
+    const int span = rl - rf;  // uniform
+    if (span <= 4) {
+        for (int b = rf + 1; b <= rl; ++b) r += (__shfl(poff_lane, b) <= j);
+    } else {
+        for (int step = span >= 32 ? 32 : span >= 16 ? 16 : span >= 8 ? 8 : 4; step > 0; step >>= 1)
+            if (r + step <= rl && poff[r + step] <= j) r += step;
+    }
+    return r;
+}
+
 struct NcEdge {
     int T, s1, s2, gam, posu;
 };
@@ -213,11 +230,10 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
         const int P = __shfl(incl, 63);
         sc->desc[lane] = rk;
         sc->poff[lane] = incl - np;
+        const int poff_lane = incl - np;
         sc->rowcnt[lane] = 0;
         if (lane == 0) sc->poff[64] = P;
         wave_sync();
-        const int nb = rv.y - base < 64 ? rv.y - base : 64;  // rows in this batch: bounds the bisection depth
-        const int step0 = nb > 32 ? 32 : nb > 16 ? 16 : nb > 8 ? 8 : nb > 4 ? 4 : nb > 2 ? 2 : 1;
         for (int j0 = 0; j0 < P; j0 += 256) {
             int4 w[4];
             int rr[4], aa[4];
@@ -227,10 +243,10 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
                 rr[q] = -1;
                 aa[q] = 0;
                 w[q] = make_int4(0, 0, 0, 0);
+                const int jf = j0 + 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+                if (jf >= P) continue;  // uniform
+                const int r = piece_row(sc->poff, poff_lane, j < P ? j : jl, jf, jl);
                 if (j < P) {
-                    int r = 0;
-                    for (int step = step0; step > 0; step >>= 1)
-                        if (sc->poff[r + step] <= j) r += step;
                     const int2 d = sc->desc[r];
                     const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
                     w[q] = load_piece(g.col, a);
@@ -350,6 +366,7 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
     const int P = __shfl(incl, 63);
     sc->desc[lane] = rk;
     sc->poff[lane] = incl - np;
+    const int poff_lane = incl - np;
     sc->rowcnt[lane] = 0;
     if (lane == 0) sc->poff[64] = P;
     wave_sync();
@@ -362,10 +379,10 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
             rr[q] = -1;
             aa[q] = 0;
             w[q] = make_int4(0, 0, 0, 0);
+            const int jf = j0 + 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+            if (jf >= P) continue;  // uniform
+            const int r = piece_row(sc->poff, poff_lane, j < P ? j : jl, jf, jl);
             if (j < P) {
-                int r = 0;
-                for (int step = 32; step > 0; step >>= 1)
-                    if (sc->poff[r + step] <= j) r += step;
                 const int2 d = sc->desc[r];
                 const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
                 w[q] = load_piece(g.col, a);
