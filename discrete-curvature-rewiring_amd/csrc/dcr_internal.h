@@ -99,6 +99,7 @@ struct dcr_graph {
     int2 *nc_units[4] = {nullptr, nullptr, nullptr, nullptr};  // {node, first sub-unit}
     int64_t nc_cap[4] = {0, 0, 0, 0};
     long long *nc_trace = nullptr;  // DCR_NC_TRACE diagnostic: [4 classes][16384 waves][2]
+    int32_t *nc_queues = nullptr;  // dequeue cursors of the two wave-class kernels, one cache line each
     uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
     int64_t nc_touch_cap = 0;
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
