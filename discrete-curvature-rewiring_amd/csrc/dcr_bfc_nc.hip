@@ -54,25 +54,47 @@ __device__ inline bool nc_owns(int a, int da, int b, int db, bool trivial_rule) 
     return da > db || (da == db && a < b);
 }
 
+// The neighbour table is an open-addressing hash set of 4-slot buckets (16 bytes): a key lives in the first free
+// slot of its home bucket, or of the next bucket when that one is full.  One 16-byte LDS read settles almost every
+// lookup (hit, or a free slot in the bucket = miss); with single-slot linear probing some lane of every
+// wave-instruction needed a second and a third probe, and that loop alone was 15 % of the pass.
+template <int SLOTS>
+__device__ inline unsigned hash_bucket(unsigned key) {
+    constexpr int BITS = __builtin_ctz(SLOTS / 4);
+    return (key * 0x9E3779B1u) >> (32 - BITS);
+}
+
+// position of key inside the bucket (0..3) or -1; go_on: not found and the bucket is full (its slots fill in order,
+// so the last one taken means all taken): the key may have spilled into the next bucket
+__device__ inline int bucket_match(const uint4 e, unsigned key, bool &go_on) {
+    const int pos = e.x == key ? 0 : e.y == key ? 1 : e.z == key ? 2 : e.w == key ? 3 : -1;
+    go_on = pos < 0 && e.w != EMPTY;
+    return pos;
+}
+
 template <int SLOTS>
 __device__ inline void nc_insert(unsigned *tab, unsigned key) {
-    unsigned h = hash_slot<SLOTS>(key);
+    unsigned b = hash_bucket<SLOTS>(key);
     while (true) {
-        const unsigned old = atomicCAS(&tab[h], EMPTY, key);
-        if (old == EMPTY || old == key) return;
-        h = (h + 1) & (SLOTS - 1);
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const unsigned old = atomicCAS(&tab[b * 4 + pos], EMPTY, key);
+            if (old == EMPTY || old == key) return;
+        }
+        b = (b + 1) & (SLOTS / 4 - 1);
     }
 }
 
-// slot of key, or -1 (the table is at most half full, so the walk always meets an empty slot)
+// slot of key, or -1 (the table is at most half full, so the walk always meets a bucket with a free slot)
 template <int SLOTS>
 __device__ inline int nc_find(const unsigned *tab, unsigned key) {
-    unsigned h = hash_slot<SLOTS>(key);
+    unsigned b = hash_bucket<SLOTS>(key);
     while (true) {
-        const unsigned e = tab[h];
-        if (e == key) return (int)h;
-        if (e == EMPTY) return -1;
-        h = (h + 1) & (SLOTS - 1);
+        bool go_on;
+        const int pos = bucket_match(*reinterpret_cast<const uint4 *>(tab + b * 4), key, go_on);
+        if (pos >= 0) return (int)(b * 4) + pos;
+        if (!go_on) return -1;
+        b = (b + 1) & (SLOTS / 4 - 1);
     }
 }
 
@@ -94,17 +116,21 @@ __device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, co
                                           int &gam) {
     const unsigned k0 = (vmask & 1u) ? (unsigned)w.x : NOKEY, k1 = (vmask & 2u) ? (unsigned)w.y : NOKEY,
                    k2 = (vmask & 4u) ? (unsigned)w.z : NOKEY, k3 = (vmask & 8u) ? (unsigned)w.w : NOKEY;
-    unsigned h0 = hash_slot<SLOTS>(k0), h1 = hash_slot<SLOTS>(k1), h2 = hash_slot<SLOTS>(k2), h3 = hash_slot<SLOTS>(k3);
-    unsigned e0 = tab[h0], e1 = tab[h1], e2 = tab[h2], e3 = tab[h3];
-    bool p0 = e0 != EMPTY && e0 != k0, p1 = e1 != EMPTY && e1 != k1, p2 = e2 != EMPTY && e2 != k2,
-         p3 = e3 != EMPTY && e3 != k3;
-    while (p0 | p1 | p2 | p3) {
-        if (p0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; p0 = e0 != EMPTY && e0 != k0; }
-        if (p1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; p1 = e1 != EMPTY && e1 != k1; }
-        if (p2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; p2 = e2 != EMPTY && e2 != k2; }
-        if (p3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; p3 = e3 != EMPTY && e3 != k3; }
+    unsigned b0 = hash_bucket<SLOTS>(k0), b1 = hash_bucket<SLOTS>(k1), b2 = hash_bucket<SLOTS>(k2), b3 = hash_bucket<SLOTS>(k3);
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    const uint4 e0 = tb[b0], e1 = tb[b1], e2 = tb[b2], e3 = tb[b3];
+    bool p0, p1, p2, p3;
+    int q0 = bucket_match(e0, k0, p0), q1 = bucket_match(e1, k1, p1), q2 = bucket_match(e2, k2, p2),
+        q3 = bucket_match(e3, k3, p3);
+    while (p0 | p1 | p2 | p3) {  // a full home bucket: rare
+        if (p0) { b0 = (b0 + 1) & (SLOTS / 4 - 1); q0 = bucket_match(tb[b0], k0, p0); }
+        if (p1) { b1 = (b1 + 1) & (SLOTS / 4 - 1); q1 = bucket_match(tb[b1], k1, p1); }
+        if (p2) { b2 = (b2 + 1) & (SLOTS / 4 - 1); q2 = bucket_match(tb[b2], k2, p2); }
+        if (p3) { b3 = (b3 + 1) & (SLOTS / 4 - 1); q3 = bucket_match(tb[b3], k3, p3); }
     }
-    unsigned found = (e0 != EMPTY ? 1u : 0u) | (e1 != EMPTY ? 2u : 0u) | (e2 != EMPTY ? 4u : 0u) | (e3 != EMPTY ? 8u : 0u);
+    const unsigned h0 = b0 * 4 + (unsigned)q0, h1 = b1 * 4 + (unsigned)q1, h2 = b2 * 4 + (unsigned)q2,
+                   h3 = b3 * 4 + (unsigned)q3;
+    unsigned found = (q0 >= 0 ? 1u : 0u) | (q1 >= 0 ? 2u : 0u) | (q2 >= 0 ? 4u : 0u) | (q3 >= 0 ? 8u : 0u);
     unsigned m = 0;
     while (found) {
         const unsigned bit = found & (0u - found);
@@ -294,17 +320,21 @@ template <int SLOTS>
 __device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt, int *acc, const int4 w, unsigned vmask) {
     const unsigned k0 = (vmask & 1u) ? (unsigned)w.x : NOKEY, k1 = (vmask & 2u) ? (unsigned)w.y : NOKEY,
                    k2 = (vmask & 4u) ? (unsigned)w.z : NOKEY, k3 = (vmask & 8u) ? (unsigned)w.w : NOKEY;
-    unsigned h0 = hash_slot<SLOTS>(k0), h1 = hash_slot<SLOTS>(k1), h2 = hash_slot<SLOTS>(k2), h3 = hash_slot<SLOTS>(k3);
-    unsigned e0 = tab[h0], e1 = tab[h1], e2 = tab[h2], e3 = tab[h3];
-    bool p0 = e0 != EMPTY && e0 != k0, p1 = e1 != EMPTY && e1 != k1, p2 = e2 != EMPTY && e2 != k2,
-         p3 = e3 != EMPTY && e3 != k3;
-    while (p0 | p1 | p2 | p3) {
-        if (p0) { h0 = (h0 + 1) & (SLOTS - 1); e0 = tab[h0]; p0 = e0 != EMPTY && e0 != k0; }
-        if (p1) { h1 = (h1 + 1) & (SLOTS - 1); e1 = tab[h1]; p1 = e1 != EMPTY && e1 != k1; }
-        if (p2) { h2 = (h2 + 1) & (SLOTS - 1); e2 = tab[h2]; p2 = e2 != EMPTY && e2 != k2; }
-        if (p3) { h3 = (h3 + 1) & (SLOTS - 1); e3 = tab[h3]; p3 = e3 != EMPTY && e3 != k3; }
+    unsigned b0 = hash_bucket<SLOTS>(k0), b1 = hash_bucket<SLOTS>(k1), b2 = hash_bucket<SLOTS>(k2), b3 = hash_bucket<SLOTS>(k3);
+    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
+    const uint4 e0 = tb[b0], e1 = tb[b1], e2 = tb[b2], e3 = tb[b3];
+    bool p0, p1, p2, p3;
+    int q0 = bucket_match(e0, k0, p0), q1 = bucket_match(e1, k1, p1), q2 = bucket_match(e2, k2, p2),
+        q3 = bucket_match(e3, k3, p3);
+    while (p0 | p1 | p2 | p3) {  // a full home bucket: rare
+        if (p0) { b0 = (b0 + 1) & (SLOTS / 4 - 1); q0 = bucket_match(tb[b0], k0, p0); }
+        if (p1) { b1 = (b1 + 1) & (SLOTS / 4 - 1); q1 = bucket_match(tb[b1], k1, p1); }
+        if (p2) { b2 = (b2 + 1) & (SLOTS / 4 - 1); q2 = bucket_match(tb[b2], k2, p2); }
+        if (p3) { b3 = (b3 + 1) & (SLOTS / 4 - 1); q3 = bucket_match(tb[b3], k3, p3); }
     }
-    unsigned found = (e0 != EMPTY ? 1u : 0u) | (e1 != EMPTY ? 2u : 0u) | (e2 != EMPTY ? 4u : 0u) | (e3 != EMPTY ? 8u : 0u);
+    const unsigned h0 = b0 * 4 + (unsigned)q0, h1 = b1 * 4 + (unsigned)q1, h2 = b2 * 4 + (unsigned)q2,
+                   h3 = b3 * 4 + (unsigned)q3;
+    unsigned found = (q0 >= 0 ? 1u : 0u) | (q1 >= 0 ? 2u : 0u) | (q2 >= 0 ? 4u : 0u) | (q3 >= 0 ? 8u : 0u);
     unsigned m = 0;
     while (found) {
         const unsigned bit = found & (0u - found);
