@@ -352,8 +352,12 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_HIP(hipEventCreate(&g->ev0));
     DCR_HIP(hipEventCreate(&g->ev1));
     DCR_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    // side[2] carries the finest-grained kernel of a pass (the smallest degree class): lowest priority, so that the
+    // kernels with long units get their workgroups resident first and the fine-grained one fills in and finishes last
+    int prio_low = 0, prio_high = 0;
+    DCR_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
     for (int b = 0; b < NBINS - 1; ++b) {
-        DCR_HIP(hipStreamCreateWithFlags(&g->side[b], hipStreamNonBlocking));
+        DCR_HIP(hipStreamCreateWithPriority(&g->side[b], hipStreamNonBlocking, b == 2 ? prio_low : prio_high));
         DCR_HIP(hipEventCreateWithFlags(&g->ev_join[b], hipEventDisableTiming));
     }
     DCR_TRY(dev_alloc(&g->rowinfo, n));
