@@ -61,6 +61,45 @@ def choice_index(p):
     return lo
 
 
+_cdf_scratch = np.empty(0, dtype=np.float64)
+
+
+def draw_index(improvements, tau):
+    """Index drawn by ``np.random.choice(n, p=softmax(improvements, tau))`` (sdrf_no_cuda.py:49-50) for finite tau, with
+    the same consumption of the legacy global stream.  ``exp`` and the pairwise ``sum`` are numpy's own (their rounding
+    is part of the bit-exact contract); the division and the sequential cumsum run fused in the library's host helper
+    ``dcr_host_cdf_from_exp`` with numpy's operations in numpy's order; validation, the one uniform and the search follow
+    ``RandomState.choice``.  Pinned against numpy in tests/test_host_cpu.py."""
+    global _cdf_scratch
+    import ctypes
+    from dcr import _lib
+    exp_a = np.exp(np.asarray(improvements, dtype=np.float64) * tau)
+    s = exp_a.sum()
+    if not np.isfinite(s) or s == 0.0:
+        return choice_index(exp_a / s)  # overflow / all-zero: numpy's own NaN pattern and error (utils/softmax.py:9-10)
+    n = exp_a.shape[0]
+    if _cdf_scratch.shape[0] < n:
+        _cdf_scratch = np.empty(n + n // 4 + 64, dtype=np.float64)
+    cdf = _cdf_scratch
+    total = ctypes.c_double()
+    _lib.check(_lib.lib().dcr_host_cdf_from_exp(exp_a.ctypes.data_as(_lib._f64p), n, float(s),
+                                                cdf.ctypes.data_as(_lib._f64p), ctypes.byref(total)))
+    t = total.value
+    if np.isnan(t):
+        raise ValueError('probabilities contain NaN')
+    if abs(t - 1.0) > _ATOL:
+        raise ValueError('probabilities do not sum to 1')
+    u = np.random.random_sample()
+    lo, hi = 0, n
+    while lo < hi:  # searchsorted(cdf / t, u, side='right'); x -> x / t is monotone in floating point
+        mid = (lo + hi) >> 1
+        if cdf[mid] / t > u:
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
+
+
 class SdrfRun:
     """One SDRF rewiring run, steppable: ``step()`` is one iteration of the loop body
     sdrf_no_cuda.py:22-66 and returns False when the reference loop would ``break``."""
@@ -104,7 +143,8 @@ class SdrfRun:
             imp, ci, cj = G.improvements(x, y, curv_type, want_candidates=want_trace)
             n_cand = imp.shape[0]
             if n_cand:
-                idx = choice_index(softmax(np.array(imp), tau=tau))
+                # tau = inf (only reached here when tracing): softmax is the one-hot special case of utils/softmax.py:5-8
+                idx = draw_index(imp, tau) if np.isfinite(tau) else choice_index(softmax(np.array(imp), tau=tau))
                 if want_trace:
                     k, l = int(ci[idx]), int(cj[idx])
                     rec['candidates'] = np.stack([ci, cj], 1).tolist()

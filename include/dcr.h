@@ -123,6 +123,13 @@ int dcr_profile_read(dcr_graph *g, double *pass_ms_total, int64_t *pass_count);
 /* SURVEY §8(d) algorithmic bytes of one BFC pass on the current graph. */
 int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes);
 
+/* ---- host helper for np.random.choice(n, p=softmax(a, tau)) — sdrf_no_cuda.py:49-50, utils/softmax.py:9-10
+ * Given e = exp(a * tau) and its sum S (both computed by the caller's numpy: their rounding is part of the bit-exact
+ * contract), fill cdf[i] = the SEQUENTIAL float64 running sum of p_i = e_i / S, i.e. numpy.cumsum(e / S), in one fused
+ * pass with numpy's operations in numpy's order, and return cdf[n-1].  The caller validates the total, draws ONE uniform
+ * from the legacy stream and bisects cdf / total exactly as RandomState.choice does.  Plain host code, no GPU. */
+int dcr_host_cdf_from_exp(const double *e, int64_t n, double S, double *out_cdf, double *out_total);
+
 /* ---- GCN aggregation (device pointers, caller's stream) --------------------
  * Replaces the propagate/scatter step of torch_geometric GCNConv (third-party,
  * call site models/gcn.py:36): C[i,:] = (bias ? bias : 0) + sum_e val[e] * B[col[e],:]

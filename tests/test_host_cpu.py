@@ -120,3 +120,23 @@ def test_choice_index_matches_numpy_choice():
         choice_index(bad)
     with pytest.raises(ValueError):
         np.random.choice(3, p=bad)
+
+
+def test_draw_index_matches_numpy_choice():
+    """The fused host draw (exp and sum by numpy, divide + sequential cumsum in the library's host helper) returns
+    numpy's index and leaves numpy's stream in numpy's state, for vectors like the improvement vectors of a run."""
+    from rewiring.sdrf_no_cuda import draw_index
+    from utils.softmax import softmax
+    rng = np.random.Generator(np.random.PCG64(8))
+    for n, tau in ((1, 3.0), (7, 163.0), (1000, 50.0), (185000, 163.0), (4096, 0.5)):
+        a = rng.choice(np.array([0.0, 1e-3, -2e-3, 0.0125, 0.0, 0.004]), size=n) + (rng.random(n) < 0.01) * rng.random(n) * 0.05
+        for seed in (0, 1, 2):
+            np.random.seed(seed)
+            want = int(np.random.choice(n, p=softmax(a, tau)))
+            state_want = np.random.get_state()[1].copy(), np.random.get_state()[2]
+            np.random.seed(seed)
+            got = draw_index(a, tau)
+            state_got = np.random.get_state()[1], np.random.get_state()[2]
+            assert got == want and state_got[1] == state_want[1] and np.array_equal(state_got[0], state_want[0])
+    with pytest.raises(ValueError):
+        draw_index(np.array([800.0, 1.0]), 163.0)      # exp overflows: numpy's NaN error, stream untouched
