@@ -714,13 +714,23 @@ using namespace dcr;
 
 extern "C" {
 
-static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental);
+static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental, bool with_argmin = false);
 
 int dcr_curvature_pass(dcr_graph *g, int curv_type) { return curvature_pass_impl(g, curv_type, false); }
 
 int dcr_curvature_pass_incremental(dcr_graph *g, int curv_type) { return curvature_pass_impl(g, curv_type, true); }
 
-static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental) {
+int dcr_curvature_pass_argmin(dcr_graph *g, int curv_type, int incremental, int32_t *out_u, int32_t *out_v,
+                              double *out_val) {
+    DCR_TRY(curvature_pass_impl(g, curv_type, incremental != 0, true));
+    if (g->hres->ext_slot < 0) DCR_FAIL(DCR_ENOTFOUND, "graph has no edges");
+    if (out_u) *out_u = g->hres->ext_u;
+    if (out_v) *out_v = g->hres->ext_v;
+    if (out_val) *out_val = g->hres->ext_val;
+    return DCR_OK;
+}
+
+static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental, bool with_argmin) {
     if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
     DCR_HIP(hipSetDevice(g->device));
@@ -732,6 +742,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
     g->dirty_tracked = true;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
+    if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));  // first minimum in G.edges order, same host sync
     DCR_TRY(sync_result(g));
     if (g->profile) {
         float ms = 0.f;

@@ -159,6 +159,9 @@ void launch_add_edge(dcr_graph *g, int32_t u, int32_t v);          // u < 0: no-
 void launch_remove_if_above(dcr_graph *g, double bound);           // acts on the last argext result
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v);         // flag {u,v} ∪ N(u) ∪ N(v)
 
+// dcr_sdrf.hip
+int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v);  // result in DevResult after the next sync
+
 // dcr_bfc.hip
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental);
 // dcr_bfc_nc.hip

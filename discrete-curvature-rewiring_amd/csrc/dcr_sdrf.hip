@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int np
 
 constexpr int ARGEXT_BLOCKS = 1024;
 
-static int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
+int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
     if (!g->red_scratch) {
         Ext *p = nullptr;
         DCR_TRY(dev_alloc(&p, ARGEXT_BLOCKS));

@@ -36,6 +36,7 @@ SIGNATURES = {
     'dcr_graph_export_edge_index': (ctypes.c_int, [_vp, _i64p]),
     'dcr_curvature_pass': (ctypes.c_int, [_vp, ctypes.c_int]),
     'dcr_curvature_pass_incremental': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'dcr_curvature_pass_argmin': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _i32p, _i32p, _f64p]),
     'dcr_curvature_read': (ctypes.c_int, [_vp, _f64p, _i32p, _i32p]),
     'dcr_curvature_edge': (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_int, _f64p]),
     'dcr_bfc_ingredients': (ctypes.c_int, [_vp, _i32, _i32, _i64p]),

@@ -122,6 +122,13 @@ class DcrGraph:
         fn = lib().dcr_curvature_pass_incremental if incremental else lib().dcr_curvature_pass
         check(fn(self._h, curv_code(curv_type)))
 
+    def curvature_pass_argmin(self, curv_type='bfc', incremental=False):
+        """One pass, then the first minimum in ``G.edges`` order: (u, v, value), one host synchronisation."""
+        u, v, val = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        check(lib().dcr_curvature_pass_argmin(self._h, curv_code(curv_type), int(bool(incremental)), ctypes.byref(u),
+                                              ctypes.byref(v), ctypes.byref(val)))
+        return u.value, v.value, val.value
+
     def curvature_read(self):
         ne = self.number_of_edges()
         cv = np.empty(ne, dtype=np.float64)

@@ -121,11 +121,9 @@ class SdrfRun:
         G, curv_type, tau, trace = self.G, self.curv_type, self.tau, self.trace
         want_trace = trace is not None
         can_add = True
-        G.curvature_pass(curv_type, incremental=self.incremental)
-
-        # Choose the edge with the lowest curvature (first minimum in G.edges order).
+        # Full curvature pass, then the edge with the lowest curvature (first minimum in G.edges order).
         try:
-            x, y, _ = G.argext(False)
+            x, y, _ = G.curvature_pass_argmin(curv_type, incremental=self.incremental)
         except KeyError:
             raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
         rec = {'argmin': [x, y]} if want_trace else None

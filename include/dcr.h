@@ -83,6 +83,9 @@ int dcr_curvature_pass(dcr_graph *g, int curv_type);
  * through this API is tracked).  Falls back to a full pass when there is no complete buffer to build on.  The
  * reference recomputes everything each iteration (sdrf_no_cuda.py:24); this is an optional mode. */
 int dcr_curvature_pass_incremental(dcr_graph *g, int curv_type);
+/* A pass followed by min(G.edges, key=curvature) — sdrf_no_cuda.py:24 and :27 — with one host synchronisation. */
+int dcr_curvature_pass_argmin(dcr_graph *g, int curv_type, int incremental, int32_t *out_u, int32_t *out_v,
+                              double *out_val);
 /* Copy the last pass out in G.edges order (float64 per undirected edge). */
 int dcr_curvature_read(dcr_graph *g, double *out_curv, int32_t *out_u, int32_t *out_v);
 /* bfc_edge(G, v1, v2), bfc_naive.py:7-40 / compute_curvature_edge, classical_curvatures.py:6 */
