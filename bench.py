@@ -274,12 +274,12 @@ def main():
                          'kernel': 'curvature pass = k_nc_plan + k_nc_wave<256|512> + k_nc_block<2048|8192>',
                          'algorithmic_bytes_per_launch': alg_bytes, 'launch_ms': pass_ms, 'launches': pass_count},
         }
-        pmc = os.path.join(REPO, 'profiles', 'r01_v5_pmc_traffic.json')
+        pmc = os.path.join(REPO, 'profiles', 'r01_v6_pmc_traffic.json')
         if os.path.exists(pmc) and args.nodes == 100000 and args.m == 10:
             # HBM-side bytes per pass from a separate rocprofv3 --pmc run (counters cannot be read in-process)
             with open(pmc) as f:
                 out['roofline']['traffic'] = json.load(f)['traffic_bytes_per_pass']
-            out['roofline']['traffic_source'] = 'profiles/r01_v5_pmc_traffic.json'
+            out['roofline']['traffic_source'] = 'profiles/r01_v6_pmc_traffic.json'
             out['roofline']['note'] = ('algorithmic bytes follow SURVEY 8(d), which charges both sides of the 4-cycle '
                                        'count; the kernels stream one side only, see traffic and DESIGN.md 4.1')
         ref_fix = os.path.join(REPO, 'tests', 'golden', 'reference_timing_s100k.json')
