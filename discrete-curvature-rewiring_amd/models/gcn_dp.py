@@ -8,6 +8,9 @@ its nodes (all columns); the weights are replicated.  Per layer:
     Z   = all_gather(Z_p)               the one exchange step of the layer      [backward: reduce_scatter]
     out = Â_p · Z + b                   local HIP SpMM (csrc/dcr_gcn.hip)        [backward: Â_pᵀ · d_out]
 
+The first layer's input is the constant feature matrix, so (as in the single-GPU model) Â_p·X is computed once — one
+all-gather of X at set-up — and the layer is then a purely local GEMM: no exchange step at all for layer 1.
+
 After backward, the weight gradients (a few tens of kilofloats) are summed with ONE all-reduce over a flat buffer:
 the message is latency-bound, so one call beats one per parameter.  The loss is the masked NLL summed locally and
 divided by the global number of training nodes, so the summed gradients equal the single-GPU gradients.
@@ -78,12 +81,28 @@ class ShardedGCN(torch.nn.Module):
         h = x_local
         layers = self.gcn.layers
         for i, layer in enumerate(layers):
+            if i == 0 and layer.propagate_input_first and not h.requires_grad:
+                h = layer.lin(self.propagated_input_local(h), layer.bias)   # (Â_p·X)·Wᵀ + b, no exchange
+                if i + 1 < len(layers):
+                    h = self.gcn.dropout(self.gcn.act_fn(h))
+                continue
             z_local = layer.lin(h)
             z = _GatherRows.apply(z_local, self.n, self.per, self.group)
             h = aggregate(z, layer.bias, self.csr)
             if i + 1 < len(layers):
                 h = self.gcn.dropout(self.gcn.act_fn(h))
         return torch.nn.functional.log_softmax(h, dim=1)
+
+    def propagated_input_local(self, x_local):
+        """Rows of Â·X owned by this rank, computed once per (x_local, graph): all-gather X, one local SpMM."""
+        key = (x_local.data_ptr(), x_local._version, tuple(x_local.shape))
+        if key != getattr(self, '_ax_key', None):
+            with torch.no_grad():
+                x_full = _GatherRows.apply(x_local.contiguous(), self.n, self.per, self.group)
+                from models.gcn import spmm
+                self._ax = spmm(self.csr.rowptr, self.csr.col, self.csr.val, x_full.contiguous(), self.csr.n_rows)
+            self._ax_key = key
+        return self._ax
 
     def allreduce_grads(self):
         params = [p for p in self.gcn.parameters() if p.grad is not None]
