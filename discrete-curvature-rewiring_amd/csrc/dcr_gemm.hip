@@ -88,13 +88,27 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_atb_partial(const float *__r
         }
 }
 
+// Sum of the K-slabs' partial tiles in slab order.  64 outputs x 4 slab groups per workgroup: thread (e, zg) adds slabs
+// zg, zg + 4, ... (four loads in flight), the four group sums are then added in group order: deterministic, and four
+// times the memory-level parallelism of one thread per output.
 __global__ void __launch_bounds__(256) k_atb_reduce(const float *__restrict__ part, float *__restrict__ C, int64_t mn,
                                                      int N, int64_t ldc, int splits) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= mn) return;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(int64_t)z * mn + i];  // slab order: deterministic
-    C[(i / N) * ldc + (i % N)] = s;
+    if (i < mn) {
+        int z = zg;
+        for (; z + 12 < splits; z += 16) {
+            const float a = part[(int64_t)z * mn + i], b = part[(int64_t)(z + 4) * mn + i],
+                        c = part[(int64_t)(z + 8) * mn + i], d = part[(int64_t)(z + 12) * mn + i];
+            s += a; s += b; s += c; s += d;
+        }
+        for (; z < splits; z += 4) s += part[(int64_t)z * mn + i];
+    }
+    red[zg][e] = s;
+    __syncthreads();
+    if (zg == 0 && i < mn) C[(i / N) * ldc + (i % N)] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
 struct AtbPlan {
@@ -156,7 +170,7 @@ extern "C" int dcr_atb_f32_dev(const float *A, const float *B, float *C, int64_t
         hipLaunchKernelGGL((k_atb_partial<1, 1, 1, 4>), grid, dim3(256), 0, st, A, B, workspace, K, (int)M, (int)N, lda, ldb,
                            p.k_chunk);
     const int64_t mn = M * N;
-    hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, workspace, C, mn, (int)N, ldc,
+    hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, st, workspace, C, mn, (int)N, ldc,
                        p.splits);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
