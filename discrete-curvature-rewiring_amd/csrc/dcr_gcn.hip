@@ -9,23 +9,23 @@
 
 namespace dcr {
 
-// accumulate non-zeros e0, e0 + stride, ... < e1 of one row into acc (four gathers of B in flight)
-template <int VEC>
+// accumulate non-zeros e0, e0 + stride, ... < e1 of one row into acc (U gathers of B in flight)
+template <int VEC, int U>
 __device__ inline void spmm_accumulate(const int32_t *__restrict__ col, const float *__restrict__ val,
                                        const float *__restrict__ B, int64_t ldb, int f0, int64_t e0, int64_t e1,
                                        int64_t stride, float (&acc)[VEC]) {
     int64_t e = e0;
-    for (; e + 3 * stride < e1; e += 4 * stride) {
-        int c[4];
-        float w[4];
-        float b[4][VEC];
+    for (; e + (U - 1) * stride < e1; e += U * stride) {
+        int c[U];
+        float w[U];
+        float b[U][VEC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             c[u] = col[e + u * stride];
             w[u] = val[e + u * stride];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const float *src = B + (int64_t)c[u] * ldb + f0;
             if (VEC == 4) {
                 const float4 t = *reinterpret_cast<const float4 *>(src);
@@ -38,7 +38,7 @@ __device__ inline void spmm_accumulate(const int32_t *__restrict__ col, const fl
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w[u], b[u][q], acc[q]);
     }
@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
                                                    int64_t ldc, const float *__restrict__ bias, int relu) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     constexpr int G = ROWS_PER_BLOCK;        // lane groups per workgroup
+    constexpr int U = LPR <= 8 ? 8 : 4;      // narrow rows of B: more gathers in flight per group
     __shared__ int long_rows[ROWS_PER_BLOCK];
     __shared__ int n_long;
     __shared__ float red[256 * VEC];
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
                 float acc[VEC];
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-                spmm_accumulate<VEC>(col, val, B, ldb, f0, e0, e1, 1, acc);
+                spmm_accumulate<VEC, U>(col, val, B, ldb, f0, e0, e1, 1, acc);
                 float *dst = C + row * ldc + f0;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
             float acc[VEC];
 #pragma unroll
             for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-            if (f0 < n_feat) spmm_accumulate<VEC>(col, val, B, ldb, f0, e0 + sub, e1, G, acc);
+            if (f0 < n_feat) spmm_accumulate<VEC, U>(col, val, B, ldb, f0, e0 + sub, e1, G, acc);
 #pragma unroll
             for (int q = 0; q < VEC; ++q) red[threadIdx.x * VEC + q] = acc[q];
             __syncthreads();
