@@ -4,21 +4,25 @@
 // bfc_naive.bfc_edge (curvature/bfc_naive.py:7-40) or compute_curvature_edge (classical_curvatures.py:14-28).
 //
 // Every undirected edge {u,v} is owned by its higher-degree endpoint u (ties: smaller id).  The neighbour set N(u) is
-// staged ONCE as a hash set in LDS and reused for all edges u owns; per edge one wave then only has to
+// staged ONCE as a hash set of 4-slot buckets in LDS and reused for all edges u owns; per edge one wave (or a quarter /
+// half of one: up to four edges of the same owner are processed side by side) then only has to
 //   1. look the members of N(v) up in that set: hits are the triangles T (bfc_naive.py:25) and get a per-edge flag,
 //      misses are DY = N(v) \ N(u) \ {u};
-//   2. stream the rows of the members of DY from HBM (aligned 16-byte pieces; short rows by 4-lane groups, long rows
-//      by the whole wave) and probe every entry against the set: an unflagged hit z is a 4-cycle u-z-w-v.  The hits
-//      of one row are |N(w) ∩ DX| (ballot + popcount), and every hit bumps a 15-bit counter on z's table slot, which
-//      after the sweep is |N(z) ∩ DY|.  sq1, sq2 and gamma (bfc_naive.py:26-29,36-37) are degree statistics of that
-//      one bipartite graph between DX = N(u) \ N(v) \ {v} and DY, so nothing else has to be read;
-//   3. keep the integers (T, |sq1|, |sq2|, gamma) in the lane that stands for the edge; after up to 64 edges all
-//      lanes evaluate the float64 closing expression together (bfc_naive.py:31-40, reference operation order).
+//   2. stream the rows of the members of DY from HBM.  Their aligned 16-byte pieces form one flat list that the 64
+//      lanes share evenly whatever the row lengths (four loads in flight per lane); every entry is probed against the
+//      set: an unflagged hit z is a 4-cycle u-z-w-v.  The hits of one row are |N(w) ∩ DX| (an LDS counter per row), and
+//      every hit bumps a 15-bit counter on z's table slot, which after the sweep is |N(z) ∩ DY|.  sq1, sq2 and gamma
+//      (bfc_naive.py:26-29,36-37) are degree statistics of that one bipartite graph between DX = N(u) \ N(v) \ {v}
+//      and DY, so nothing else has to be read;
+//   3. park the integers (T, |sq1|, |sq2|, gamma) per position of the unit; after its (up to 16) edges the lanes that
+//      stand for them evaluate the float64 closing expression together (bfc_naive.py:31-40, reference operation order).
 // Compared with the edge-centric kernels in dcr_bfc.hip there is no per-edge table build, no sizing of both sides,
 // no descriptor list of the unstreamed side, no final table scan and, for hubs, no workgroup barrier per edge.
 //
-// Nodes are grouped by degree: up to 254 neighbours a wave owns a node and its private table ("wave classes");
-// above, a workgroup builds one table and each wave takes a 64-neighbour chunk of the row ("block classes").
+// Work units are 16 (4 for hubs) positions of a row, strided over the row; nodes are grouped by degree: up to 254
+// neighbours a wave owns a unit and its private table ("wave classes"), above that a workgroup builds one table and each
+// of its waves takes a unit ("block classes").  A two-phase plan lays the units out heaviest first; persistent waves
+// pull them from eight cursors.  DESIGN.md §4.1 has the measurements behind each of these choices.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
