@@ -280,6 +280,8 @@ def main():
             with open(pmc) as f:
                 out['roofline']['traffic'] = json.load(f)['traffic_bytes_per_pass']
             out['roofline']['traffic_source'] = 'profiles/r01_v6_pmc_traffic.json'
+            # what the fabric actually moved per pass (separate PMC run) over this run's pass time, as a share of peak
+            out['roofline']['traffic_frac'] = out['roofline']['traffic'] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
             out['roofline']['note'] = ('algorithmic bytes follow SURVEY 8(d), which charges both sides of the 4-cycle '
                                        'count; the kernels stream one side only, see traffic and DESIGN.md 4.1')
         ref_fix = os.path.join(REPO, 'tests', 'golden', 'reference_timing_s100k.json')
