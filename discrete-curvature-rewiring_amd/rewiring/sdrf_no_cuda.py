@@ -5,10 +5,10 @@ Same signature, same loop, same results (edge list bit-identical for a given
 
   reference line                       here
   :20  to_networkx                     DcrGraph.from_data  (HBM-resident rows, insertion order)
-  :24  compute_curvature_graph         G.curvature_pass    (csrc/dcr_bfc.hip)
-  :27  min(G.edges, key=...)           G.argext(False)     (wavefront reduction, first minimum)
+  :24  compute_curvature_graph  \       G.curvature_pass_argmin   (csrc/dcr_bfc_nc.hip; wavefront reduction for
+  :27  min(G.edges, key=...)    /                                  the first minimum; one host sync for both)
   :29-46 candidates + improvements     G.improvements      (csrc/dcr_sdrf.hip)
-  :49-50 softmax + np.random.choice    host numpy, unchanged (bit-exact draw)
+  :49-50 softmax + np.random.choice    draw_index: numpy's exp and sum, the rest fused on the host (bit-exact draw)
   :51,57-66 add / stale arg-max / remove   G.sdrf_tail     (one fused device step)
   :68  from_networkx                   G.to_edge_index
 
