@@ -724,6 +724,11 @@ int dcr_curvature_pass_argmin(dcr_graph *g, int curv_type, int incremental, int3
                               double *out_val) {
     DCR_TRY(curvature_pass_impl(g, curv_type, incremental != 0, true));
     if (g->hres->ext_slot < 0) DCR_FAIL(DCR_ENOTFOUND, "graph has no edges");
+    g->am_x = g->hres->ext_u;
+    g->am_y = g->hres->ext_v;
+    g->am_dx = g->hres->ext_du;
+    g->am_dy = g->hres->ext_dv;
+    g->am_valid = true;
     if (out_u) *out_u = g->hres->ext_u;
     if (out_v) *out_v = g->hres->ext_v;
     if (out_val) *out_val = g->hres->ext_val;

@@ -46,6 +46,7 @@ struct DevResult {
     double ext_val;       // argext value
     int32_t ext_slot;     // argext slot (-1: none)
     int32_t ext_u, ext_v;
+    int32_t ext_du, ext_dv;  // their degrees (saves dcr_improvements a round trip)
     int32_t add_status;   // 0 ok, 1 row overflow (nothing changed), 2 already present
     int32_t removed_u, removed_v;
     int32_t overflow_row;
@@ -89,6 +90,10 @@ struct dcr_graph {
     int32_t *col = nullptr;      // [cap_total] neighbour ids
     int32_t *slot_row = nullptr; // [cap_total] owning row of each slot
     double *curv = nullptr;      // [cap_total] curvature of the undirected edge stored at slot (col > row)
+
+    // degrees of the last arg-min edge as seen by the device; dropped by any edit
+    int32_t am_x = -1, am_y = -1, am_dx = 0, am_dy = 0;
+    bool am_valid = false;
 
     int curv_type_last = -1;
     bool curv_valid = false;

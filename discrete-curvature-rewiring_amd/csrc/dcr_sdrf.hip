@@ -119,6 +119,8 @@ __global__ void __launch_bounds__(256) k_argext_final(RowView g, const Ext *part
         res->ext_slot = best.slot;
         res->ext_u = best.slot >= 0 ? g.slot_row[best.slot] : -1;
         res->ext_v = best.slot >= 0 ? g.col[best.slot] : -1;
+        res->ext_du = best.slot >= 0 ? g.rowinfo[res->ext_u].y : 0;
+        res->ext_dv = best.slot >= 0 ? g.rowinfo[res->ext_v].y : 0;
     }
 }
 
@@ -657,11 +659,18 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
     DCR_HIP(hipSetDevice(g->device));
-    int2 rxy[2];
-    DCR_HIP(hipMemcpyAsync(&rxy[0], g->rowinfo + x, sizeof(int2), hipMemcpyDeviceToHost, g->stream));
-    DCR_HIP(hipMemcpyAsync(&rxy[1], g->rowinfo + y, sizeof(int2), hipMemcpyDeviceToHost, g->stream));
-    DCR_HIP(hipStreamSynchronize(g->stream));
-    const int dx = rxy[0].y, dy = rxy[1].y;
+    int dx, dy;
+    if (g->am_valid && g->am_x == x && g->am_y == y) {  // the arg-min step already brought the degrees over
+        dx = g->am_dx;
+        dy = g->am_dy;
+    } else {
+        int2 rxy[2];
+        DCR_HIP(hipMemcpyAsync(&rxy[0], g->rowinfo + x, sizeof(int2), hipMemcpyDeviceToHost, g->stream));
+        DCR_HIP(hipMemcpyAsync(&rxy[1], g->rowinfo + y, sizeof(int2), hipMemcpyDeviceToHost, g->stream));
+        DCR_HIP(hipStreamSynchronize(g->stream));
+        dx = rxy[0].y;
+        dy = rxy[1].y;
+    }
     const int64_t keys = (int64_t)dx + dy;
     int64_t ts = 64;
     while (ts < 4 * keys) ts <<= 1;
@@ -744,25 +753,27 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     hipLaunchKernelGGL(k_imp_emit, dim3(rows), dim3(256), 0, g->stream, vw, B, x, y, words, curv_type, g->imp_out,
                        g->imp_ci, g->imp_cj);
     DCR_HIP(hipGetLastError());
-    DCR_TRY(sync_result(g));
-    const int64_t n = g->hres->n_cand;
-    g->imp_n = n;
-    *n_out = n;
-    if (n > 0 && out_improvement) {
-        DCR_TRY(pinned_regrow(&g->imp_out_h, &g->imp_out_h_cap, n));
-        DCR_HIP(hipMemcpyAsync(g->imp_out_h, g->imp_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, g->stream));
+    // one host sync: the result block and the values go out together; the candidate count is not known yet, so the
+    // copy is sized by its upper bound (dx+1)(dy+1), which the real count nearly reaches on a sparse graph
+    if (upper > 0 && out_improvement) {
+        DCR_TRY(pinned_regrow(&g->imp_out_h, &g->imp_out_h_cap, upper));
+        DCR_HIP(hipMemcpyAsync(g->imp_out_h, g->imp_out, sizeof(double) * (size_t)upper, hipMemcpyDeviceToHost, g->stream));
     }
-    if (n > 0 && want_candidates) {
-        if (n > g->imp_cand_h_cap) {
+    if (upper > 0 && want_candidates) {
+        if (upper > g->imp_cand_h_cap) {
             int64_t c1 = g->imp_cand_h_cap, c2 = g->imp_cand_h_cap;
-            DCR_TRY(pinned_regrow(&g->imp_ci_h, &c1, n));
-            DCR_TRY(pinned_regrow(&g->imp_cj_h, &c2, n));
+            DCR_TRY(pinned_regrow(&g->imp_ci_h, &c1, upper));
+            DCR_TRY(pinned_regrow(&g->imp_cj_h, &c2, upper));
             g->imp_cand_h_cap = c1 < c2 ? c1 : c2;
         }
-        DCR_HIP(hipMemcpyAsync(g->imp_ci_h, g->imp_ci, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, g->stream));
-        DCR_HIP(hipMemcpyAsync(g->imp_cj_h, g->imp_cj, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, g->stream));
+        DCR_HIP(hipMemcpyAsync(g->imp_ci_h, g->imp_ci, sizeof(int32_t) * (size_t)upper, hipMemcpyDeviceToHost, g->stream));
+        DCR_HIP(hipMemcpyAsync(g->imp_cj_h, g->imp_cj, sizeof(int32_t) * (size_t)upper, hipMemcpyDeviceToHost, g->stream));
     }
-    DCR_HIP(hipStreamSynchronize(g->stream));
+    DCR_TRY(sync_result(g));
+    const int64_t n = g->hres->n_cand;
+    if (n < 0 || n > upper) DCR_FAIL(DCR_ESTATE, "candidate count outside its bound");
+    g->imp_n = n;
+    *n_out = n;
     if (out_improvement) *out_improvement = n > 0 ? g->imp_out_h : nullptr;
     if (out_ci) *out_ci = (n > 0 && want_candidates) ? g->imp_ci_h : nullptr;
     if (out_cj) *out_cj = (n > 0 && want_candidates) ? g->imp_cj_h : nullptr;
@@ -813,6 +824,7 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
         }
     }
     DCR_HIP(hipSetDevice(g->device));
+    g->am_valid = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_add_edge(g, add_k, add_l);
         launch_mark_dirty(g, add_k, add_l);  // after the append: the new neighbours are flagged too
