@@ -74,6 +74,10 @@ __device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, int32_t u, int32_t 
 __global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *rowcap, int32_t *col, int32_t u,
                                                  int32_t v, DevResult *res) {
     int lane = threadIdx.x;
+    if (u == -2) {  // the pair picked on the device (dcr_sdrf_tail_at)
+        u = res->cand_i;
+        v = res->cand_j;
+    }
     if (u < 0) {  // nothing to add (no candidates this iteration)
         if (lane == 0) res->add_status = 0;
         return;
@@ -140,7 +144,11 @@ __device__ inline void dev_mark_dirty(const int2 *rowinfo, const int32_t *col, u
 }
 
 __global__ void __launch_bounds__(256) k_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u,
-                                                     int32_t v) {
+                                                     int32_t v, const DevResult *res) {
+    if (u == -2) {
+        u = res->cand_i;
+        v = res->cand_j;
+    }
     dev_mark_dirty(rowinfo, col, dirty, u, v, threadIdx.x, blockDim.x);
 }
 
@@ -197,8 +205,8 @@ void launch_remove_if_above(dcr_graph *g, double bound) {
 }
 
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v) {
-    if (u < 0 || v < 0) return;
-    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v);
+    if (u != -2 && (u < 0 || v < 0)) return;
+    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v, g->dres);
 }
 
 int sync_result(dcr_graph *g) {

@@ -84,8 +84,12 @@ __device__ inline Ext ext_block_reduce(Ext e, int want_max, Ext *sh) {
 }
 
 __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_total, const double *curv, int want_max,
-                                                       int excl_u, int excl_v, Ext *partial) {
+                                                       int excl_u, int excl_v, const DevResult *res, Ext *partial) {
     __shared__ Ext sh[4];
+    if (excl_u == -2) {  // the edge picked on the device (dcr_sdrf_tail_at)
+        excl_u = res->cand_i;
+        excl_v = res->cand_j;
+    }
     Ext best;
     best.val = 0.0;
     best.slot = -1;
@@ -165,7 +169,7 @@ int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
     if (blocks > ARGEXT_BLOCKS) blocks = ARGEXT_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_argext_edges, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->cap_total, g->curv,
-                       want_max, excl_u, excl_v, (Ext *)g->red_scratch);
+                       want_max, excl_u, excl_v, g->dres, (Ext *)g->red_scratch);
     hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, g->stream, vw, (const Ext *)g->red_scratch, (int)blocks,
                        want_max, g->dres);
     DCR_HIP(hipGetLastError());
@@ -628,6 +632,13 @@ static int pinned_regrow(T **p, int64_t *cap, int64_t need) {
     return DCR_OK;
 }
 
+// the candidate drawn on the host, by index: (k, l) never leaves the device (dcr_sdrf_tail_at)
+__global__ void k_pick_candidate(const int32_t *ci, const int32_t *cj, int64_t index, DevResult *res) {
+    const int32_t a = ci[index], b = cj[index];
+    res->cand_i = a < b ? a : b;
+    res->cand_j = a < b ? b : a;
+}
+
 }  // namespace dcr
 
 using namespace dcr;
@@ -811,10 +822,33 @@ int dcr_candidate_at(dcr_graph *g, int64_t index, int32_t *out_i, int32_t *out_j
     return DCR_OK;
 }
 
+static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
+                          int32_t out_removed[2], double *out_max_val);
+
+int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int32_t out_added[2],
+                     int32_t out_removed[2], double *out_max_val) {
+    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
+    if (cand_index < 0 || cand_index >= g->imp_n) DCR_FAIL(DCR_EINVAL, "candidate index out of range");
+    DCR_HIP(hipSetDevice(g->device));
+    hipLaunchKernelGGL(k_pick_candidate, dim3(1), dim3(1), 0, g->stream, g->imp_ci, g->imp_cj, cand_index, g->dres);
+    DCR_TRY(sdrf_tail_impl(g, -2, -2, do_remove, removal_bound, out_removed, out_max_val));
+    if (out_added) {
+        out_added[0] = g->hres->cand_i;
+        out_added[1] = g->hres->cand_j;
+    }
+    return DCR_OK;
+}
+
 int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
                   int32_t out_removed[2], double *out_max_val) {
+    return sdrf_tail_impl(g, add_k, add_l, do_remove, removal_bound, out_removed, out_max_val);
+}
+
+static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
+                          int32_t out_removed[2], double *out_max_val) {
     if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
     if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
+    const bool adding = add_k >= 0 || add_k == -2;  // -2: the pair k_pick_candidate left in the result block
     if (add_k >= 0) {
         if (add_l < 0 || add_k >= g->n || add_l >= g->n || add_k == add_l) DCR_FAIL(DCR_EINVAL, "bad edge to add");
         if (add_k > add_l) {
@@ -829,7 +863,7 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
         launch_add_edge(g, add_k, add_l);
         launch_mark_dirty(g, add_k, add_l);  // after the append: the new neighbours are flagged too
         if (do_remove) {
-            DCR_TRY(launch_argext(g, 1, add_k >= 0 ? add_k : -1, add_k >= 0 ? add_l : -1));
+            DCR_TRY(launch_argext(g, 1, adding ? add_k : -1, adding ? add_l : -1));
             launch_remove_if_above(g, removal_bound);
         }
         DCR_HIP(hipGetLastError());
@@ -838,7 +872,7 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
         if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
         DCR_TRY(relayout(g));
     }
-    if (add_k >= 0 && g->hres->add_status == 0) {
+    if (adding && g->hres->add_status == 0) {
         g->n_edges++;
         g->max_deg_bound++;
     }

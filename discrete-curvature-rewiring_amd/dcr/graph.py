@@ -202,6 +202,17 @@ class DcrGraph:
         rem = None if removed[0] < 0 else (removed[0], removed[1])
         return rem, mx.value
 
+    def sdrf_tail_at(self, cand_index, do_remove, removal_bound):
+        """``sdrf_tail`` with the edge to add given by its index in the last candidate list; returns
+        (added pair, removed pair or None, stale maximum)."""
+        added = (ctypes.c_int32 * 2)(-1, -1)
+        removed = (ctypes.c_int32 * 2)(-1, -1)
+        mx = ctypes.c_double()
+        check(lib().dcr_sdrf_tail_at(self._h, int(cand_index), int(bool(do_remove)), float(removal_bound), added, removed,
+                                     ctypes.byref(mx)))
+        rem = None if removed[0] < 0 else (removed[0], removed[1])
+        return (added[0], added[1]), rem, mx.value
+
     # ---- measurement hooks ------------------------------------------------------------
     def profile_reset(self):
         check(lib().dcr_profile_reset(self._h))

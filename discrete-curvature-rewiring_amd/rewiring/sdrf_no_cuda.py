@@ -128,7 +128,7 @@ class SdrfRun:
             raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
         rec = {'argmin': [x, y]} if want_trace else None
 
-        k = l = None
+        k = l = idx = None
         if tau == float('inf') and not want_trace:
             # softmax is one-hot at the first arg-max (utils/softmax.py:5-8): the draw is that
             # index whatever the uniform is; consume the one double np.random.choice would.
@@ -136,7 +136,6 @@ class SdrfRun:
             if n_cand:
                 idx = G.improvements_argmax()
                 np.random.random_sample()
-                k, l = G.candidate_at(idx)
         else:
             imp, ci, cj = G.improvements(x, y, curv_type, want_candidates=want_trace)
             n_cand = imp.shape[0]
@@ -144,12 +143,9 @@ class SdrfRun:
                 # tau = inf (only reached here when tracing): softmax is the one-hot special case of utils/softmax.py:5-8
                 idx = draw_index(imp, tau) if np.isfinite(tau) else choice_index(softmax(np.array(imp), tau=tau))
                 if want_trace:
-                    k, l = int(ci[idx]), int(cj[idx])
                     rec['candidates'] = np.stack([ci, cj], 1).tolist()
                     rec['improvements'] = imp.tolist()
                     rec['choice'] = idx
-                else:
-                    k, l = G.candidate_at(idx)
         if want_trace and not n_cand:
             rec.update(candidates=[], improvements=[], choice=None)
 
@@ -161,8 +157,12 @@ class SdrfRun:
                     trace.append(rec)
                 return False
 
-        # add (k, l); then the stale arg-max (excluding the new edge) is removed if above the bound
-        removed, _ = G.sdrf_tail((k, l) if n_cand else None, self.remove_edges, self.removal_bound)
+        # add candidate idx = (k, l), looked up on the device; then the stale arg-max (excluding the new edge) is
+        # removed if above the bound
+        if n_cand:
+            (k, l), removed, _ = G.sdrf_tail_at(idx, self.remove_edges, self.removal_bound)
+        else:
+            removed, _ = G.sdrf_tail(None, self.remove_edges, self.removal_bound)
         if want_trace:
             rec['added'] = [k, l] if n_cand else None
             rec['removed'] = list(removed) if removed else None

@@ -118,6 +118,10 @@ int dcr_candidate_at(dcr_graph *g, int64_t index, int32_t *out_i, int32_t *out_j
  * the maximum examined. */
 int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
                   int32_t out_removed[2], double *out_max_val);
+/* The same with the edge to add given as an index into the candidate list of the last dcr_improvements call (the
+ * index np.random.choice returned, sdrf_no_cuda.py:49-51): the pair is looked up on the device, out_added receives it. */
+int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int32_t out_added[2],
+                     int32_t out_removed[2], double *out_max_val);
 
 /* Timing hooks for bench.py: accumulated device time (HIP events on the
  * handle's stream) of the curvature-pass kernels since the last reset. */
