@@ -176,3 +176,133 @@ extern "C" int dcr_spmm_csr_f32_dev(const int64_t *rowptr, const int32_t *col, c
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ReLU + dropout between the GCN layers (models/gcn.py:38-42: x = act_fn(x); x = dropout(x)) as ONE pass over the
+// activations in each direction, with the keep mask packed to one bit per element: forward reads x, writes y and the
+// bits (N*F/8 bytes); backward reads the gradient and the bits.  The stock path is four element-wise kernels and a
+// byte mask (4.9 GB of traffic per training step at 1M x 128; this is 2.1 GB).  Random numbers: Philox-4x32-10 keyed by
+// (seed, call offset), counter = element-quad index, so a run is reproducible for a given torch seed.
+namespace dcr {
+
+__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__device__ inline void philox4x32_10(uint64_t index, uint64_t offset, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = c[j];
+}
+
+// thread t owns elements 4t .. 4t+3; wave w stores the four keep-ballots of its 256 elements in bits[4w .. 4w+3]
+__global__ void __launch_bounds__(256) k_relu_dropout_fwd(const float *__restrict__ x, float *__restrict__ y,
+                                                           unsigned long long *__restrict__ bits, int64_t n, float scale,
+                                                           uint32_t threshold, uint64_t seed, uint64_t offset) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e0 = t * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e0 + 3 < n) {
+        const float4 q = *reinterpret_cast<const float4 *>(x + e0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (e0 + j < n) v[j] = x[e0 + j];
+    }
+    uint32_t r[4];
+    philox4x32_10((uint64_t)t, offset, seed, r);
+    bool keep[4];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        keep[j] = v[j] > 0.f && r[j] >= threshold;  // P(r >= threshold) = 1 - p
+        o[j] = keep[j] ? v[j] * scale : 0.f;
+    }
+    if (e0 + 3 < n) {
+        *reinterpret_cast<float4 *>(y + e0) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (e0 + j < n) y[e0 + j] = o[j];
+    }
+    const int64_t wave = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long m = __ballot(keep[j]);
+        if ((threadIdx.x & 63) == 0) bits[wave * 4 + j] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_relu_dropout_bwd(const float *__restrict__ g, float *__restrict__ gin,
+                                                           const unsigned long long *__restrict__ bits, int64_t n,
+                                                           float scale) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e0 = t * 4;
+    if (e0 >= n) return;
+    const int64_t wave = t >> 6;
+    const int lane = threadIdx.x & 63;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e0 + 3 < n) {
+        const float4 q = *reinterpret_cast<const float4 *>(g + e0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (e0 + j < n) v[j] = g[e0 + j];
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ((bits[wave * 4 + j] >> lane) & 1ull) ? v[j] * scale : 0.f;
+    if (e0 + 3 < n) {
+        *reinterpret_cast<float4 *>(gin + e0) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (e0 + j < n) gin[e0 + j] = o[j];
+    }
+}
+
+}  // namespace dcr
+
+extern "C" int dcr_relu_dropout_bits_words(int64_t n, int64_t *out_words) {
+    if (!out_words || n < 0) DCR_FAIL(DCR_EINVAL, "bad argument");
+    const int64_t threads = (n + 3) / 4, blocks = (threads + 255) / 256;
+    *out_words = blocks * 4 * 4;  // 4 waves per workgroup, 4 ballots per wave
+    return DCR_OK;
+}
+
+extern "C" int dcr_relu_dropout_fwd_f32_dev(const float *x, float *y, uint64_t *bits, int64_t n, double p, uint64_t seed,
+                                            uint64_t offset, void *hip_stream) {
+    if (!x || !y || !bits || n < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad relu_dropout arguments");
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) DCR_FAIL(DCR_EINVAL, "relu_dropout: 16-byte aligned tensors expected");
+    if (n == 0) return DCR_OK;
+    const int64_t threads = (n + 3) / 4, blocks = (threads + 255) / 256;
+    const double th = p * 4294967296.0;
+    const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    hipLaunchKernelGGL(k_relu_dropout_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, x, y,
+                       (unsigned long long *)bits, n, (float)(1.0 / (1.0 - p)), threshold, seed, offset);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_relu_dropout_bwd_f32_dev(const float *grad_out, float *grad_in, const uint64_t *bits, int64_t n,
+                                            double p, void *hip_stream) {
+    if (!grad_out || !grad_in || !bits || n < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad relu_dropout arguments");
+    if (((uintptr_t)grad_out & 15) || ((uintptr_t)grad_in & 15))
+        DCR_FAIL(DCR_EINVAL, "relu_dropout: 16-byte aligned tensors expected");
+    if (n == 0) return DCR_OK;
+    const int64_t threads = (n + 3) / 4, blocks = (threads + 255) / 256;
+    hipLaunchKernelGGL(k_relu_dropout_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, grad_out, grad_in,
+                       (const unsigned long long *)bits, n, (float)(1.0 / (1.0 - p)));
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}

@@ -186,6 +186,50 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+_dropout_calls = 0  # offset of the Philox stream: one step per fused ReLU+dropout call of the process
+
+
+class _ReluDropoutFn(torch.autograd.Function):
+    """y = dropout(relu(x)) in one pass each way (csrc/dcr_gcn.hip), the keep mask packed to one bit per element."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        global _dropout_calls
+        from dcr import _lib
+        x = x.contiguous()
+        n = x.numel()
+        words = ctypes.c_int64()
+        _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n, ctypes.byref(words)))
+        bits = torch.empty(max(words.value, 1), dtype=torch.int64, device=x.device)
+        y = torch.empty_like(x)
+        _dropout_calls += 1
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(_lib.lib().dcr_relu_dropout_fwd_f32_dev(x.data_ptr(), y.data_ptr(), bits.data_ptr(), n, float(p),
+                                                           torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls,
+                                                           ctypes.c_void_p(stream)))
+        ctx.bits, ctx.p = bits, float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from dcr import _lib
+        grad_out = grad_out.contiguous()
+        gin = torch.empty_like(grad_out)
+        stream = torch.cuda.current_stream(grad_out.device).cuda_stream
+        _lib.check(_lib.lib().dcr_relu_dropout_bwd_f32_dev(grad_out.data_ptr(), gin.data_ptr(), ctx.bits.data_ptr(),
+                                                           grad_out.numel(), ctx.p, ctypes.c_void_p(stream)))
+        return gin, None
+
+
+def relu_dropout(x, act_fn, dropout):
+    """``dropout(act_fn(x))`` (models/gcn.py:38-42).  Training on the MI355X with ReLU: the fused kernel; otherwise the
+    two stock modules (evaluation, CPU tests, other activations)."""
+    if (_AGG_BACKEND == 'hip' and x.is_cuda and x.dtype == torch.float32 and dropout.training and 0.0 < dropout.p < 1.0
+            and isinstance(act_fn, ReLU) and x.data_ptr() % 16 == 0):
+        return _ReluDropoutFn.apply(x, dropout.p)
+    return dropout(act_fn(x))
+
+
 class _Linear(torch.nn.Module):
     """torch_geometric.nn.dense.linear.Linear(in, out, bias=False, weight_initializer='glorot')."""
 
@@ -289,8 +333,7 @@ class GCN(torch.nn.Module):
             if i == len(self.layers) - 1:
                 break
 
-            x = self.act_fn(x)
-            x = self.dropout(x)
+            x = relu_dropout(x, self.act_fn, self.dropout)
 
         return torch.nn.functional.log_softmax(x, dim=1)
 

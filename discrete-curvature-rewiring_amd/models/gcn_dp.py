@@ -18,7 +18,7 @@ divided by the global number of training nodes, so the summed gradients equal th
 import torch
 import torch.distributed as dist
 
-from models.gcn import GCN, aggregate, gcn_norm_csr
+from models.gcn import GCN, aggregate, gcn_norm_csr, relu_dropout
 
 
 def block_range(n, world, rank):
@@ -84,13 +84,13 @@ class ShardedGCN(torch.nn.Module):
             if i == 0 and layer.propagate_input_first and not h.requires_grad:
                 h = layer.lin(self.propagated_input_local(h), layer.bias)   # (Â_p·X)·Wᵀ + b, no exchange
                 if i + 1 < len(layers):
-                    h = self.gcn.dropout(self.gcn.act_fn(h))
+                    h = relu_dropout(h, self.gcn.act_fn, self.gcn.dropout)
                 continue
             z_local = layer.lin(h)
             z = _GatherRows.apply(z_local, self.n, self.per, self.group)
             h = aggregate(z, layer.bias, self.csr)
             if i + 1 < len(layers):
-                h = self.gcn.dropout(self.gcn.act_fn(h))
+                h = relu_dropout(h, self.gcn.act_fn, self.gcn.dropout)
         return torch.nn.functional.log_softmax(h, dim=1)
 
     def propagated_input_local(self, x_local):

@@ -159,6 +159,16 @@ int dcr_atb_f32_workspace(int64_t K, int64_t M, int64_t N, int64_t *out_floats);
 int dcr_atb_f32_dev(const float *A_dev, const float *B_dev, float *C_dev, int64_t K, int64_t M, int64_t N, int64_t lda,
                     int64_t ldb, int64_t ldc, float *workspace_dev, int64_t workspace_floats, void *hip_stream);
 
+/* ---- ReLU + dropout between the GCN layers (device pointers, caller's stream) ------------------------------------
+ * models/gcn.py:38-42 (x = act_fn(x); x = dropout(x)) as one pass per direction: y = x > 0 and kept ? x / (1 - p) : 0,
+ * the keep decisions packed one bit per element into `bits` (dcr_relu_dropout_bits_words(n) 64-bit words); backward
+ * scales the incoming gradient by the same bits.  Philox-4x32-10 keyed by (seed, offset): reproducible for a seed. */
+int dcr_relu_dropout_bits_words(int64_t n, int64_t *out_words);
+int dcr_relu_dropout_fwd_f32_dev(const float *x_dev, float *y_dev, uint64_t *bits_dev, int64_t n, double p, uint64_t seed,
+                                 uint64_t offset, void *hip_stream);
+int dcr_relu_dropout_bwd_f32_dev(const float *grad_out_dev, float *grad_in_dev, const uint64_t *bits_dev, int64_t n,
+                                 double p, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -298,3 +298,29 @@ def test_linear_backward_uses_mfma_kernel_and_matches_autograd():
     gw_ref = (w.double().t() @ x.detach().double()).float()
     assert torch.allclose(gx, w @ lin.weight.detach(), atol=1e-4)
     assert torch.allclose(gw, gw_ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_fused_relu_dropout():
+    """One-pass ReLU+dropout: survivors are positive inputs scaled by 1/(1-p), the keep rate is 1-p, the backward pass
+    uses the same bits, a seed reproduces the mask, evaluation mode is plain ReLU."""
+    from models.gcn import relu_dropout
+    act, drop = torch.nn.ReLU(), torch.nn.Dropout(p=0.3)
+    torch.manual_seed(5)
+    x = torch.randn(3001, 129, device='cuda', requires_grad=True)   # odd sizes: exercises the tail
+    drop.train()
+    y = relu_dropout(x, act, drop)
+    kept = y != 0
+    pos = x.detach() > 0
+    assert not (kept & ~pos).any()
+    rate = kept.sum().item() / pos.sum().item()
+    assert abs(rate - 0.7) < 0.01, rate
+    assert torch.equal(y[kept], (x.detach() * (1.0 / (1.0 - 0.3)))[kept].float())
+    y.sum().backward()
+    want = torch.where(kept, torch.full_like(y, float(np.float32(1.0 / (1.0 - 0.3)))), torch.zeros_like(y))
+    assert torch.equal(x.grad, want)
+    drop.eval()
+    assert torch.equal(relu_dropout(x.detach(), act, drop), torch.relu(x.detach()))
+    # successive calls draw different masks
+    drop.train()
+    assert not torch.equal(relu_dropout(x.detach(), act, drop) != 0, kept)
