@@ -180,6 +180,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the measured path)')
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:  # rehearsal of the N > 1 path on a box with fewer GPUs (DCR_BENCH_BACKEND=gloo): share
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get('DCR_BENCH_FORCE_DIST') == '1'  # exercise the N>1 code path on one GPU (testing aid)
@@ -187,7 +190,11 @@ def main():
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('DCR_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm; gloo only for rehearsals
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:
