@@ -1,9 +1,9 @@
 """Randomised parity sweep on the GPU box (not part of the test suite): many small and medium graphs of different
 families, every curvature kind, full pass + incremental pass + SDRF runs against the C oracle.
-Usage: SECONDS_BUDGET=240 python tools/fuzz_parity.py"""
+Usage: SECONDS_BUDGET=240 python tests/fuzz_parity.py  (lives under tests/ because it uses the oracle)"""
 import os, sys, time
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path[:0] = [REPO, os.path.join(REPO, 'discrete-curvature-rewiring_amd')]
 import torch
 from dcr import synthetic
