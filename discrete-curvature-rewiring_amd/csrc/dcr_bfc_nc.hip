@@ -857,9 +857,11 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         for (int b = 0; b < 3; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
         s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2];
     }
-    launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
-    launch_nc_block<2, MODE>(g, vw, curv_type, s1);
-    launch_nc_wave<1, MODE>(g, vw, curv_type, s2);
+    // a class whose smallest degree exceeds the (host-tracked upper bound of the) largest degree has no units: on
+    // small graphs that saves the dispatch of up to three full persistent grids
+    if (g->max_deg_bound > nc_maxdeg(2)) launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
+    if (g->max_deg_bound > nc_maxdeg(1)) launch_nc_block<2, MODE>(g, vw, curv_type, s1);
+    if (g->max_deg_bound > nc_maxdeg(0)) launch_nc_wave<1, MODE>(g, vw, curv_type, s2);
     launch_nc_wave<0, MODE>(g, vw, curv_type, s3);
     if (!serial) {
         for (int b = 0; b < 3; ++b) {
