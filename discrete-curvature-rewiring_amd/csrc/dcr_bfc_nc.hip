@@ -795,7 +795,12 @@ static void launch_nc_wave(dcr_graph *g, const View &vw, int curv_type, hipStrea
     int per_cu = (160 * 1024) / LDS;
     if (per_cu > 8) per_cu = 8;  // 32 wave slots per CU, 4 waves per workgroup
     if (per_cu < 1) per_cu = 1;
-    hipLaunchKernelGGL((k_nc_wave<SLOTS, MODE, CHUNK>), dim3(g->num_cu * per_cu), dim3(256), 0, st, vw, g->nc_units[C],
+    // no more workgroups than there can be work for (small graphs): units <= nodes of the class + their slots / 16
+    int64_t grid = (int64_t)g->num_cu * per_cu;
+    const int64_t nodes_bound = C == 0 ? g->n : g->cap_total / (nc_maxdeg(C - 1) + 1);
+    const int64_t by_work = (nodes_bound + g->cap_total / 16) / (4 * CHUNK) + 1;
+    if (grid > by_work) grid = by_work;
+    hipLaunchKernelGGL((k_nc_wave<SLOTS, MODE, CHUNK>), dim3((unsigned)grid), dim3(256), 0, st, vw, g->nc_units[C],
                        &g->dres->nc_count[C], g->nc_cap[C], g->nc_queues + C * NC_QUEUES * NC_QUEUE_STRIDE, curv_type,
                        g->curv);
 }
