@@ -391,3 +391,26 @@ def test_data_parallel_two_ranks_hip_kernels():
         pytest.skip(f'gloo cannot move device tensors in this torch build: {dict(ret)}')
     for rank, (err_fwd, err_w, dacc) in ret.items():
         assert err_fwd < 1e-5 and err_w < 1e-5 and dacc < 1e-6, (rank, err_fwd, err_w, dacc)
+
+
+@pytest.mark.gpu
+def test_cora_shaped_logits_within_tolerance():
+    """BASELINE.json's tolerance (logits within 1e-5 of the reference GCN) at Cora's shape: 2,485 nodes, 1,433 sparse
+    row-normalised features, hidden 128, 7 classes — the first layer runs as (Â·X)·Wᵀ, the check is the dense fp64
+    restatement of PyG's Â·(X·Wᵀ)."""
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from models.gcn import GCN, dense_reference_logits
+    ei, n = synthetic.powerlaw_graph(2485, 2, seed=1)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, 1433, generator=g) < 0.0127).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1.0)
+    data = Data(x=x, edge_index=torch.from_numpy(ei), y=torch.randint(0, 7, (n,), generator=g), num_nodes=n).to('cuda')
+    torch.manual_seed(3)
+    model = GCN(Dataset(data, 7), hidden=[128], dropout=0.3396).cuda()
+    model.eval()
+    with torch.no_grad():
+        got = model(data)
+        want = dense_reference_logits(model, data.x, data.edge_index, n)
+    err = (got.double() - want).abs().max().item()
+    assert err < 1e-5, err
