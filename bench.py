@@ -153,6 +153,41 @@ def gcn_bench(args, rank, world, local_rank, dist):
     return res
 
 
+def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, epochs=200):
+    """BASELINE.json configs[3] shape (Citeseer-LCC: 2,120 nodes, 3,703 features, hidden 64, 6 classes; hyper-parameters
+    of utils/hyperparams.py) on a synthetic graph of that size: epochs/sec of train step + validation forward."""
+    import torch
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from experiment.training_loop import evaluate, train
+    from models.gcn import GCN
+    dev = torch.device('cuda', local_rank)
+    ei_np, n = synthetic.powerlaw_graph(n, m, seed=12345)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.rand(n, n_feat, device=dev, generator=g) < 0.009).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1.0)
+    y = torch.randint(0, n_cls, (n,), device=dev, generator=g)
+    r = torch.rand(n, device=dev, generator=g)
+    data = Data(x=x, edge_index=torch.from_numpy(ei_np).to(dev), y=y, num_nodes=n, train_mask=r < 0.1,
+                val_mask=(r >= 0.1) & (r < 0.4))
+    torch.manual_seed(0)
+    model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=dropout).to(dev)
+    opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                            {'params': model.reg_params, 'weight_decay': wd}], lr=lr)
+    for _ in range(10):
+        train(model, opt, data); evaluate(model, data, test=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        train(model, opt, data); evaluate(model, data, test=False)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {'metric': 'GCN epochs/sec', 'value': epochs / el, 'unit': 'epochs/sec', 'ms_per_epoch': el / epochs * 1e3,
+            'dtype': 'f32', 'config': {'workload': f'Citeseer-shaped synthetic graph N={n} E={ei_np.shape[1] // 2}, '
+                                                   f'F={n_feat}, hidden={hidden}, classes={n_cls}, dropout {dropout}, '
+                                                   f'Adam lr {lr} wd {wd}; epoch = train step + val forward'}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -303,6 +338,8 @@ def main():
             out['incremental_mode'] = inc
         if gcn is not None:
             out['gcn'] = gcn
+            if world == 1:
+                out['gcn_citeseer_shape'] = gcn_small_shape(2120, 2, 3703, 64, 6, 0.4103, 0.0199, 0.4551, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(ei, n, E)
         print(json.dumps(out), flush=True)
