@@ -68,8 +68,8 @@ __device__ inline int count_hits(unsigned m, unsigned long long sel, int shift) 
 constexpr int LONG_ROW = 60;  // longer rows are streamed by a whole wave; shorter ones fit four 64-byte group steps
 
 // ---- node-centric pass: which edges it takes (dcr_bfc_nc.hip) -------------------------------------------------
-constexpr int NC_CLASSES = 4;
-constexpr int NC_MAXD = 4094;       // largest degree whose neighbour table fits the biggest class
+constexpr int NC_CLASSES = 5;
+constexpr int NC_MAXD = 8190;       // largest degree whose neighbour table fits the biggest class
 constexpr int NC_MAXOTHER = 16382;  // largest degree of the other endpoint (15-bit per-slot counters)
 
 __device__ __host__ inline bool nc_takes(int da, int db) {

@@ -32,12 +32,16 @@
 
 namespace dcr {
 
-__host__ __device__ constexpr int nc_slots(int c) { return c == 0 ? 256 : c == 1 ? 512 : c == 2 ? 2048 : 8192; }
-__host__ __device__ constexpr int nc_maxdeg(int c) { return c == 0 ? 62 : c == 1 ? 254 : c == 2 ? 1022 : NC_MAXD; }
-__host__ __device__ constexpr int nc_waves(int c) { return c == 2 ? 8 : 4; }  // waves per workgroup
+__host__ __device__ constexpr int nc_slots(int c) { return c == 0 ? 256 : c == 1 ? 512 : c == 2 ? 2048 : c == 3 ? 8192 : 16384; }
+__host__ __device__ constexpr int nc_maxdeg(int c) {
+    return c == 0 ? 62 : c == 1 ? 254 : c == 2 ? 1022 : c == 3 ? 4094 : NC_MAXD;
+}
+// waves per workgroup; the last class (64 KiB table + 32 KiB of slot state per wave) fits two
+__host__ __device__ constexpr int nc_waves(int c) { return c == 2 ? 8 : c == 4 ? 2 : 4; }
 
 __device__ inline int nc_class_of(int d) {
-    return d <= nc_maxdeg(0) ? 0 : d <= nc_maxdeg(1) ? 1 : d <= nc_maxdeg(2) ? 2 : d <= nc_maxdeg(3) ? 3 : -1;
+    return d <= nc_maxdeg(0) ? 0 : d <= nc_maxdeg(1) ? 1 : d <= nc_maxdeg(2) ? 2 : d <= nc_maxdeg(3) ? 3
+           : d <= nc_maxdeg(4) ? 4 : -1;
 }
 
 // compiler-level ordering of one wave's LDS traffic (the hardware executes a wave's DS instructions in order)
@@ -616,7 +620,7 @@ __global__ void __launch_bounds__(64 * W) k_nc_block(View g, const int2 *units, 
         row_ok(g, make_int2(-1, total), 17, 0, 0);
         return;
     }
-    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == 2048 ? 32768 : 49152) + (int)(blockIdx.x * W + wid) % 16384) : nullptr;
+    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == 2048 ? 32768 : SLOTS == 8192 ? 49152 : 65536) + (int)(blockIdx.x * W + wid) % 16384) : nullptr;
     if (tr && (threadIdx.x & 63) == 0) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
     // dynamic dequeue: thread 0 pulls the next unit and publishes it through LDS between two barriers, so every value
     // that steers control flow around the barriers is uniform in the workgroup
@@ -662,9 +666,9 @@ struct NcLists {
 
 // Units are laid out heaviest first inside each class (by degree bucket of the owning node), so that with dynamic
 // dequeue the long-running units start at once and the cheap ones fill the tail.
-constexpr int NC_BUCKETS = 15;
+constexpr int NC_BUCKETS = 16;
 __device__ inline int nc_bucket_lo(int b) {
-    constexpr int lo[NC_BUCKETS] = {1, 13, 17, 25, 33, 49, 63, 97, 129, 193, 255, 511, 767, 1023, 2047};
+    constexpr int lo[NC_BUCKETS] = {1, 13, 17, 25, 33, 49, 63, 97, 129, 193, 255, 511, 767, 1023, 2047, 4095};
     return lo[b];
 }
 __device__ inline int nc_bucket_of(int d) {
@@ -673,7 +677,7 @@ __device__ inline int nc_bucket_of(int d) {
     for (int i = 1; i < NC_BUCKETS; ++i) b += (d >= nc_bucket_lo(i));
     return b;
 }
-__device__ inline int nc_bucket_class(int b) { return b < 6 ? 0 : b < 10 ? 1 : b < 13 ? 2 : 3; }
+__device__ inline int nc_bucket_class(int b) { return b < 6 ? 0 : b < 10 ? 1 : b < 13 ? 2 : b < 15 ? 3 : 4; }
 
 // PHASE 0 counts the units per bucket; PHASE 1 places them (class list = its buckets, heaviest first).  Reservations
 // are aggregated wave -> workgroup (LDS) -> one global atomic per bucket and workgroup: the few bucket counters are
@@ -769,7 +773,7 @@ __global__ void k_nc_clear(DevResult *res) {
 static int ensure_nc(dcr_graph *g) {
     // units per class, from the smallest degree a member node can have and its sub-units (16 or 4 positions each)
     const int64_t need[NC_CLASSES] = {g->n * 4 + 64, g->cap_total / 3 + 64, g->cap_total / 6 + 64,
-                                      g->cap_total / 3 + 64};
+                                      g->cap_total / 3 + 64, g->cap_total / 6 + 64};
     for (int c = 0; c < NC_CLASSES; ++c) {
         if (g->nc_cap[c] < need[c]) {
             if (g->nc_units[c]) (void)hipFree(g->nc_units[c]);
@@ -830,8 +834,8 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
             (int32_t)g->n, 1, nullptr};
     static const bool want_trace = getenv("DCR_NC_TRACE") != nullptr;
     if (want_trace) {
-        if (!g->nc_trace) DCR_TRY(dev_alloc(&g->nc_trace, 4 * 16384 * 2));
-        DCR_HIP(hipMemsetAsync(g->nc_trace, 0, sizeof(long long) * 4 * 16384 * 2, g->stream));
+        if (!g->nc_trace) DCR_TRY(dev_alloc(&g->nc_trace, NC_CLASSES * 16384 * 2));
+        DCR_HIP(hipMemsetAsync(g->nc_trace, 0, sizeof(long long) * NC_CLASSES * 16384 * 2, g->stream));
         vw.trace = g->nc_trace;
     }
     NcLists L;
@@ -854,35 +858,36 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         hipLaunchKernelGGL(k_nc_plan<1>, dim3((unsigned)pblocks), dim3(PLAN_THREADS), 0, g->stream, vw, L, g->nc_touch,
                            g->dres);
     }
-    // the four classes are independent: fork them onto side streams; the rarest, longest-running units first
+    // the five classes are independent: fork them onto side streams; the rarest, longest-running units first
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;  // debugging aid: one stream
-    hipStream_t s1 = g->stream, s2 = g->stream, s3 = g->stream;
+    hipStream_t s1 = g->stream, s2 = g->stream, s3 = g->stream, s4 = g->stream;
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        for (int b = 0; b < 3; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
-        s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2];
+        for (int b = 0; b < 4; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
+        s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2]; s4 = g->side[3];
     }
     // a class whose smallest degree exceeds the (host-tracked upper bound of the) largest degree has no units: on
-    // small graphs that saves the dispatch of up to three full persistent grids
+    // small graphs that saves the dispatch of up to four full persistent grids
+    if (g->max_deg_bound > nc_maxdeg(3)) launch_nc_block<4, MODE>(g, vw, curv_type, s4);
     if (g->max_deg_bound > nc_maxdeg(2)) launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
     if (g->max_deg_bound > nc_maxdeg(1)) launch_nc_block<2, MODE>(g, vw, curv_type, s1);
     if (g->max_deg_bound > nc_maxdeg(0)) launch_nc_wave<1, MODE>(g, vw, curv_type, s2);
     launch_nc_wave<0, MODE>(g, vw, curv_type, s3);
     if (!serial) {
-        for (int b = 0; b < 3; ++b) {
+        for (int b = 0; b < 4; ++b) {
             DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
             DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[b], 0));
         }
     }
     DCR_HIP(hipGetLastError());
     if (want_trace) {  // per class: when did the waves start / make their last progress (100 MHz ticks -> microseconds)
-        std::vector<long long> h(4 * 16384 * 2);
+        std::vector<long long> h(NC_CLASSES * 16384 * 2);
         DCR_HIP(hipStreamSynchronize(g->stream));
         DCR_HIP(hipMemcpy(h.data(), g->nc_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
         long long t0 = 0;
         for (size_t i = 0; i < h.size(); i += 2)
             if (h[i] && (!t0 || h[i] < t0)) t0 = h[i];
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC_CLASSES; ++c) {
             std::vector<double> st, en;
             for (int w = 0; w < 16384; ++w) {
                 const long long a = h[2 * (c * 16384 + w)], b = h[2 * (c * 16384 + w) + 1];

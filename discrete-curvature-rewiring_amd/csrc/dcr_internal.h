@@ -53,8 +53,8 @@ struct DevResult {
     int32_t max_keys;     // largest du+dv+2 seen by classify
     int32_t work_count[NBINS];
     int32_t work_next[NBINS];  // dequeue cursors of the persistent bin kernels
-    int32_t nc_count[4];       // node-centric pass: units per degree class
-    int32_t nc_next[4];        // dequeue cursors of its kernels
+    int32_t nc_count[5];       // node-centric pass: units per degree class
+    int32_t nc_next[5];        // dequeue cursors of its kernels
     int32_t nc_bucket[16];     // units per degree bucket (plan phase 0)
     int32_t nc_fill[16];       // placement cursors per bucket (plan phase 1)
     int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS
@@ -101,9 +101,9 @@ struct dcr_graph {
     bool dirty_tracked = false;  // flags cover every edit since the last pass
 
     // node-centric pass (dcr_bfc_nc.hip): unit lists per degree class
-    int2 *nc_units[4] = {nullptr, nullptr, nullptr, nullptr};  // {node, first sub-unit}
-    int64_t nc_cap[4] = {0, 0, 0, 0};
-    long long *nc_trace = nullptr;  // DCR_NC_TRACE diagnostic: [4 classes][16384 waves][2]
+    int2 *nc_units[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // {node, first sub-unit}
+    int64_t nc_cap[5] = {0, 0, 0, 0, 0};
+    long long *nc_trace = nullptr;  // DCR_NC_TRACE diagnostic: [5 classes][16384 waves][2]
     int32_t *nc_queues = nullptr;  // dequeue cursors of the two wave-class kernels, one cache line each
     uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
     int64_t nc_touch_cap = 0;

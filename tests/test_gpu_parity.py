@@ -435,25 +435,26 @@ def test_s100k_incremental_equals_full():
 
 
 # ------------------------------------------------------------------------------------------------ degree limits
-def test_hubs_beyond_node_centric_limits(dcr, oracle):
-    """Two hubs with more than 4,094 neighbours each, joined by an edge: that edge (and only that one) is outside the
-    node-centric kernels' table sizes and goes through the edge-centric fallback; a third hub with ~3,000 neighbours
-    exercises the largest node-centric class.  Whole pass bit-compared with the oracle."""
+@pytest.mark.parametrize('n,da,db,dc', [(9000, 4300, 4200, 3000), (18000, 8195, 8180, 6000)])
+def test_hubs_at_and_beyond_node_centric_limits(dcr, oracle, n, da, db, dc):
+    """Three hubs joined to each other.  First case: 4,300 / 4,200 / 3,000 neighbours — the two largest node-centric
+    classes (tables of 16,384 and 8,192 slots).  Second case: hub 0 has 8,197 neighbours, above every table size (its
+    edges are owned by the other endpoints, including hub 1 with 8,182: the largest class at its limit).  Whole pass
+    bit-compared with the oracle; then edits and an incremental pass."""
     rng = np.random.Generator(np.random.PCG64(99))
-    n = 9000
     src, dst = [0], [1]
-    a = rng.choice(np.arange(3, n), size=4300, replace=False)     # leaves of hub 0
-    b = rng.choice(np.arange(3, n), size=4200, replace=False)     # leaves of hub 1 (overlap: triangles on (0,1))
-    c = rng.choice(np.arange(3, n), size=3000, replace=False)     # leaves of hub 2
+    a = rng.choice(np.arange(3, n), size=da, replace=False)     # leaves of hub 0
+    b = rng.choice(np.arange(3, n), size=db, replace=False)     # leaves of hub 1 (overlap: triangles on (0,1))
+    c = rng.choice(np.arange(3, n), size=dc, replace=False)     # leaves of hub 2
     for hub, leaves in ((0, a), (1, b), (2, c)):
         src += [hub] * len(leaves); dst += leaves.tolist()
     src += [0, 1]; dst += [2, 2]
-    extra = rng.integers(3, n, size=(2, 6000))                    # leaf-leaf edges: 4-cycles through the hubs
+    extra = rng.integers(3, n, size=(2, 6000))                  # leaf-leaf edges: 4-cycles through the hubs
     src += extra[0].tolist(); dst += extra[1].tolist()
     from dcr import synthetic
     ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
     G = dcr(ei, n)
-    assert max(G.degree(0), G.degree(1)) > 4094 and 1022 < G.degree(2) <= 4094
+    assert min(G.degree(0), G.degree(1)) > da - 200 and G.degree(2) > dc - 200
     C = oracle.CGraph(ei, n)
     for ct in ('bfc', 'augmented'):
         eu, ev, cv = G.curvature_all(ct)
@@ -461,7 +462,7 @@ def test_hubs_beyond_node_centric_limits(dcr, oracle):
         assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
         bad = np.nonzero(cv != oc)[0]
         assert bad.size == 0, (ct, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:5]])
-    # edits keep working across the fallback boundary, and the incremental pass agrees
+    # edits keep working across the class / fallback boundaries, and the incremental pass agrees
     G.add_edge(5, 6) if not C.has_edge(5, 6) else None
     C.add_edge(5, 6) if not C.has_edge(5, 6) else None
     G.remove_edge(0, 1); C.remove_edge(0, 1)
