@@ -608,28 +608,30 @@ __global__ void __launch_bounds__(256, 6) k_nc_wave(View g, const int2 *units, c
 }
 
 // ---- block classes: one table per workgroup, wave w takes sub-unit sub0 + w of the row --------------------------
-template <int SLOTS, int W, int MODE>
-__global__ void __launch_bounds__(64 * W) k_nc_block(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
-                                                      int32_t *next, int curv_type, double *curv) {
-    __shared__ __attribute__((aligned(16))) unsigned tab[SLOTS];
-    __shared__ __attribute__((aligned(16))) unsigned cnt_all[W][SLOTS / 2];
-    __shared__ NcScratch sc_all[W];
+// The unit loop of one class, run by a workgroup of BW waves of which the first W work on units (W < BW only in the
+// combined kernel below).  LDS comes from the caller.
+template <int SLOTS, int W, int BW, int MODE>
+__device__ inline void nc_block_units(const View &g, const int2 *units, const int32_t *count, int64_t unit_cap,
+                                      int32_t *next, int curv_type, double *curv, unsigned *tab, unsigned *cnt_base,
+                                      NcScratch *sc_all, int *it_sh, int trace_slot) {
     const int wid = threadIdx.x >> 6;
     const int total = *count;
-    if (total < 0 || total > unit_cap) {
+    if (total < 0 || total > unit_cap) {  // uniform
         row_ok(g, make_int2(-1, total), 17, 0, 0);
         return;
     }
-    long long *tr = g.trace ? g.trace + 2 * ((SLOTS == 2048 ? 32768 : SLOTS == 8192 ? 49152 : 65536) + (int)(blockIdx.x * W + wid) % 16384) : nullptr;
-    if (tr && (threadIdx.x & 63) == 0) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
+    long long *tr = g.trace ? g.trace + 2 * (trace_slot * 16384 + (int)(blockIdx.x * BW + wid) % 16384) : nullptr;
+    if (tr && (threadIdx.x & 63) == 0 && wid < W) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
     // dynamic dequeue: thread 0 pulls the next unit and publishes it through LDS between two barriers, so every value
     // that steers control flow around the barriers is uniform in the workgroup
-    __shared__ int it_sh;
     for (int round = 0; round <= total; ++round) {
-        if (threadIdx.x == 0) it_sh = atomicAdd(next, 1);
+        if (threadIdx.x == 0) *it_sh = atomicAdd(next, 1);
         __syncthreads();
-        const int it = it_sh;
-        if (it >= total || it < 0) break;
+        const int it = *it_sh;
+        if (it >= total || it < 0) {
+            __syncthreads();  // nobody may still be reading it_sh when the caller's next loop writes it
+            break;
+        }
         const int2 un = units[it];
         const int u = un.x, sub0 = un.y;
         bool ok = u >= 0 && u < g.n && sub0 >= 0;
@@ -642,20 +644,48 @@ __global__ void __launch_bounds__(64 * W) k_nc_block(View g, const int2 *units, 
             __syncthreads();
             continue;
         }
-        for (int i = threadIdx.x; i < SLOTS; i += 64 * W) tab[i] = EMPTY;
+        for (int i = threadIdx.x; i < SLOTS; i += 64 * BW) tab[i] = EMPTY;
         __syncthreads();
-        for (int i = threadIdx.x; i < ru.y; i += 64 * W) {
+        for (int i = threadIdx.x; i < ru.y; i += 64 * BW) {
             const int k = g.col[ru.x + i];
             if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k);
         }
         __syncthreads();
         const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
         const int sub = sub0 + wid;
-        if (sub < nsub)
-            nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_all[wid], &sc_all[wid], curv_type, curv);
-        if (tr && (threadIdx.x & 63) == 0) tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wid < W && sub < nsub)
+            nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_base + wid * (SLOTS / 2), &sc_all[wid], curv_type, curv);
+        if (tr && (threadIdx.x & 63) == 0 && wid < W) tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
         __syncthreads();  // the table and the unit index are rewritten by the next round
     }
+}
+
+template <int SLOTS, int W, int MODE>
+__global__ void __launch_bounds__(64 * W) k_nc_block(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+                                                      int32_t *next, int curv_type, double *curv) {
+    __shared__ __attribute__((aligned(16))) unsigned tab[SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned cnt_all[W * (SLOTS / 2)];
+    __shared__ NcScratch sc_all[W];
+    __shared__ int it_sh;
+    nc_block_units<SLOTS, W, W, MODE>(g, units, count, unit_cap, next, curv_type, curv, tab, cnt_all, sc_all, &it_sh,
+                                      SLOTS == 2048 ? 2 : 3);
+}
+
+// The two largest classes in ONE kernel.  Their workgroups need most of a CU's LDS (table 64 KB + 2 x 32 KB of slot
+// state, or 32 KB + 4 x 16 KB); launched as kernels of their own, the second one found no CU with that much LDS free
+// until the other persistent kernels had finished (measured on the 1M-node graph: it started at the very end of the
+// pass and added its whole run time).  One launch, first on the main stream, 4 waves: the workgroups take the units of
+// the 16,384-slot class first (waves 2 and 3 only help to build the table), then those of the 8,192-slot class.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_nc_block_big(View g, const int2 *units4, const int32_t *count4, int64_t cap4,
+                                                       int32_t *next4, const int2 *units3, const int32_t *count3,
+                                                       int64_t cap3, int32_t *next3, int curv_type, double *curv) {
+    __shared__ __attribute__((aligned(16))) unsigned tab[16384];
+    __shared__ __attribute__((aligned(16))) unsigned cnt_all[2 * (16384 / 2)];  // = 4 * (8192 / 2)
+    __shared__ NcScratch sc_all[4];
+    __shared__ int it_sh;
+    nc_block_units<16384, 2, 4, MODE>(g, units4, count4, cap4, next4, curv_type, curv, tab, cnt_all, sc_all, &it_sh, 4);
+    nc_block_units<8192, 4, 4, MODE>(g, units3, count3, cap3, next3, curv_type, curv, tab, cnt_all, sc_all, &it_sh, 3);
 }
 
 // ---- plan: one thread per node appends its units to the list of its degree class -----------------------------
@@ -822,6 +852,13 @@ static void launch_nc_block(dcr_graph *g, const View &vw, int curv_type, hipStre
 }
 
 template <int MODE>
+static void launch_nc_block_big(dcr_graph *g, const View &vw, int curv_type, hipStream_t st) {
+    hipLaunchKernelGGL((k_nc_block_big<MODE>), dim3(g->num_cu), dim3(256), 0, st, vw, g->nc_units[4],
+                       &g->dres->nc_count[4], g->nc_cap[4], &g->dres->nc_next[4], g->nc_units[3], &g->dres->nc_count[3],
+                       g->nc_cap[3], &g->dres->nc_next[3], curv_type, g->curv);
+}
+
+template <int MODE>
 static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
     DCR_TRY(ensure_nc(g));
     if (g->num_cu <= 0) {
@@ -858,23 +895,23 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         hipLaunchKernelGGL(k_nc_plan<1>, dim3((unsigned)pblocks), dim3(PLAN_THREADS), 0, g->stream, vw, L, g->nc_touch,
                            g->dres);
     }
-    // the five classes are independent: fork them onto side streams; the rarest, longest-running units first
+    // the classes are independent: fork them onto side streams; the rarest, longest-running units first
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;  // debugging aid: one stream
-    hipStream_t s1 = g->stream, s2 = g->stream, s3 = g->stream, s4 = g->stream;
+    hipStream_t s1 = g->stream, s2 = g->stream, s3 = g->stream;
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        for (int b = 0; b < 4; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
-        s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2]; s4 = g->side[3];
+        for (int b = 0; b < 3; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
+        s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2];
     }
     // a class whose smallest degree exceeds the (host-tracked upper bound of the) largest degree has no units: on
     // small graphs that saves the dispatch of up to four full persistent grids
-    if (g->max_deg_bound > nc_maxdeg(3)) launch_nc_block<4, MODE>(g, vw, curv_type, s4);
-    if (g->max_deg_bound > nc_maxdeg(2)) launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
+    if (g->max_deg_bound > nc_maxdeg(3)) launch_nc_block_big<MODE>(g, vw, curv_type, g->stream);  // classes 4 and 3
+    else if (g->max_deg_bound > nc_maxdeg(2)) launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
     if (g->max_deg_bound > nc_maxdeg(1)) launch_nc_block<2, MODE>(g, vw, curv_type, s1);
     if (g->max_deg_bound > nc_maxdeg(0)) launch_nc_wave<1, MODE>(g, vw, curv_type, s2);
     launch_nc_wave<0, MODE>(g, vw, curv_type, s3);
     if (!serial) {
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 3; ++b) {
             DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
             DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[b], 0));
         }
