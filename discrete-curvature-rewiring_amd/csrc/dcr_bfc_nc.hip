@@ -66,29 +66,44 @@ __device__ inline bool nc_owns(int a, int da, int b, int db, bool trivial_rule) 
 // slot of its home bucket, or of the next bucket when that one is full.  One 16-byte LDS read settles almost every
 // lookup (hit, or a free slot in the bucket = miss); with single-slot linear probing some lane of every
 // wave-instruction needed a second and a third probe, and that loop alone was 15 % of the pass.
+// A free slot.  Not 0xFFFFFFFF: that is what the slack behind a row holds, and the fast test below compares raw row
+// pieces (slack included) with the bucket contents.
+constexpr unsigned NC_EMPTY = 0xFFFFFFFDu;
+
 template <int SLOTS>
 __device__ inline unsigned hash_bucket(unsigned key) {
     constexpr int BITS = __builtin_ctz(SLOTS / 4);
+#ifdef DCR_HASH_MUL32
     return (key * 0x9E3779B1u) >> (32 - BITS);
+#else
+    // Fibonacci hashing in a 24-bit word: v_mul_u32_u24 is a full-rate instruction, the 32-bit v_mul_lo_u32 is
+    // quarter rate and this runs once per streamed neighbour id.  Only the low 24 bits of the id are hashed (the
+    // bucket stores the whole id, so ids that differ above bit 23 merely share a home bucket).
+    // (inline assembly: the compiler drops the 24-bit mask as not demanded and then picks the 32-bit multiply)
+    unsigned prod;
+    asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(prod) : "v"(key));
+    return (prod >> (24 - BITS)) & ((1u << BITS) - 1);
+#endif
 }
 
 // position of key inside the bucket (0..3) or -1; go_on: not found and the bucket is full (its slots fill in order,
 // so the last one taken means all taken): the key may have spilled into the next bucket
 __device__ inline int bucket_match(const uint4 e, unsigned key, bool &go_on) {
     const int pos = e.x == key ? 0 : e.y == key ? 1 : e.z == key ? 2 : e.w == key ? 3 : -1;
-    go_on = pos < 0 && e.w != EMPTY;
+    go_on = pos < 0 && e.w != NC_EMPTY;
     return pos;
 }
 
 template <int SLOTS>
-__device__ inline void nc_insert(unsigned *tab, unsigned key) {
+__device__ inline void nc_insert(unsigned *tab, unsigned key, int *spilled) {
     unsigned b = hash_bucket<SLOTS>(key);
     while (true) {
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
-            const unsigned old = atomicCAS(&tab[b * 4 + pos], EMPTY, key);
-            if (old == EMPTY || old == key) return;
+            const unsigned old = atomicCAS(&tab[b * 4 + pos], NC_EMPTY, key);
+            if (old == NC_EMPTY || old == key) return;
         }
+        *spilled = 1;  // some key of this table lives outside its home bucket
         b = (b + 1) & (SLOTS / 4 - 1);
     }
 }
@@ -114,41 +129,65 @@ __device__ inline unsigned cnt_add(unsigned *cnt, int h) {
 }
 
 // One aligned piece of a streamed row: which of its four entries (those selected by `vmask`) are unflagged members of
-// the table, as a 4-bit mask; s1 / gam pick up what the slot counters say about the node that was hit.  Entries
-// outside the row are replaced by a key no table holds, so the probe sequence needs no per-entry validity tests; the
-// (rare) hits of a lane are handled one at a time in a loop instead of four predicated copies of that code.
-constexpr unsigned NOKEY = 0xFFFFFFFEu;
+// the table, as a 4-bit mask; s1 / gam pick up what the slot counters say about the node that was hit.
+//
+// Almost every streamed id is NOT in the table, so the common case is kept to the bare minimum: hash, one 16-byte
+// LDS read, four equality compares and a "bucket full" compare per id, whose lane masks are combined on the scalar
+// unit.  Only when some lane of the wave-instruction has a match or a full home bucket does the wave branch into the
+// full lookup for that id: slot position, walk to the next bucket, validity of the entry (pieces are compared raw;
+// ids outside the row, slack included, can only cause a needless visit of the slow path), slot counter update.
+template <int SLOTS>
+__device__ inline int nc_find_from(const uint4 *tb, unsigned b, uint4 e, unsigned key) {
+    while (true) {
+        bool go_on;
+        const int pos = bucket_match(e, key, go_on);
+        if (pos >= 0) return (int)(b * 4) + pos;
+        if (!go_on) return -1;
+        b = (b + 1) & (SLOTS / 4 - 1);
+        e = tb[b];
+    }
+}
+
+// ovf (uniform): the table has keys outside their home buckets, so a full home bucket without a match is not yet a miss
+// vskip: the other endpoint v of the edge.  It is in the table (a neighbour of u) and in EVERY streamed row (their nodes
+// are neighbours of v), and it is never counted (flagged): without this test each row would take the slow path once.
+__device__ inline bool bucket_look(const uint4 e, unsigned key, bool ovf, unsigned vskip) {
+    bool look = (e.x == key) | (e.y == key) | (e.z == key) | (e.w == key);
+    if (ovf) look |= e.w != NC_EMPTY;
+    return look & (key != vskip);
+}
 
 template <int SLOTS>
 __device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, const int4 w, unsigned vmask, int &s1,
-                                          int &gam) {
-    const unsigned k0 = (vmask & 1u) ? (unsigned)w.x : NOKEY, k1 = (vmask & 2u) ? (unsigned)w.y : NOKEY,
-                   k2 = (vmask & 4u) ? (unsigned)w.z : NOKEY, k3 = (vmask & 8u) ? (unsigned)w.w : NOKEY;
-    unsigned b0 = hash_bucket<SLOTS>(k0), b1 = hash_bucket<SLOTS>(k1), b2 = hash_bucket<SLOTS>(k2), b3 = hash_bucket<SLOTS>(k3);
+                                          int &gam, bool ovf, unsigned vskip) {
+    const unsigned k[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
-    const uint4 e0 = tb[b0], e1 = tb[b1], e2 = tb[b2], e3 = tb[b3];
-    bool p0, p1, p2, p3;
-    int q0 = bucket_match(e0, k0, p0), q1 = bucket_match(e1, k1, p1), q2 = bucket_match(e2, k2, p2),
-        q3 = bucket_match(e3, k3, p3);
-    while (p0 | p1 | p2 | p3) {  // a full home bucket: rare
-        if (p0) { b0 = (b0 + 1) & (SLOTS / 4 - 1); q0 = bucket_match(tb[b0], k0, p0); }
-        if (p1) { b1 = (b1 + 1) & (SLOTS / 4 - 1); q1 = bucket_match(tb[b1], k1, p1); }
-        if (p2) { b2 = (b2 + 1) & (SLOTS / 4 - 1); q2 = bucket_match(tb[b2], k2, p2); }
-        if (p3) { b3 = (b3 + 1) & (SLOTS / 4 - 1); q3 = bucket_match(tb[b3], k3, p3); }
+    unsigned b[4];
+    uint4 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b[j] = hash_bucket<SLOTS>(k[j]);
+        e[j] = tb[b[j]];
     }
-    const unsigned h0 = b0 * 4 + (unsigned)q0, h1 = b1 * 4 + (unsigned)q1, h2 = b2 * 4 + (unsigned)q2,
-                   h3 = b3 * 4 + (unsigned)q3;
-    unsigned found = (q0 >= 0 ? 1u : 0u) | (q1 >= 0 ? 2u : 0u) | (q2 >= 0 ? 4u : 0u) | (q3 >= 0 ? 8u : 0u);
     unsigned m = 0;
-    while (found) {
-        const unsigned bit = found & (0u - found);
-        found ^= bit;
-        const unsigned h = bit == 1u ? h0 : bit == 2u ? h1 : bit == 4u ? h2 : h3;
-        const unsigned old = cnt_add(cnt, (int)h);
-        if (!(old & 0x8000u)) {
-            m |= bit;
-            s1 += (old == 0u);
-            gam = (int)old + 1 > gam ? (int)old + 1 : gam;
+    bool look[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) look[j] = bucket_look(e[j], k[j], ovf, vskip);
+    if (!__ballot(look[0] | look[1] | look[2] | look[3])) return 0u;  // uniform; the common case
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (__ballot(look[j])) {  // uniform
+            if (look[j] && ((vmask >> j) & 1u)) {
+                const int h = nc_find_from<SLOTS>(tb, b[j], e[j], k[j]);
+                if (h >= 0) {
+                    const unsigned old = cnt_add(cnt, h);
+                    if (!(old & 0x8000u)) {
+                        m |= 1u << j;
+                        s1 += (old == 0u);
+                        gam = (int)old + 1 > gam ? (int)old + 1 : gam;
+                    }
+                }
+            }
         }
     }
     return m;
@@ -192,12 +231,13 @@ struct NcScratch {
     int acc4[4][2];  // the same per edge of a batch
     int res[4][5];   // batch results per edge: T, |sq| table side, |sq| row side, gamma, position of u in row v
     int fin[16][5];  // the same per position of the unit, read back when the closing expressions are evaluated
+    int spilled;     // set while the table is built: some key lives outside its home bucket
 };
 
 // One edge {u,v} owned by u, by one wave.  `tab` holds N(u); cnt and sc are this wave's scratch.
 template <int SLOTS, int MODE>
 __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const unsigned *tab, unsigned *cnt,
-                                 NcScratch *sc) {
+                                 NcScratch *sc, bool ovf) {
     const int lane = threadIdx.x & 63;
     const int32_t *rowv = g.col + rv.x;
     NcEdge out;
@@ -292,7 +332,8 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
             for (int q = 0; q < 4; ++q) {
                 if (rr[q] >= 0) {
                     const int2 d = sc->desc[rr[q]];
-                    const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], piece_mask(aa[q], d.x, d.x + d.y), s1, gam);
+                    const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], piece_mask(aa[q], d.x, d.x + d.y), s1, gam, ovf,
+                                                             (unsigned)v);
                     if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one probe sequence live at a time: keeps the wave at 8 per SIMD
@@ -325,34 +366,36 @@ __host__ __device__ constexpr int nc_batch_for_slots(int slots) { return slots <
 // nc_probe_piece for a batch: the lanes of one wave-instruction work on rows of different edges, so the slot counters
 // (cnt) and the per-edge totals (acc: LDS atomics, hits are rare) are passed per lane
 template <int SLOTS>
-__device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt, int *acc, const int4 w, unsigned vmask) {
-    const unsigned k0 = (vmask & 1u) ? (unsigned)w.x : NOKEY, k1 = (vmask & 2u) ? (unsigned)w.y : NOKEY,
-                   k2 = (vmask & 4u) ? (unsigned)w.z : NOKEY, k3 = (vmask & 8u) ? (unsigned)w.w : NOKEY;
-    unsigned b0 = hash_bucket<SLOTS>(k0), b1 = hash_bucket<SLOTS>(k1), b2 = hash_bucket<SLOTS>(k2), b3 = hash_bucket<SLOTS>(k3);
+__device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt, int *acc, const int4 w, unsigned vmask,
+                                              bool ovf, unsigned vskip) {
+    const unsigned k[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
-    const uint4 e0 = tb[b0], e1 = tb[b1], e2 = tb[b2], e3 = tb[b3];
-    bool p0, p1, p2, p3;
-    int q0 = bucket_match(e0, k0, p0), q1 = bucket_match(e1, k1, p1), q2 = bucket_match(e2, k2, p2),
-        q3 = bucket_match(e3, k3, p3);
-    while (p0 | p1 | p2 | p3) {  // a full home bucket: rare
-        if (p0) { b0 = (b0 + 1) & (SLOTS / 4 - 1); q0 = bucket_match(tb[b0], k0, p0); }
-        if (p1) { b1 = (b1 + 1) & (SLOTS / 4 - 1); q1 = bucket_match(tb[b1], k1, p1); }
-        if (p2) { b2 = (b2 + 1) & (SLOTS / 4 - 1); q2 = bucket_match(tb[b2], k2, p2); }
-        if (p3) { b3 = (b3 + 1) & (SLOTS / 4 - 1); q3 = bucket_match(tb[b3], k3, p3); }
+    unsigned b[4];
+    uint4 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b[j] = hash_bucket<SLOTS>(k[j]);
+        e[j] = tb[b[j]];
     }
-    const unsigned h0 = b0 * 4 + (unsigned)q0, h1 = b1 * 4 + (unsigned)q1, h2 = b2 * 4 + (unsigned)q2,
-                   h3 = b3 * 4 + (unsigned)q3;
-    unsigned found = (q0 >= 0 ? 1u : 0u) | (q1 >= 0 ? 2u : 0u) | (q2 >= 0 ? 4u : 0u) | (q3 >= 0 ? 8u : 0u);
     unsigned m = 0;
-    while (found) {
-        const unsigned bit = found & (0u - found);
-        found ^= bit;
-        const unsigned h = bit == 1u ? h0 : bit == 2u ? h1 : bit == 4u ? h2 : h3;
-        const unsigned old = cnt_add(cnt, (int)h);
-        if (!(old & 0x8000u)) {
-            m |= bit;
-            if (old == 0u) atomicAdd(&acc[0], 1);          // a new member of sq on the table side
-            else atomicMax(&acc[1], (int)old + 1);         // (a first hit's 1 is covered by the row-side maximum)
+    bool look[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) look[j] = bucket_look(e[j], k[j], ovf, vskip);
+    if (!__ballot(look[0] | look[1] | look[2] | look[3])) return 0u;  // uniform; the common case
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (__ballot(look[j])) {  // uniform
+            if (look[j] && ((vmask >> j) & 1u)) {
+                const int h = nc_find_from<SLOTS>(tb, b[j], e[j], k[j]);
+                if (h >= 0) {
+                    const unsigned old = cnt_add(cnt, h);
+                    if (!(old & 0x8000u)) {
+                        m |= 1u << j;
+                        if (old == 0u) atomicAdd(&acc[0], 1);   // a new member of sq on the table side
+                        else atomicMax(&acc[1], (int)old + 1);  // (a first hit's 1 is covered by the row-side maximum)
+                    }
+                }
+            }
         }
     }
     return m;
@@ -363,7 +406,7 @@ __device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt
 // Results go to sc->res[b].
 template <int SLOTS, int B>
 __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const unsigned *tab, unsigned *cnt,
-                                     NcScratch *sc) {
+                                     NcScratch *sc, bool ovf) {
     constexpr int G = 64 / B;
     const int lane = threadIdx.x & 63, grp = lane / G, gl = lane % G;
     const unsigned long long gmask = ((1ull << G) - 1ull) << (grp * G);
@@ -430,11 +473,12 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            const int gr = (rr[q] < 0 ? 0 : rr[q]) / G;
+            const unsigned vgr = (unsigned)__shfl(v, gr * G);  // the edge this row belongs to (all lanes converged here)
             if (rr[q] >= 0) {
                 const int2 d = sc->desc[rr[q]];
-                const int gr = rr[q] / G;
                 const unsigned m = nc_probe_piece_acc<SLOTS>(tab, cnt + gr * (SLOTS / 2), sc->acc4[gr], w[q],
-                                                             piece_mask(aa[q], d.x, d.x + d.y));
+                                                             piece_mask(aa[q], d.x, d.x + d.y), ovf, vgr);
                 if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
             }
             __builtin_amdgcn_sched_barrier(0);  // one probe sequence live at a time
@@ -462,7 +506,8 @@ __host__ __device__ constexpr int nc_lanes_for_slots(int slots) { return slots <
 
 template <int SLOTS, int MODE>
 __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub, const unsigned *tab, unsigned *cnt,
-                                NcScratch *sc, int curv_type, double *curv) {
+                                NcScratch *sc, const int *spilled, int curv_type, double *curv) {
+    const bool ovf = __builtin_amdgcn_readfirstlane(*spilled) != 0;  // uniform, in a scalar register
     const int lane = threadIdx.x & 63;
     const int p = sub + lane * nsub;
     int v = -1;
@@ -506,7 +551,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
             const int vg = __shfl(v, src < 0 ? 0 : src);
             int2 rvg = make_int2(__shfl(rv.x, src < 0 ? 0 : src), __shfl(rv.y, src < 0 ? 0 : src));
             if (src < 0) rvg.y = 0;
-            nc_edge_batch<SLOTS, B>(g, u, vg, rvg, tab, cnt, sc);
+            nc_edge_batch<SLOTS, B>(g, u, vg, rvg, tab, cnt, sc, ovf);
 #pragma unroll
             for (int b = 0; b < B; ++b)
                 if (lane == lsel[b]) {
@@ -523,7 +568,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
         todo &= todo - 1;
         const int ve = __shfl(v, l);
         const int2 rve = make_int2(__shfl(rv.x, l), __shfl(rv.y, l));
-        const NcEdge r = nc_edge<SLOTS, MODE>(g, u, ve, rve, tab, cnt, sc);
+        const NcEdge r = nc_edge<SLOTS, MODE>(g, u, ve, rve, tab, cnt, sc, ovf);
         if (lane == l) {
             sc->fin[lane][0] = r.T; sc->fin[lane][1] = r.s1; sc->fin[lane][2] = r.s2; sc->fin[lane][3] = r.gam;
             sc->fin[lane][4] = r.posu;
@@ -593,14 +638,15 @@ __global__ void __launch_bounds__(256, 6) k_nc_wave(View g, const int2 *units, c
                 if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;  // the plan keeps the load <= 1/2
                 const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
                 if (sub >= nsub) continue;
-                for (int i = lane; i < SLOTS; i += 64) tab[i] = EMPTY;
+                for (int i = lane; i < SLOTS; i += 64) tab[i] = NC_EMPTY;
+                if (lane == 0) sc->spilled = 0;
                 wave_sync();
                 for (int i = lane; i < ru.y; i += 64) {
                     const int k = g.col[ru.x + i];
-                    if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k);
+                    if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k, &sc->spilled);
                 }
                 wave_sync();
-                nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt, sc, curv_type, curv);
+                nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt, sc, &sc->spilled, curv_type, curv);
             }
             if (tr && lane == 0) tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
         }
@@ -644,17 +690,19 @@ __device__ inline void nc_block_units(const View &g, const int2 *units, const in
             __syncthreads();
             continue;
         }
-        for (int i = threadIdx.x; i < SLOTS; i += 64 * BW) tab[i] = EMPTY;
+        for (int i = threadIdx.x; i < SLOTS; i += 64 * BW) tab[i] = NC_EMPTY;
+        if (threadIdx.x == 0) sc_all[0].spilled = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < ru.y; i += 64 * BW) {
             const int k = g.col[ru.x + i];
-            if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k);
+            if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k, &sc_all[0].spilled);
         }
         __syncthreads();
         const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
         const int sub = sub0 + wid;
         if (wid < W && sub < nsub)
-            nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_base + wid * (SLOTS / 2), &sc_all[wid], curv_type, curv);
+            nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_base + wid * (SLOTS / 2), &sc_all[wid], &sc_all[0].spilled,
+                                  curv_type, curv);
         if (tr && (threadIdx.x & 63) == 0 && wid < W) tr[1] = (long long)__builtin_amdgcn_s_memrealtime();
         __syncthreads();  // the table and the unit index are rewritten by the next round
     }

@@ -80,6 +80,39 @@ def test_sdrf_traces_golden(fname):
         assert final.tolist() == case['final_edge_index'], label
 
 
+@pytest.mark.parametrize('fname', ['sdrf_grid_karate.json', 'sdrf_cora_shaped.json'])
+def test_sdrf_compact_fixtures(fname):
+    """The reference's own runs over the SURVEY §8(c) parameter grid and on the Cora-shaped graph (BASELINE.json
+    configs[1]: 50 iterations, Cora hyperparameters): traced path per iteration, production path on the final list."""
+    from dcr.data import Data
+    from rewiring.rewire import rewire
+    import torch
+    gold = load_golden(fname)
+    for case in gold['cases']:
+        g = gold['graphs'][case['graph']]
+        full = dict(case, edge_index=g['edge_index'], num_nodes=g['num_nodes'])
+        label = {k: case[k] for k in ('graph', 'curv_type', 'loops', 'removal_bound', 'tau', 'seed')}
+        if case['error']:
+            with pytest.raises(ValueError):
+                _run_case(full)
+            continue
+        trace, final = _run_case(full)
+        ref = case['iterations']
+        assert len(trace) == len(ref), label
+        for it, (a, b) in enumerate(zip(trace, ref)):
+            assert b['argmin'] is None or a['argmin'] == b['argmin'], (label, it)
+            assert len(a['candidates']) == b['n_candidates'], (label, it)
+            assert a['choice'] == b['choice'], (label, it)
+            assert a['added'] == b['added'], (label, it)
+            assert a['removed'] == b['removed'], (label, it)
+        assert final.tolist() == case['final_edge_index'], label
+        tau = float('inf') if case['tau'] == 'inf' else case['tau']
+        data = Data(edge_index=torch.tensor(g['edge_index']), num_nodes=g['num_nodes'])
+        np.random.seed(case['seed'])
+        assert rewire(data, case['curv_type'], case['loops'], case['removal_bound'], tau).tolist() == \
+            case['final_edge_index'], label
+
+
 def test_sdrf_untraced_paths_match_golden():
     """The production paths (no trace: candidates stay on the device; tau=inf: device arg-max) give the same
     final edge list as the traced path checked above."""

@@ -106,3 +106,36 @@ def test_sdrf_traces_python_oracle():
         final = sdrf_oracle.sdrf(np.array(case['edge_index']), case['num_nodes'], case['curv_type'], case['loops'],
                                  case.get('remove_edges', True), case['removal_bound'], tau, trace=trace)
         _check_trace(case, trace, final)
+
+
+def _check_compact(case, trace, final):
+    """Compact fixtures keep, per iteration, the selected edge, the candidate count, the drawn index and the edits."""
+    ref_iters = case['iterations']
+    assert len(trace) == len(ref_iters)
+    for it, (a, b) in enumerate(zip(trace, ref_iters)):
+        assert b['argmin'] is None or a['argmin'] == b['argmin'], it
+        assert len(a['candidates']) == b['n_candidates'], it
+        assert a['choice'] == b['choice'], it
+        assert a['added'] == b['added'], it
+        assert a['removed'] == b['removed'], it
+    assert final.tolist() == case['final_edge_index']
+
+
+@pytest.mark.parametrize('fname', ['sdrf_grid_karate.json', 'sdrf_cora_shaped.json'])
+def test_sdrf_compact_fixtures_c_oracle(fname):
+    """tau x removal_bound x loops x seed x curvature grid, and the Cora-shaped 50-iteration
+    run of BASELINE.json configs[0], both produced by the reference itself."""
+    gold = load_golden(fname)
+    for case in gold['cases']:
+        g = gold['graphs'][case['graph']]
+        tau = float('inf') if case['tau'] == 'inf' else case['tau']
+        trace = []
+        np.random.seed(case['seed'])
+        args = (np.array(g['edge_index']), g['num_nodes'], case['curv_type'], case['loops'],
+                case.get('remove_edges', True), case['removal_bound'], tau)
+        if case['error']:
+            with pytest.raises(ValueError):
+                c_oracle.sdrf(*args, trace=trace)
+            continue
+        final = c_oracle.sdrf(*args, trace=trace)
+        _check_compact(case, trace, final)

@@ -265,7 +265,9 @@ def _close_iter(cur, events, iters):
     iters.append(rec)
 
 
-def make_sdrf(cases, out_name):
+def make_sdrf(cases, out_name, compact=False):
+    """compact: keep per iteration only argmin / number of candidates / choice / added / removed (no candidate and
+    improvement vectors) so that a large parameter grid stays a small fixture."""
     cat = graph_catalog()
     out = {'_about': 'reference sdrf_no_cuda traces (bfc via bfc_naive.bfc_edge); float64 hex', 'cases': []}
     for c in cases:
@@ -276,7 +278,12 @@ def make_sdrf(cases, out_name):
                                             c['removal_bound'], tau, c['seed'])
         rec = dict(c)
         rec['num_nodes'] = n
-        rec['edge_index'] = ei.tolist()
+        if compact:
+            out.setdefault('graphs', {})[c['graph']] = {'num_nodes': n, 'edge_index': ei.tolist()}
+            iters = [{'argmin': it['argmin'], 'n_candidates': len(it['candidates']), 'choice': it['choice'],
+                      'added': it['added'], 'removed': it['removed']} for it in iters]
+        else:
+            rec['edge_index'] = ei.tolist()
         rec['iterations'] = iters
         rec['error'] = err
         rec['final_edge_index'] = None if final is None else final.tolist()
@@ -394,6 +401,19 @@ SDRF_CASES_MEDIUM = [
 ]
 
 
+# the full parameter grid on one small graph, compact records
+SDRF_CASES_GRID = [
+    {'graph': 'karate', 'curv_type': ct, 'loops': loops, 'removal_bound': rb, 'tau': tau, 'seed': seed}
+    for ct in ('bfc', '1d', 'augmented', 'haantjes') for tau in ('inf', 50, 163) for rb in (0.5, 0.95)
+    for loops in (10, 50) for seed in (0, 1, 2)
+]
+
+# BASELINE.json configs[0]/[1] on the Cora-shaped surrogate (Cora hyperparameters, hyperparams.py:8-10; 50 iterations)
+SDRF_CASES_CORA_SHAPED = [
+    {'graph': 'ba2485m2', 'curv_type': 'bfc', 'loops': 50, 'removal_bound': 0.95, 'tau': 163, 'seed': 0},
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
@@ -414,6 +434,10 @@ def main():
             make_sdrf(SDRF_CASES_SMALL, 'sdrf_traces_small.json')
         elif what == 'sdrf_medium':
             make_sdrf(SDRF_CASES_MEDIUM, 'sdrf_traces_medium.json')
+        elif what == 'sdrf_grid':
+            make_sdrf(SDRF_CASES_GRID, 'sdrf_grid_karate.json', compact=True)
+        elif what == 'sdrf_cora_shaped':
+            make_sdrf(SDRF_CASES_CORA_SHAPED, 'sdrf_cora_shaped.json', compact=True)
         elif what == 'timing':
             make_timing()
 

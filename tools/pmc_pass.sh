@@ -1,0 +1,5 @@
+#!/bin/bash
+# SQ counters of the curvature pass kernels: tools/pmc_pass.sh <tag>   (run on the GPU box from the repo root)
+cd /tmp && export TMPDIR=/tmp
+REPS=5 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d /tmp/pmc_$1 -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_pass.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_$1.log 2>&1 || exit 1
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_$1/p_counter_collection.csv k_nc_wave > $GRAFT_REPO_ROOT/gpurun_out/pmc_$1_summary.txt
