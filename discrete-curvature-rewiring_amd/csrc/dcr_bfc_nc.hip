@@ -136,6 +136,22 @@ __device__ inline unsigned cnt_add(unsigned *cnt, int h) {
 // unit.  Only when some lane of the wave-instruction has a match or a full home bucket does the wave branch into the
 // full lookup for that id: slot position, walk to the next bucket, validity of the entry (pieces are compared raw;
 // ids outside the row, slack included, can only cause a needless visit of the slow path), slot counter update.
+#ifdef NC_STATS  // diagnostic build (tools/build_variant.sh stats -DNC_STATS): how often the fast test fails
+__device__ unsigned long long nc_stats[8];
+#define NC_STATS_COUNT(look_any)                                                             \
+    {                                                                                        \
+        const unsigned long long act = __ballot(true), lk = __ballot(look_any);              \
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {                        \
+            atomicAdd(&nc_stats[0], 1ull);                                                   \
+            atomicAdd(&nc_stats[1], lk ? 1ull : 0ull);                                       \
+            atomicAdd(&nc_stats[2], (unsigned long long)__popcll(act));                      \
+            atomicAdd(&nc_stats[3], (unsigned long long)__popcll(lk));                       \
+        }                                                                                    \
+    }
+#else
+#define NC_STATS_COUNT(look_any)
+#endif
+
 template <int SLOTS>
 __device__ inline int nc_find_from(const uint4 *tb, unsigned b, uint4 e, unsigned key) {
     while (true) {
@@ -173,6 +189,7 @@ __device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, co
     bool look[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) look[j] = bucket_look(e[j], k[j], ovf, vskip);
+    NC_STATS_COUNT(look[0] | look[1] | look[2] | look[3])
     if (!__ballot(look[0] | look[1] | look[2] | look[3])) return 0u;  // uniform; the common case
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -381,6 +398,7 @@ __device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt
     bool look[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) look[j] = bucket_look(e[j], k[j], ovf, vskip);
+    NC_STATS_COUNT(look[0] | look[1] | look[2] | look[3])
     if (!__ballot(look[0] | look[1] | look[2] | look[3])) return 0u;  // uniform; the common case
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -591,12 +609,17 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
     }
 }
 
+// waves per SIMD the wave kernels are compiled for (measured on S100k: 5 -> 2.32 ms, 6 -> 2.05, 7 -> 2.23, 8 -> 2.39:
+// below 6 the load latency shows, above it the spills cost more than the extra waves hide)
+#ifndef NC_WAVE_OCC
+#define NC_WAVE_OCC 6
+#endif
 constexpr int NC_QUEUES = 8;         // dequeue cursors per wave-class kernel
 constexpr int NC_QUEUE_STRIDE = 32;  // ints between cursors: one 128-byte line each
 
 // ---- wave classes: a wave owns a node; persistent waves pull CHUNK nodes at a time ----------------------------
 template <int SLOTS, int MODE, int CHUNK>
-__global__ void __launch_bounds__(256, 6) k_nc_wave(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+__global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
                                                   int32_t *next, int curv_type, double *curv) {
     constexpr int WPB = 4;
     __shared__ __attribute__((aligned(16))) unsigned tab_all[WPB][SLOTS];
@@ -965,6 +988,16 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         }
     }
     DCR_HIP(hipGetLastError());
+#ifdef NC_STATS
+    {
+        unsigned long long h[8];
+        DCR_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(nc_stats), sizeof(h)));
+        fprintf(stderr, "[nc stats] piece probes (wave level) %llu, slow path %llu (%.1f%%), lanes active %.1f of 64, lanes with a candidate per slow probe %.2f\n",
+                h[0], h[1], 100.0 * h[1] / (h[0] ? h[0] : 1), (double)h[2] / (h[0] ? h[0] : 1), (double)h[3] / (h[1] ? h[1] : 1));
+        unsigned long long z[8] = {0};
+        DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nc_stats), z, sizeof(z)));
+    }
+#endif
     if (want_trace) {  // per class: when did the waves start / make their last progress (100 MHz ticks -> microseconds)
         std::vector<long long> h(NC_CLASSES * 16384 * 2);
         DCR_HIP(hipStreamSynchronize(g->stream));
