@@ -72,7 +72,7 @@ class CGraph:
             raise ValueError(f'dcro_graph_create failed ({rc})')
 
     def __del__(self):
-        if getattr(self, 'h', None):
+        if getattr(self, 'h', None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().dcro_graph_destroy(self.h)
             self.h = None
 

@@ -526,3 +526,49 @@ def test_two_pass_implementations_agree_at_scale(dcr):
         del G
     for a, b in zip(out['node'], out['edge']):
         assert a.shape[0] == ei.shape[1] // 2 and np.array_equal(a, b)
+
+
+def test_neighbour_ids_that_collide_in_the_lds_table(dcr, oracle):
+    """The node-centric pass keeps N(u) in an LDS hash set of 4-slot buckets (24-bit multiplicative hash) and tests
+    streamed ids against the home bucket only unless the table recorded a spill.  Here the neighbour ids of several
+    owners (one per table size class) are chosen to share their top hash bits, so buckets overflow into long chains:
+    the spill flag, the walk to following buckets and the fast test all have to agree with the oracle."""
+    n = 300000
+    ids = np.arange(n, dtype=np.uint64)
+    top12 = (((ids & 0xFFFFFF) * 0x9E3779) & 0xFFFFFF) >> 12          # bucket index of the largest table
+    order = np.argsort(top12, kind='stable')
+    groups = np.split(order, np.nonzero(np.diff(top12[order]))[0] + 1)
+    groups = [g for g in groups if len(g) >= 60][:8]
+    assert len(groups) == 8
+    rng = np.random.Generator(np.random.PCG64(4))
+    src, dst = [], []
+    owners = [7, 11, 13, 17]
+    sizes = [40, 60, 60, 60]                     # colliding neighbours per owner
+    pads = [0, 120, 700, 3000]                   # ordinary neighbours on top: classes 0, 1, 2, 3
+    for o, (own, sz, pad) in enumerate(zip(owners, sizes, pads)):
+        coll = [int(x) for x in groups[o][:sz] if int(x) not in owners]
+        rest = rng.choice(np.arange(20, n), size=pad, replace=False).tolist()
+        for k in coll + rest:
+            src.append(own); dst.append(k)
+        # edges among the colliding ids and to the ids of the next group: triangles and 4-cycles through the chains
+        for a, b in zip(coll[:-1], coll[1:]):
+            src.append(a); dst.append(b)
+        nxt = [int(x) for x in groups[o + 4][:sz]]
+        for a, b in zip(coll, nxt):
+            src.append(a); dst.append(b)
+            src.append(b); dst.append(coll[(coll.index(a) + 3) % len(coll)])
+    for a in range(len(owners)):
+        for b in range(a + 1, len(owners)):
+            src.append(owners[a]); dst.append(owners[b])
+    ex = rng.integers(20, n, size=(2, 20000))
+    src += ex[0].tolist(); dst += ex[1].tolist()
+    from dcr import synthetic
+    ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
+    G = dcr(ei, n)
+    C = oracle.CGraph(ei, n)
+    for ct in ('bfc', 'augmented', 'haantjes'):
+        eu, ev, cv = G.curvature_all(ct)
+        ou, ov, oc = C.curv_all(ct, nthreads=8)
+        assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
+        bad = np.nonzero(cv != oc)[0]
+        assert bad.size == 0, (ct, bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:5]])
