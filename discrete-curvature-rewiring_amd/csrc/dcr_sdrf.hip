@@ -11,6 +11,8 @@
 //   * j == y, i in DX: mirrored.
 //   * every other admissible pair leaves all ingredients unchanged: improvement = +0.0.
 #include "dcr_internal.h"
+#include <chrono>
+#include <cstdio>
 
 namespace dcr {
 
@@ -670,6 +672,10 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
     DCR_HIP(hipSetDevice(g->device));
+#ifdef DCR_IMP_TIMING
+    static double t_enq = 0, t_sync = 0; static long t_n = 0;
+    const auto T0 = std::chrono::steady_clock::now();
+#endif
     int dx, dy;
     if (g->am_valid && g->am_x == x && g->am_y == y) {  // the arg-min step already brought the degrees over
         dx = g->am_dx;
@@ -780,7 +786,16 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
         DCR_HIP(hipMemcpyAsync(g->imp_ci_h, g->imp_ci, sizeof(int32_t) * (size_t)upper, hipMemcpyDeviceToHost, g->stream));
         DCR_HIP(hipMemcpyAsync(g->imp_cj_h, g->imp_cj, sizeof(int32_t) * (size_t)upper, hipMemcpyDeviceToHost, g->stream));
     }
+#ifdef DCR_IMP_TIMING
+    const auto T1 = std::chrono::steady_clock::now();
+#endif
     DCR_TRY(sync_result(g));
+#ifdef DCR_IMP_TIMING
+    const auto T2 = std::chrono::steady_clock::now();
+    t_enq += std::chrono::duration<double, std::micro>(T1 - T0).count();
+    t_sync += std::chrono::duration<double, std::micro>(T2 - T1).count();
+    if (++t_n % 50 == 0) fprintf(stderr, "[imp timing] enqueue %.1f us, sync wait %.1f us (avg of %ld)\n", t_enq / t_n, t_sync / t_n, t_n);
+#endif
     const int64_t n = g->hres->n_cand;
     if (n < 0 || n > upper) DCR_FAIL(DCR_ESTATE, "candidate count outside its bound");
     g->imp_n = n;

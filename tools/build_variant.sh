@@ -7,8 +7,9 @@ name=$1; shift
 mkdir -p variants/$name
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -Wall -Wno-unused-function"
 for f in dcr_graph dcr_bfc dcr_bfc_nc dcr_sdrf dcr_gcn dcr_gemm; do
-  if [ $f = dcr_bfc_nc ] || [ ! -f $f.o ]; then /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o variants/$name/$f.o; else cp $f.o variants/$name/$f.o; fi
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o variants/$name/$f.o &
 done
+wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libdcr_hip_$name.so variants/$name/*.o
 rm -rf variants/$name
 echo built variants/libdcr_hip_$name.so
