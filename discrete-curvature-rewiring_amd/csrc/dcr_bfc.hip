@@ -739,6 +739,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
     DCR_HIP(hipSetDevice(g->device));
+    g->amax_valid = false;
     // incremental is only sound on top of a complete buffer of the same curvature kind whose later edits were all
     // recorded in the dirty flags (dcr_graph_add_edge / _remove_edge / dcr_sdrf_tail do that)
     const bool incremental = want_incremental && g->curv_valid && g->curv_type_last == curv_type && g->dirty_tracked;

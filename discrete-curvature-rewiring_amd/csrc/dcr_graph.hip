@@ -444,6 +444,7 @@ int dcr_graph_add_edge(dcr_graph *g, int32_t u, int32_t v) {
     DCR_TRY(check_pair(g, u, v));
     DCR_HIP(hipSetDevice(g->device));
     g->am_valid = false;
+    g->amax_valid = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_add_edge(g, u, v);
         DCR_HIP(hipGetLastError());
@@ -464,6 +465,7 @@ int dcr_graph_remove_edge(dcr_graph *g, int32_t u, int32_t v) {
     DCR_TRY(check_pair(g, u, v));
     DCR_HIP(hipSetDevice(g->device));
     g->am_valid = false;
+    g->amax_valid = false;
     launch_mark_dirty(g, u, v);
     hipLaunchKernelGGL(k_remove_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, u, v, g->dres);
     DCR_HIP(hipGetLastError());

@@ -94,6 +94,7 @@ struct dcr_graph {
     // degrees of the last arg-min edge as seen by the device; dropped by any edit
     int32_t am_x = -1, am_y = -1, am_dx = 0, am_dy = 0;
     bool am_valid = false;
+    bool amax_valid = false;  // the result block holds the stale arg-max of the current graph (computed ahead of the tail)
 
     int curv_type_last = -1;
     bool curv_valid = false;

@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int np
 constexpr int ARGEXT_BLOCKS = 1024;
 
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
+    g->amax_valid = false;  // the ext fields of the result block are about to be overwritten
     if (!g->red_scratch) {
         Ext *p = nullptr;
         DCR_TRY(dev_alloc(&p, ARGEXT_BLOCKS));
@@ -800,6 +801,13 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     if (n < 0 || n > upper) DCR_FAIL(DCR_ESTATE, "candidate count outside its bound");
     g->imp_n = n;
     *n_out = n;
+    // The removal step looks for the highest STALE curvature (sdrf_no_cuda.py:57-61), which does not depend on the edge
+    // about to be drawn (that one is excluded there only because it has no stale value): compute it now, while the host
+    // draws, and let dcr_sdrf_tail* pick it up.  Any pass or edit in between drops it.
+    if (g->curv_valid && n > 0) {
+        DCR_TRY(launch_argext(g, 1, -1, -1));
+        g->amax_valid = true;
+    }
     if (out_improvement) *out_improvement = n > 0 ? g->imp_out_h : nullptr;
     if (out_ci) *out_ci = (n > 0 && want_candidates) ? g->imp_ci_h : nullptr;
     if (out_cj) *out_cj = (n > 0 && want_candidates) ? g->imp_cj_h : nullptr;
@@ -874,11 +882,13 @@ static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_rem
     }
     DCR_HIP(hipSetDevice(g->device));
     g->am_valid = false;
+    const bool have_amax = g->amax_valid;  // computed on this graph before the add: nothing to exclude
+    g->amax_valid = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_add_edge(g, add_k, add_l);
         launch_mark_dirty(g, add_k, add_l);  // after the append: the new neighbours are flagged too
         if (do_remove) {
-            DCR_TRY(launch_argext(g, 1, adding ? add_k : -1, adding ? add_l : -1));
+            if (!(have_amax && attempt == 0)) DCR_TRY(launch_argext(g, 1, adding ? add_k : -1, adding ? add_l : -1));
             launch_remove_if_above(g, removal_bound);
         }
         DCR_HIP(hipGetLastError());
