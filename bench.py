@@ -56,14 +56,17 @@ def cpu_baseline(ei, n, E, budget_s=12.0):
     imp_s = 0.0
     if k:
         sel = np.sort(rng.choice(n_cand, size=k, replace=False))
-        t0 = time.perf_counter()
-        C.improvements(x, y, ci[sel], cj[sel], 'bfc')
-        imp_s = (time.perf_counter() - t0) * n_cand / k
+        best = float('inf')
+        for _ in range(5):  # single-threaded and short: the fastest of five is the least disturbed by other tenants
+            t0 = time.perf_counter()
+            C.improvements(x, y, ci[sel], cj[sel], 'bfc')
+            best = min(best, time.perf_counter() - t0)
+        imp_s = best * n_cand / k
     iter_s = pass_s + imp_s
     return {
         'value': 1.0 / iter_s, 'unit': 'SDRF iterations/sec', 'cores': cores, 'kind': 'port',
         'sample': f'BFC pass over {n_sample} of {E} randomly sampled edges on {cores} threads (extrapolated x{E / n_sample:.1f}) '
-                  f'+ {k} of {n_cand} candidate improvements of edge ({x},{y}) on 1 thread (extrapolated)',
+                  f'+ {k} of {n_cand} candidate improvements of edge ({x},{y}) on 1 thread (fastest of 5 runs, extrapolated)',
         'bfc_edges_per_sec': edges_per_s, 'pass_seconds_extrapolated': pass_s, 'improvements_seconds_extrapolated': imp_s,
     }
 
@@ -316,12 +319,12 @@ def main():
                          'kernel': 'curvature pass = k_nc_plan + k_nc_wave<256|512> + k_nc_block<2048|8192>',
                          'algorithmic_bytes_per_launch': alg_bytes, 'launch_ms': pass_ms, 'launches': pass_count},
         }
-        pmc = os.path.join(REPO, 'profiles', 'r01_v6_pmc_traffic.json')
+        pmc = os.path.join(REPO, 'profiles', 'r01_v7_pmc_traffic.json')
         if os.path.exists(pmc) and args.nodes == 100000 and args.m == 10:
             # HBM-side bytes per pass from a separate rocprofv3 --pmc run (counters cannot be read in-process)
             with open(pmc) as f:
                 out['roofline']['traffic'] = json.load(f)['traffic_bytes_per_pass']
-            out['roofline']['traffic_source'] = 'profiles/r01_v6_pmc_traffic.json'
+            out['roofline']['traffic_source'] = 'profiles/r01_v7_pmc_traffic.json'
             # what the fabric actually moved per pass (separate PMC run) over this run's pass time, as a share of peak
             out['roofline']['traffic_frac'] = out['roofline']['traffic'] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
             out['roofline']['note'] = ('algorithmic bytes follow SURVEY 8(d), which charges both sides of the 4-cycle '
