@@ -28,6 +28,7 @@ constexpr unsigned KEY_MASK = (1u << 30) - 1u;
 
 struct WorkLists {
     int32_t *w[NBINS];
+    int32_t *giant;  // records of the edges no bin can hold (nullptr: report them as too big)
 };
 
 // keys (= du + dv + 2) admitted per bin: load factor <= 1/4 except the last bin (<= 1/2)
@@ -522,7 +523,7 @@ __global__ void __launch_bounds__(TEAM) k_edge_single(View g, int u, int v, int6
 constexpr int CLASSIFY_CHUNK = 4096;
 
 __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total, int curv_type, int mode, double *curv,
-                                    DevResult *res, double *bytes_total, bool finish_trivial) {
+                                    DevResult *res, double *bytes_total, bool finish_trivial, int32_t *giant) {
     if (s >= cap_total) return -1;
     const int u = g.slot_row[s];
     const int2 ru = g.rowinfo[u];
@@ -547,8 +548,18 @@ __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total,
     int bin = NBINS;
     for (int b = NBINS - 1; b >= 0; --b)
         if (keys <= bin_max_keys(b)) bin = b;
-    if (bin == NBINS) {
-        res->flag_too_big = 1;
+    if (bin == NBINS) {  // beyond the largest LDS table: listed for the device-memory path (dcr_bfc_giant.hip)
+        if (mode == MODE_BYTES || !giant) {
+            res->flag_too_big = 1;
+        } else if (finish_trivial) {
+            const int idx = atomicAdd(&res->giant_count, 1);
+            if (idx < GIANT_LIST_CAP) {
+                int32_t *r = giant + (size_t)idx * 5;
+                r[0] = (int32_t)s; r[1] = u; r[2] = v; r[3] = du; r[4] = dv;
+            } else {
+                res->flag_too_big = 1;
+            }
+        }
         return -1;
     }
     return bin;
@@ -565,7 +576,7 @@ __global__ void __launch_bounds__(256) k_classify(View g, int64_t cap_total, int
     // phase 1: count per bin (and finish the trivial edges)
     int mycnt[NBINS] = {0, 0, 0, 0, 0};
     for (int o = threadIdx.x; o < CLASSIFY_CHUNK; o += 256) {
-        const int bin = classify_slot(g, chunk0 + o, cap_total, curv_type, mode, curv, res, bytes_total, true);
+        const int bin = classify_slot(g, chunk0 + o, cap_total, curv_type, mode, curv, res, bytes_total, true, wl.giant);
 #pragma unroll
         for (int b = 0; b < NBINS; ++b) mycnt[b] += (bin == b);
     }
@@ -585,7 +596,7 @@ __global__ void __launch_bounds__(256) k_classify(View g, int64_t cap_total, int
     // phase 2: write the items
     for (int o = threadIdx.x; o < CLASSIFY_CHUNK; o += 256) {
         const int64_t s = chunk0 + o;
-        const int bin = classify_slot(g, s, cap_total, curv_type, mode, curv, res, bytes_total, false);
+        const int bin = classify_slot(g, s, cap_total, curv_type, mode, curv, res, bytes_total, false, wl.giant);
 #pragma unroll
         for (int b = 0; b < NBINS; ++b) {
             const unsigned long long m = __ballot(bin == b);
@@ -605,7 +616,10 @@ __global__ void k_clear_counts(DevResult *res, int keep_guard) {
         res->work_count[threadIdx.x] = 0;
         res->work_next[threadIdx.x] = 0;
     }
-    if (threadIdx.x == 0) res->flag_too_big = 0;
+    if (threadIdx.x == 0) {
+        res->flag_too_big = 0;
+        res->giant_count = 0;
+    }
 }
 
 static int ensure_work(dcr_graph *g) {
@@ -649,6 +663,10 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incre
             (int32_t)g->n, nc_rest ? 1 : 0, nullptr};
     WorkLists wl;
     for (int b = 0; b < NBINS; ++b) wl.w[b] = g->work[b];
+    // can an edge exceed the largest table at all?  (max_deg_bound is an upper bound of every degree)
+    const bool giant_possible = MODE != MODE_BYTES && 2 * (int64_t)g->max_deg_bound + 2 > bin_max_keys(NBINS - 1);
+    if (giant_possible && !g->giant_list) DCR_TRY(dev_alloc(&g->giant_list, (int64_t)GIANT_LIST_CAP * 5));
+    wl.giant = giant_possible ? g->giant_list : nullptr;
     if (g->num_cu <= 0) {
         g->num_cu = 256;
         hipDeviceProp_t prop;
@@ -683,6 +701,7 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incre
         }
     }
     DCR_HIP(hipGetLastError());
+    if (giant_possible) DCR_TRY(process_giant_edges(g, curv_type));
     return DCR_OK;
 }
 
@@ -764,7 +783,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
         DCR_FAIL(DCR_EHIP, buf);
     }
     if (g->hres->flag_too_big)
-        DCR_FAIL(DCR_ECAPACITY, "an edge has deg(u)+deg(v)+2 > 16384: beyond the LDS table of the largest bin");
+        DCR_FAIL(DCR_ECAPACITY, "more than 65536 edges with deg(u)+deg(v)+2 > 16384 (beyond every LDS table) in one pass");
     g->curv_type_last = curv_type;
     g->curv_valid = true;
     return DCR_OK;
@@ -786,9 +805,12 @@ int dcr_bfc_ingredients(dcr_graph *g, int32_t u, int32_t v, int64_t out6[6]) {
     else if (keys <= bin_max_keys(2)) launch_single<2>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(3)) launch_single<3>(g, vw, u, v, d_out);
     else if (keys <= bin_max_keys(4)) launch_single<4>(g, vw, u, v, d_out);
-    else {
-        (void)hipFree(d_out);
-        DCR_FAIL(DCR_ECAPACITY, "deg(u)+deg(v)+2 > 16384");
+    else {  // beyond every LDS table: device-memory path (the pair must be an edge for its flags to mean anything)
+        int rc = giant_edge(g, u, v, du, dv, -1, DCR_CURV_BFC, true, d_out);
+        if (rc != DCR_OK) {
+            (void)hipFree(d_out);
+            return rc;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out6, d_out, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream);

@@ -36,6 +36,7 @@ void set_error(const std::string &msg);
 // An undirected edge (u,v) needs an LDS hash set over N(u) ∪ N(v) ∪ {u,v}; the bin is chosen by
 // that size so the table keeps a load factor <= 1/4 (1/2 in the last bin).  Threads per edge ("team") grow with the bin.
 constexpr int NBINS = 5;
+constexpr int GIANT_LIST_CAP = 65536;  // edges beyond every LDS table that one pass can list
 constexpr int BIN_SLOTS[NBINS] = {128, 512, 2048, 4096, 32768};
 constexpr int BIN_TEAM[NBINS] = {64, 64, 256, 512, 1024};
 constexpr int MAX_TABLE_KEYS = BIN_SLOTS[NBINS - 1] / 2;  // du + dv + 2 must not exceed this
@@ -57,7 +58,8 @@ struct DevResult {
     int32_t nc_next[5];        // dequeue cursors of its kernels
     int32_t nc_bucket[16];     // units per degree bucket (plan phase 0)
     int32_t nc_fill[16];       // placement cursors per bucket (plan phase 1)
-    int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS
+    int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS and could not be put on the giant list either
+    int32_t giant_count;  // edges beyond every LDS table, listed for the device-memory path (dcr_bfc_giant.hip)
     int64_t n_cand;
     int64_t imp_argmax;
     int32_t cand_i, cand_j;
@@ -110,6 +112,13 @@ struct dcr_graph {
     int64_t nc_touch_cap = 0;
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
     int pass_impl = 0;            // 0: node-centric (default), 1: edge-centric kernels only (DCR_PASS=edge)
+
+    // edges beyond every LDS table (dcr_bfc_giant.hip): records {slot, u, v, deg u, deg v}; position map over all ids
+    int32_t *giant_list = nullptr;
+    int32_t *giant_pos = nullptr;
+    uint32_t *giant_cnt = nullptr;
+    int64_t giant_cnt_cap = 0;
+    int32_t *giant_acc = nullptr;
 
     // curvature-pass work lists (edge-centric kernels)
     int32_t *work[dcr::NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -166,7 +175,9 @@ void launch_remove_if_above(dcr_graph *g, double bound);           // acts on th
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v);         // flag {u,v} ∪ N(u) ∪ N(v)
 
 // dcr_sdrf.hip
-int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v);  // result in DevResult after the next sync
+int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v);
+int process_giant_edges(dcr_graph *g, int curv_type);  // dcr_bfc_giant.hip; syncs once
+int giant_edge(dcr_graph *g, int u, int v, int du, int dv, int64_t slot, int curv_type, bool need_cycles, int64_t *d_out6);  // result in DevResult after the next sync
 
 // dcr_bfc.hip
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental);

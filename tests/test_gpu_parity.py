@@ -572,3 +572,43 @@ def test_neighbour_ids_that_collide_in_the_lds_table(dcr, oracle):
         assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
         bad = np.nonzero(cv != oc)[0]
         assert bad.size == 0, (ct, bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:5]])
+
+
+def test_edges_beyond_every_lds_table(dcr, oracle):
+    """Hubs joined to each other whose degrees exceed every table (12,000 + 11,000 + 2 > 16,384 keys, and one hub with
+    17,000 neighbours): those edges take the device-memory path (csrc/dcr_bfc_giant.hip).  Whole pass, single-edge
+    queries and an incremental pass after an edit, bit-compared with the oracle."""
+    n = 40000
+    rng = np.random.Generator(np.random.PCG64(21))
+    src, dst = [], []
+    hubs = [(0, 12000), (1, 11000), (2, 17000), (3, 9000)]
+    for hub, d in hubs:
+        leaves = rng.choice(np.arange(10, n), size=d, replace=False)
+        src += [hub] * d; dst += leaves.tolist()
+    for a in range(4):
+        for b in range(a + 1, 4):
+            src.append(a); dst.append(b)
+    extra = rng.integers(10, n, size=(2, 30000))       # leaf-leaf edges: 4-cycles through the hubs
+    src += extra[0].tolist(); dst += extra[1].tolist()
+    from dcr import synthetic
+    ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
+    G = dcr(ei, n)
+    C = oracle.CGraph(ei, n)
+    assert G.degree(0) + G.degree(1) + 2 > 16384 and G.degree(2) > 16382
+    for ct in ('bfc', 'augmented', 'haantjes', '1d'):
+        eu, ev, cv = G.curvature_all(ct)
+        ou, ov, oc = C.curv_all(ct, nthreads=8)
+        assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
+        bad = np.nonzero(cv != oc)[0]
+        assert bad.size == 0, (ct, bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:5]])
+    for (a, b) in ((0, 1), (2, 0), (1, 2), (3, 2)):
+        assert G.curvature_edge(a, b) == C.curv_edge(a, b), (a, b)
+    G.curvature_pass('bfc')
+    G.remove_edge(0, 1); C.remove_edge(0, 1)
+    k = next(int(x) for x in range(10, n) if not C.has_edge(2, int(x)))
+    G.add_edge(2, k); C.add_edge(2, k)
+    G.curvature_pass('bfc', incremental=True)
+    eu, ev, cv = G.curvature_read()
+    oc = C.curv_all('bfc', nthreads=8)[2]
+    bad = np.nonzero(cv != oc)[0]
+    assert bad.size == 0, (bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:5]])
