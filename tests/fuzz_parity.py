@@ -20,6 +20,18 @@ n_graphs = n_edges_checked = n_sdrf = 0
 
 def random_graph():
     kind = rng.integers(0, 6)
+    if rng.random() < 0.04:  # hubs joined to each other with degrees beyond the LDS tables (device-memory path)
+        n = int(rng.integers(20000, 45000)); hubs = int(rng.integers(2, 4))
+        src, dst = [], []
+        for h in range(hubs):
+            d = int(rng.integers(7000, min(18000, n - 100)))
+            src += [h] * d; dst += rng.choice(np.arange(hubs, n), size=d, replace=False).tolist()
+        for a in range(hubs):
+            for b in range(a + 1, hubs):
+                src.append(a); dst.append(b)
+        ex = rng.integers(hubs, n, (2, int(rng.integers(0, 2 * n))))
+        return synthetic.coalesced_edge_index(np.concatenate([np.array(src), ex[0]]),
+                                              np.concatenate([np.array(dst), ex[1]]), n), n
     if kind == 0:
         n = int(rng.integers(5, 400)); p = float(rng.uniform(0.01, 0.3))
         return synthetic.erdos_renyi_graph(n, p, seed=int(rng.integers(1 << 30)))
