@@ -80,7 +80,7 @@ def test_sdrf_traces_golden(fname):
         assert final.tolist() == case['final_edge_index'], label
 
 
-@pytest.mark.parametrize('fname', ['sdrf_grid_karate.json'])
+@pytest.mark.parametrize('fname', ['sdrf_grid_karate.json', 'sdrf_cora_shaped.json'])
 def test_sdrf_compact_fixtures(fname):
     """The reference's own runs over the SURVEY §8(c) parameter grid and on the Cora-shaped graph (BASELINE.json
     configs[1]: 50 iterations, Cora hyperparameters): traced path per iteration, production path on the final list."""

@@ -121,7 +121,7 @@ def _check_compact(case, trace, final):
     assert final.tolist() == case['final_edge_index']
 
 
-@pytest.mark.parametrize('fname', ['sdrf_grid_karate.json'])
+@pytest.mark.parametrize('fname', ['sdrf_grid_karate.json', 'sdrf_cora_shaped.json'])
 def test_sdrf_compact_fixtures_c_oracle(fname):
     """tau x removal_bound x loops x seed x curvature grid, and the Cora-shaped 50-iteration
     run of BASELINE.json configs[0], both produced by the reference itself."""
