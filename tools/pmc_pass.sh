@@ -1,5 +1,8 @@
 #!/bin/bash
-# SQ counters of the curvature pass kernels: tools/pmc_pass.sh <tag>   (run on the GPU box from the repo root)
+# SQ counters of the curvature pass kernels (two sets, separate runs): tools/pmc_pass.sh <tag>
+# (run on the GPU box from the repo root; writes gpurun_out/<tag>_pmc_sq_{insts,waits}.txt)
 cd /tmp && export TMPDIR=/tmp
-REPS=5 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d /tmp/pmc_$1 -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_pass.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_$1.log 2>&1 || exit 1
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_$1/p_counter_collection.csv k_nc_wave > $GRAFT_REPO_ROOT/gpurun_out/pmc_$1_summary.txt
+REPS=5 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d /tmp/pmca_$1 -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_pass.py > $GRAFT_REPO_ROOT/gpurun_out/$1_pmc_a.log 2>&1 || exit 1
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmca_$1/p_counter_collection.csv k_nc > $GRAFT_REPO_ROOT/gpurun_out/$1_pmc_sq_insts.txt
+REPS=5 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmcb_$1 -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_pass.py > $GRAFT_REPO_ROOT/gpurun_out/$1_pmc_b.log 2>&1 || exit 1
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmcb_$1/p_counter_collection.csv k_nc > $GRAFT_REPO_ROOT/gpurun_out/$1_pmc_sq_waits.txt
