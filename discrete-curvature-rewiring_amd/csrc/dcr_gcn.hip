@@ -210,7 +210,9 @@ __device__ inline void philox4x32_10(uint64_t index, uint64_t offset, uint64_t s
 // thread t owns elements 4t .. 4t+3; wave w stores the four keep-ballots of its 256 elements in bits[4w .. 4w+3]
 __global__ void __launch_bounds__(256) k_relu_dropout_fwd(const float *__restrict__ x, float *__restrict__ y,
                                                            unsigned long long *__restrict__ bits, int64_t n, float scale,
-                                                           uint32_t threshold, uint64_t seed, uint64_t offset) {
+                                                           uint32_t threshold, uint64_t seed, uint64_t offset,
+                                                           const uint64_t *__restrict__ offset_dev) {
+    if (offset_dev) offset += *offset_dev;  // call counter kept in device memory: the launch can be replayed from a hipGraph
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t e0 = t * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -280,8 +282,9 @@ extern "C" int dcr_relu_dropout_bits_words(int64_t n, int64_t *out_words) {
     return DCR_OK;
 }
 
-extern "C" int dcr_relu_dropout_fwd_f32_dev(const float *x, float *y, uint64_t *bits, int64_t n, double p, uint64_t seed,
-                                            uint64_t offset, void *hip_stream) {
+extern "C" int dcr_relu_dropout_fwd_f32_ctr_dev(const float *x, float *y, uint64_t *bits, int64_t n, double p,
+                                                uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                                                void *hip_stream) {
     if (!x || !y || !bits || n < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad relu_dropout arguments");
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) DCR_FAIL(DCR_EINVAL, "relu_dropout: 16-byte aligned tensors expected");
     if (n == 0) return DCR_OK;
@@ -289,9 +292,14 @@ extern "C" int dcr_relu_dropout_fwd_f32_dev(const float *x, float *y, uint64_t *
     const double th = p * 4294967296.0;
     const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
     hipLaunchKernelGGL(k_relu_dropout_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, x, y,
-                       (unsigned long long *)bits, n, (float)(1.0 / (1.0 - p)), threshold, seed, offset);
+                       (unsigned long long *)bits, n, (float)(1.0 / (1.0 - p)), threshold, seed, offset, offset_dev);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
+}
+
+extern "C" int dcr_relu_dropout_fwd_f32_dev(const float *x, float *y, uint64_t *bits, int64_t n, double p, uint64_t seed,
+                                            uint64_t offset, void *hip_stream) {
+    return dcr_relu_dropout_fwd_f32_ctr_dev(x, y, bits, n, p, seed, offset, nullptr, hip_stream);
 }
 
 extern "C" int dcr_relu_dropout_bwd_f32_dev(const float *grad_out, float *grad_in, const uint64_t *bits, int64_t n,

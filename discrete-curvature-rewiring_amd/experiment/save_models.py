@@ -47,9 +47,10 @@ def hyperparams_for(dname):
 def build_model_and_optimizer(dataset, hp, device):
     model = GCN(dataset=dataset, hidden=[hp['hidden_dim']] * hp['hidden_depth'], dropout=hp['dropout']).to(device)
     # weight decay on the first layer's parameters only (save_models.py:78-82)
+    # capturable: the step can then be part of the captured HIP graph of an epoch (experiment/training_loop.py)
     optimizer = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
                                   {'params': model.reg_params, 'weight_decay': hp['weight_decay']}],
-                                 lr=hp['learning_rate'])
+                                 lr=hp['learning_rate'], capturable=torch.device(device).type == 'cuda')
     return model, optimizer
 
 

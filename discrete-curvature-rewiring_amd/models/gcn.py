@@ -186,7 +186,16 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
-_dropout_calls = 0  # offset of the Philox stream: one step per fused ReLU+dropout call of the process
+_dropout_ctr = {}  # per device: int64 call counter IN DEVICE MEMORY = offset of the Philox stream (one step per fused
+#                    ReLU+dropout call).  On the device so that a captured hipGraph of the training step draws a new
+#                    mask at every replay: the launch parameters stay constant, the counter moves.
+
+
+def _dropout_counter(device):
+    key = str(device)
+    if key not in _dropout_ctr:
+        _dropout_ctr[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _dropout_ctr[key]
 
 
 class _ReluDropoutFn(torch.autograd.Function):
@@ -194,7 +203,6 @@ class _ReluDropoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, p):
-        global _dropout_calls
         from dcr import _lib
         x = x.contiguous()
         n = x.numel()
@@ -202,11 +210,12 @@ class _ReluDropoutFn(torch.autograd.Function):
         _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n, ctypes.byref(words)))
         bits = torch.empty(max(words.value, 1), dtype=torch.int64, device=x.device)
         y = torch.empty_like(x)
-        _dropout_calls += 1
+        ctr = _dropout_counter(x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(_lib.lib().dcr_relu_dropout_fwd_f32_dev(x.data_ptr(), y.data_ptr(), bits.data_ptr(), n, float(p),
-                                                           torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_calls,
-                                                           ctypes.c_void_p(stream)))
+        _lib.check(_lib.lib().dcr_relu_dropout_fwd_f32_ctr_dev(x.data_ptr(), y.data_ptr(), bits.data_ptr(), n, float(p),
+                                                               torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0,
+                                                               ctr.data_ptr(), ctypes.c_void_p(stream)))
+        ctr.add_(1)
         ctx.bits, ctx.p = bits, float(p)
         return y
 

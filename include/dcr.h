@@ -166,6 +166,10 @@ int dcr_atb_f32_dev(const float *A_dev, const float *B_dev, float *C_dev, int64_
 int dcr_relu_dropout_bits_words(int64_t n, int64_t *out_words);
 int dcr_relu_dropout_fwd_f32_dev(const float *x_dev, float *y_dev, uint64_t *bits_dev, int64_t n, double p, uint64_t seed,
                                  uint64_t offset, void *hip_stream);
+/* the same with the stream offset = offset + *offset_dev (a call counter the caller keeps in device memory and bumps
+ * after each call): the launch parameters are then constants, so the call can be captured in a hipGraph and replayed */
+int dcr_relu_dropout_fwd_f32_ctr_dev(const float *x_dev, float *y_dev, uint64_t *bits_dev, int64_t n, double p,
+                                     uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *hip_stream);
 int dcr_relu_dropout_bwd_f32_dev(const float *grad_out_dev, float *grad_in_dev, const uint64_t *bits_dev, int64_t n,
                                  double p, void *hip_stream);
 

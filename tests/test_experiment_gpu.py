@@ -72,3 +72,62 @@ def test_redo_rewiring_writes_one_edge_list_per_seed(tmp_path):
                 epochs=3, verbose=False)
     folder = os.path.join(tmp, 'edge_indices', 'Tiny_redo_rewiring', 'augmented')
     assert sorted(os.listdir(folder)) == ['edge_index_augmented_00.pk', 'edge_index_augmented_01.pk']
+
+
+@pytest.mark.gpu
+def test_graphed_epochs_equal_eager_epochs():
+    """experiment/training_loop.py replays the training step and the validation forward as captured HIP graphs after
+    three eager epochs.  Same kernels in the same order: with dropout off (no random stream involved) the weights and
+    the validation accuracies after 12 epochs are identical to 12 eager epochs; with dropout on the masks must differ
+    from replay to replay (the Philox call counter lives in device memory)."""
+    import copy
+    import torch
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from experiment.training_loop import GraphedEpoch, evaluate, make_epoch, train
+    from models.gcn import GCN
+    dev = torch.device('cuda')
+    ei_np, n = synthetic.powerlaw_graph(1500, 3, seed=5)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(n, 96, device=dev, generator=g)
+    y = torch.randint(0, 5, (n,), device=dev, generator=g)
+    r = torch.rand(n, device=dev, generator=g)
+    data = Data(x=x, edge_index=torch.from_numpy(ei_np).to(dev), y=y, num_nodes=n, train_mask=r < 0.3,
+                val_mask=(r >= 0.3) & (r < 0.6))
+
+    def build(dropout):
+        torch.manual_seed(3)
+        model = GCN(Dataset(data, 5), hidden=[32], dropout=dropout).to(dev)
+        opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                                {'params': model.reg_params, 'weight_decay': 5e-3}], lr=0.02, capturable=True)
+        return model, opt
+
+    m1, o1 = build(0.0)
+    accs_eager = []
+    for _ in range(12):
+        train(m1, o1, data)
+        accs_eager.append(evaluate(m1, data, test=False)['val_acc'])
+    m2, o2 = build(0.0)
+    epoch = make_epoch(m2, o2, data)
+    assert isinstance(epoch, GraphedEpoch)
+    accs_graph = [epoch() for _ in range(12)]
+    assert epoch.train_graph is not None
+    assert accs_graph == accs_eager
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    # dropout on: every replay must draw a fresh mask -> the loss sequence is not periodic / constant
+    m3, o3 = build(0.5)
+    epoch3 = make_epoch(m3, o3, data)
+    before = None
+    changed = 0
+    for i in range(10):
+        epoch3()
+        if i >= GraphedEpoch.WARMUP + 1:
+            cur = float(epoch3.loss.detach())
+            changed += before is not None and cur != before
+            before = cur
+    assert changed >= 4
+    # without a capturable optimiser the loop stays eager
+    m4 = GCN(Dataset(data, 5), hidden=[32], dropout=0.0).to(dev)
+    o4 = torch.optim.Adam(m4.parameters(), lr=0.01)
+    assert not isinstance(make_epoch(m4, o4, data), GraphedEpoch)
