@@ -532,7 +532,7 @@ __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total,
     if (v <= u) return -1;
     if (g.dirty && !(g.dirty[u] | g.dirty[v])) return -1;  // untouched neighbourhood: the stored value is still exact
     const int dv = g.rowinfo[v].y, du = ru.y;
-    if (g.nc_handles && nc_takes(du, dv)) return -1;  // the node-centric kernels own this edge
+    if (g.nc_handles && (nc_takes(du, dv) || hub_takes(du, dv))) return -1;  // the node-centric / hub kernels own this edge
     if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
         if (finish_trivial) curv[s] = (double)(4 - du - dv);
         return -1;
@@ -715,8 +715,9 @@ int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental) {
     // than NC_MAXD neighbours each), which cannot exist while the largest degree is within the limit
     DCR_TRY(launch_curvature_pass_nc(g, curv_type, incremental));
     if (g->max_deg_bound > NC_MAXD) {
-        if (curv_type == DCR_CURV_BFC) return run_pass<MODE_BFC>(g, curv_type, nullptr, incremental, true);
-        return run_pass<MODE_TRI>(g, curv_type, nullptr, incremental, true);
+        if (curv_type == DCR_CURV_BFC) DCR_TRY(run_pass<MODE_BFC>(g, curv_type, nullptr, incremental, true));
+        else DCR_TRY(run_pass<MODE_TRI>(g, curv_type, nullptr, incremental, true));
+        DCR_TRY(process_hub_edges(g, curv_type, incremental));  // hub-to-small-node edges (dcr_bfc_giant.hip)
     }
     return DCR_OK;
 }

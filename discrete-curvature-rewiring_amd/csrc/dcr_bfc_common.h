@@ -72,7 +72,17 @@ constexpr int NC_CLASSES = 5;
 constexpr int NC_MAXD = 8190;       // largest degree whose neighbour table fits the biggest class
 constexpr int NC_MAXOTHER = 16382;  // largest degree of the other endpoint (15-bit per-slot counters)
 
+// Edges between a hub above every table size and a node of moderate degree are swept from the hub's side with a
+// position map in device memory (dcr_bfc_giant.hip, k_hub_edges): the rows streamed are then those of the small
+// endpoint's neighbours.  (Owned by the small endpoint they would stream every neighbour row of the hub, per edge.)
+constexpr int HUB_OTHER_MAX = 1022;
+__device__ __host__ inline bool hub_takes(int da, int db) {
+    const int dmax = da > db ? da : db, dmin = da < db ? da : db;
+    return dmax > NC_MAXD && dmin <= HUB_OTHER_MAX;
+}
+
 __device__ __host__ inline bool nc_takes(int da, int db) {
+    if (hub_takes(da, db)) return false;
     const int dmin = da < db ? da : db, dmax = da < db ? db : da;
     return dmin <= NC_MAXD && dmax <= NC_MAXOTHER;
 }

@@ -401,7 +401,7 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
                         g->imp_stats, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
                         g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
-                        g->giant_pos, g->giant_cnt, g->giant_acc};
+                        g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)

@@ -60,6 +60,7 @@ struct DevResult {
     int32_t nc_fill[16];       // placement cursors per bucket (plan phase 1)
     int32_t flag_too_big; // an edge exceeded MAX_TABLE_KEYS and could not be put on the giant list either
     int32_t giant_count;  // edges beyond every LDS table, listed for the device-memory path (dcr_bfc_giant.hip)
+    int32_t hub_count;    // nodes with more neighbours than the largest table (k_find_hubs)
     int64_t n_cand;
     int64_t imp_argmax;
     int32_t cand_i, cand_j;
@@ -119,6 +120,10 @@ struct dcr_graph {
     uint32_t *giant_cnt = nullptr;
     int64_t giant_cnt_cap = 0;
     int32_t *giant_acc = nullptr;
+    int32_t *hub_list = nullptr;   // {node, degree} pairs of the nodes above every table size
+    int64_t hub_list_cap = 0;
+    uint32_t *hub_cnt = nullptr;   // per-wave slot counters of k_hub_edges (kept all-zero between edges)
+    int64_t hub_cnt_cap = 0;
 
     // curvature-pass work lists (edge-centric kernels)
     int32_t *work[dcr::NBINS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -177,6 +182,7 @@ void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v);         // flag {u,v
 // dcr_sdrf.hip
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v);
 int process_giant_edges(dcr_graph *g, int curv_type);  // dcr_bfc_giant.hip; syncs once
+int process_hub_edges(dcr_graph *g, int curv_type, bool incremental);  // dcr_bfc_giant.hip; syncs once
 int giant_edge(dcr_graph *g, int u, int v, int du, int dv, int64_t slot, int curv_type, bool need_cycles, int64_t *d_out6);  // result in DevResult after the next sync
 
 // dcr_bfc.hip

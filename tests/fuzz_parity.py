@@ -20,7 +20,7 @@ n_graphs = n_edges_checked = n_sdrf = 0
 
 def random_graph():
     kind = rng.integers(0, 6)
-    if rng.random() < 0.04:  # hubs joined to each other with degrees beyond the LDS tables (device-memory path)
+    if rng.random() < float(os.environ.get("HUB_PROB", 0.04)):  # hubs joined to each other with degrees beyond the LDS tables (device-memory path)
         n = int(rng.integers(20000, 45000)); hubs = int(rng.integers(2, 4))
         src, dst = [], []
         for h in range(hubs):

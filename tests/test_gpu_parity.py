@@ -612,3 +612,50 @@ def test_edges_beyond_every_lds_table(dcr, oracle):
     oc = C.curv_all('bfc', nthreads=8)[2]
     bad = np.nonzero(cv != oc)[0]
     assert bad.size == 0, (bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:5]])
+
+
+def test_hub_edges_swept_from_the_hub_side(dcr, oracle):
+    """Edges between a hub above every LDS table (> 8,190 neighbours) and a node of at most 1,022 neighbours are swept
+    from the hub's side with a position map in device memory (k_hub_edges).  Three hubs (0 and 1 adjacent, 2 adjacent to
+    neither but sharing thousands of leaves with 0, so that a leaf adjacent to 0 and 2 overflows the per-edge list of
+    touched slots), leaves with a few random edges, degree-1 leaves, a 2,000-neighbour node adjacent to hub 0 (stays
+    with the node-centric classes).  All curvature kinds, then edits and an incremental pass."""
+    n = 40000
+    rng = np.random.Generator(np.random.PCG64(77))
+    src, dst = [], []
+    l0 = rng.choice(np.arange(10, n), size=12000, replace=False)
+    l1 = rng.choice(np.arange(10, n), size=9000, replace=False)
+    l2 = np.concatenate([l0[:6000], rng.choice(np.setdiff1d(np.arange(10, n), l0), size=4000, replace=False)])
+    for hub, leaves in ((0, l0), (1, l1), (2, l2)):
+        src += [hub] * len(leaves); dst += leaves.tolist()
+    src.append(0); dst.append(1)
+    mid = 3
+    lm = rng.choice(np.arange(10, n), size=2000, replace=False)
+    src += [mid] * len(lm); dst += lm.tolist()
+    src.append(mid); dst.append(0)
+    extra = rng.integers(10, n, size=(2, 50000))
+    src += extra[0].tolist(); dst += extra[1].tolist()
+    from dcr import synthetic
+    ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
+    G = dcr(ei, n)
+    C = oracle.CGraph(ei, n)
+    assert G.degree(0) > 8190 and G.degree(1) > 8190 and G.degree(2) > 8190 and 1022 < G.degree(mid) < 8190
+    for ct in ('bfc', 'augmented', 'haantjes', '1d'):
+        eu, ev, cv = G.curvature_all(ct)
+        ou, ov, oc = C.curv_all(ct, nthreads=8)
+        assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
+        bad = np.nonzero(cv != oc)[0]
+        assert bad.size == 0, (ct, bad.size, [(int(eu[i]), int(ev[i]), G.degree(int(eu[i])), G.degree(int(ev[i])), cv[i], oc[i])
+                                              for i in bad[:6]])
+    # a second full pass gives the same values (the per-wave counters were left all-zero)
+    G.curvature_pass('bfc')
+    assert np.array_equal(G.curvature_read()[2], C.curv_all('bfc', nthreads=8)[2])
+    leaf = int(l0[7])
+    G.remove_edge(0, leaf); C.remove_edge(0, leaf)
+    k = next(int(x) for x in range(10, n) if not C.has_edge(1, int(x)))
+    G.add_edge(1, k); C.add_edge(1, k)
+    G.curvature_pass('bfc', incremental=True)
+    eu, ev, cv = G.curvature_read()
+    oc = C.curv_all('bfc', nthreads=8)[2]
+    bad = np.nonzero(cv != oc)[0]
+    assert bad.size == 0, (bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:6]])
