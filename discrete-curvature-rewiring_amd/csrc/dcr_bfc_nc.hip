@@ -247,7 +247,7 @@ struct NcScratch {
     int acc[2];      // wave totals: |sq| on the table side, gamma
     int acc4[4][2];  // the same per edge of a batch
     int res[4][5];   // batch results per edge: T, |sq| table side, |sq| row side, gamma, position of u in row v
-    int fin[16][5];  // the same per position of the unit, read back when the closing expressions are evaluated
+    int fin[32][5];  // the same per position of the unit, read back when the closing expressions are evaluated
     int spilled;     // set while the table is built: some key lives outside its home bucket
 };
 
@@ -517,10 +517,22 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
     wave_sync();
 }
 
-// positions per sub-unit: 16 where edges are cheap (amortises the table build and the closing expression), 4 for the
+// positions per sub-unit: 16 where edges are cheap (amortises the table build and the closing expression), 8 for the
 // block classes, whose edges cost thousands of entries each (more, smaller units: shorter tails)
-__host__ __device__ constexpr int nc_lanes(int c) { return c < 2 ? 16 : 4; }
-__host__ __device__ constexpr int nc_lanes_for_slots(int slots) { return slots <= 512 ? 16 : 4; }
+// (measured on S100k / S1M, pass ms: positions per unit in the wave classes 8: 2.22, 16: 2.07, 32: 2.09; in the block
+//  classes 2: 2.11, 4: 2.07 / 23.5, 8: 2.03 / 22.6, 16: 2.10 / 22.1; units per dequeue in the smallest class 1: 2.13,
+//  2: 2.07, 4: 2.05, 8: 2.12)
+#ifndef NC_LANES_SMALL
+#define NC_LANES_SMALL 16
+#endif
+#ifndef NC_LANES_BIG
+#define NC_LANES_BIG 8
+#endif
+#ifndef NC_CHUNK0
+#define NC_CHUNK0 4
+#endif
+__host__ __device__ constexpr int nc_lanes(int c) { return c < 2 ? NC_LANES_SMALL : NC_LANES_BIG; }
+__host__ __device__ constexpr int nc_lanes_for_slots(int slots) { return slots <= 512 ? NC_LANES_SMALL : NC_LANES_BIG; }
 
 template <int SLOTS, int MODE>
 __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub, const unsigned *tab, unsigned *cnt,
@@ -895,7 +907,7 @@ static int ensure_nc(dcr_graph *g) {
 template <int C, int MODE>
 static void launch_nc_wave(dcr_graph *g, const View &vw, int curv_type, hipStream_t st) {
     constexpr int SLOTS = nc_slots(C);
-    constexpr int CHUNK = C == 0 ? 2 : 1;
+    constexpr int CHUNK = C == 0 ? NC_CHUNK0 : 1;
     constexpr int LDS = 4 * (SLOTS * 4 + nc_batch_for_slots(SLOTS) * SLOTS * 2 + (int)sizeof(NcScratch));
     int per_cu = (160 * 1024) / LDS;
     if (per_cu > 8) per_cu = 8;  // 32 wave slots per CU, 4 waves per workgroup
@@ -903,7 +915,7 @@ static void launch_nc_wave(dcr_graph *g, const View &vw, int curv_type, hipStrea
     // no more workgroups than there can be work for (small graphs): units <= nodes of the class + their slots / 16
     int64_t grid = (int64_t)g->num_cu * per_cu;
     const int64_t nodes_bound = C == 0 ? g->n : g->cap_total / (nc_maxdeg(C - 1) + 1);
-    const int64_t by_work = (nodes_bound + g->cap_total / 16) / (4 * CHUNK) + 1;
+    const int64_t by_work = (nodes_bound + g->cap_total / NC_LANES_SMALL) / (4 * CHUNK) + 1;
     if (grid > by_work) grid = by_work;
     hipLaunchKernelGGL((k_nc_wave<SLOTS, MODE, CHUNK>), dim3((unsigned)grid), dim3(256), 0, st, vw, g->nc_units[C],
                        &g->dres->nc_count[C], g->nc_cap[C], g->nc_queues + C * NC_QUEUES * NC_QUEUE_STRIDE, curv_type,
