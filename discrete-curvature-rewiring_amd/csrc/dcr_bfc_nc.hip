@@ -626,7 +626,10 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
 #ifndef NC_WAVE_OCC
 #define NC_WAVE_OCC 6
 #endif
-constexpr int NC_QUEUES = 8;         // dequeue cursors per wave-class kernel
+#ifndef NC_QUEUES_N
+#define NC_QUEUES_N 8
+#endif
+constexpr int NC_QUEUES = NC_QUEUES_N;         // dequeue cursors per wave-class kernel
 constexpr int NC_QUEUE_STRIDE = 32;  // ints between cursors: one 128-byte line each
 
 // ---- wave classes: a wave owns a node; persistent waves pull CHUNK nodes at a time ----------------------------
