@@ -355,6 +355,23 @@ def test_edge_cases(dcr, oracle):
     assert len(trace) == 1
 
 
+def test_s100k_values_of_the_reference_itself(dcr):
+    """tests/golden/reference_timing_s100k.json holds the reference's own bfc_edge values for edges sampled from the
+    north-star graph (tools/make_golden.py timed them for BASELINE's CPU figure): the full pass on that graph gives
+    exactly those values at those edges."""
+    from dcr import synthetic
+    ref = load_golden('reference_timing_s100k.json')
+    ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    G = dcr(ei, n)
+    assert G.number_of_edges() == ref['num_edges']
+    eu, ev, cv = G.curvature_all('bfc')
+    got = {(int(u), int(v)): c for u, v, c in zip(eu.tolist(), ev.tolist(), cv.tolist())}
+    assert len(ref['values']) >= 40
+    for u, v, hx_ in ref['values']:
+        key = (u, v) if (u, v) in got else (v, u)
+        assert got[key] == fh(hx_), (u, v)
+
+
 @pytest.mark.parametrize('ct', ['1d', 'haantjes'])
 def test_classical_improvements_vs_oracle(dcr, oracle, ct):
     from dcr import synthetic

@@ -139,3 +139,17 @@ def test_sdrf_compact_fixtures_c_oracle(fname):
             continue
         final = c_oracle.sdrf(*args, trace=trace)
         _check_compact(case, trace, final)
+
+
+def test_north_star_graph_values_of_the_reference():
+    """The reference's own bfc_edge values on edges sampled from the north-star graph (the timing fixture keeps them):
+    the C oracle reproduces them on the full 100k-node graph."""
+    from dcr import synthetic
+    ref = load_golden('reference_timing_s100k.json')
+    ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    C = c_oracle.CGraph(ei, n)
+    assert C.num_edges() == ref['num_edges']
+    eu = np.array([r[0] for r in ref['values']], dtype=np.int32)
+    ev = np.array([r[1] for r in ref['values']], dtype=np.int32)
+    want = np.array([fh(r[2]) for r in ref['values']])
+    assert np.array_equal(C.curv_edges(eu, ev, 'bfc', nthreads=4), want)

@@ -350,7 +350,7 @@ def make_timing():
     G = build_nx(ei, n)
     edges = list(G.edges)
     rng = np.random.Generator(np.random.PCG64(7))
-    pick = rng.choice(len(edges), size=40, replace=False).tolist()
+    pick = rng.choice(len(edges), size=int(os.environ.get('TIMING_SAMPLES', 300)), replace=False).tolist()  # >= 300
     times = []
     vals = []
     for i in pick:
