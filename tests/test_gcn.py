@@ -198,12 +198,14 @@ def _dp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_data_parallel_two_ranks_gloo():
+@pytest.mark.parametrize('world', [2, 3])
+def test_data_parallel_ranks_gloo(world):
+    """world 2 and 3 (61 nodes: blocks of 31 + 30 and of 21 + 21 + 19)"""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
-    assert len(ret) == 2
+    mp.spawn(_dp_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
     for rank, (err_fwd, err_w, dacc) in ret.items():
         assert err_fwd < TOL and err_w < TOL and dacc < 1e-6, (rank, err_fwd, err_w, dacc)
 
