@@ -116,12 +116,25 @@ class ShardedGCN(torch.nn.Module):
             p.grad.copy_(flat[off:off + k].view_as(p.grad))
             off += k
 
+    def _selection(self, mask_local, y_local):
+        """Index tensor and labels of a mask, computed once per mask: boolean-mask indexing costs a host sync (and a
+        data-dependent shape) at every use, and an epoch of this model is launch-bound on more than a few GPUs."""
+        key = (mask_local.data_ptr(), mask_local._version, y_local.data_ptr(), y_local._version)
+        cache = getattr(self, '_sel_cache', None)
+        if cache is None:
+            cache = self._sel_cache = {}
+        if key not in cache:
+            idx = mask_local.nonzero().squeeze(1)
+            cache[key] = (idx, y_local.index_select(0, idx), int(idx.numel()))
+        return cache[key]
+
     def train_step(self, optimizer, x_local, y_local, train_mask_local, n_train_global):
         self.train()
         optimizer.zero_grad()
         logp = self(x_local)
-        if train_mask_local.any():
-            loss = torch.nn.functional.nll_loss(logp[train_mask_local], y_local[train_mask_local], reduction='sum')
+        idx, y_sel, count = self._selection(train_mask_local, y_local)
+        if count:
+            loss = torch.nn.functional.nll_loss(logp.index_select(0, idx), y_sel, reduction='sum')
         else:
             loss = logp.sum() * 0.0
         loss = loss / n_train_global
@@ -134,6 +147,8 @@ class ShardedGCN(torch.nn.Module):
     def eval_correct(self, x_local, y_local, mask_local):
         self.eval()
         logp = self(x_local)
-        stats = torch.stack([(logp[mask_local].argmax(1) == y_local[mask_local]).sum(), mask_local.sum()]).double()
+        idx, y_sel, count = self._selection(mask_local, y_local)
+        correct = (logp.index_select(0, idx).argmax(1) == y_sel).sum() if count else logp.new_zeros((), dtype=torch.long)
+        stats = torch.stack([correct.double(), torch.tensor(float(count), dtype=torch.float64, device=logp.device)])
         dist.all_reduce(stats, group=self.group)
         return (stats[0] / stats[1].clamp(min=1)).item()
