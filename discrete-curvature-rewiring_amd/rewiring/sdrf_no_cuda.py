@@ -16,6 +16,8 @@ Same signature, same loop, same results (edge list bit-identical for a given
 (the reference raises there; BASELINE.json names this composition as the parity
 target).  ``trace`` (optional list) receives one dict per iteration.
 """
+import os
+
 import numpy as np
 
 from dcr.graph import DcrGraph, curv_code
@@ -104,11 +106,13 @@ class SdrfRun:
     """One SDRF rewiring run, steppable: ``step()`` is one iteration of the loop body
     sdrf_no_cuda.py:22-66 and returns False when the reference loop would ``break``."""
 
-    def __init__(self, data, curv_type, remove_edges, removal_bound, tau, trace=None, device=0, incremental=False):
+    def __init__(self, data, curv_type, remove_edges, removal_bound, tau, trace=None, device=0, incremental=None):
         curv_code(curv_type)
         # incremental=False recomputes every edge each iteration like the reference (sdrf_no_cuda.py:24);
         # True only recomputes edges near the previous iteration's edits: same values, less work
-        self.incremental = incremental
+        if incremental is None:  # the reference's signature has no such switch: DCR_INCREMENTAL=1 turns it on for drop-in callers
+            incremental = os.environ.get('DCR_INCREMENTAL', '0') == '1'
+        self.incremental = bool(incremental)
         self.data = data
         self.curv_type = curv_type
         self.remove_edges = remove_edges
@@ -175,7 +179,7 @@ class SdrfRun:
         return _make_data(self.data, self.G.to_edge_index())
 
 
-def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0, incremental=False):
+def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace=None, device=0, incremental=None):
     """
     Perform SDRF graph rewiring using the given discrete curvature type.
     :param data: data to be rewired (undirected by default in this work).
