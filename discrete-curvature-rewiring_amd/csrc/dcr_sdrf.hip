@@ -197,6 +197,29 @@ __device__ inline int g_find(const int32_t *keys, unsigned mask, int key) {
     }
 }
 
+// four look-ups with their first probes in flight together (the rows swept by the improvement kernels are walked by one
+// wave each: the longest row sets the kernel's duration, and its steps are chains of dependent loads)
+__device__ inline void g_find4(const int32_t *keys, unsigned mask, const int (&key)[4], const bool (&valid)[4], int (&out)[4]) {
+    unsigned h[4];
+    int e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        h[q] = g_hash((unsigned)key[q], mask);
+        e[q] = valid[q] ? keys[h[q]] : (int)T_EMPTY;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[q] = -1;
+        if (!valid[q]) continue;
+        while (true) {
+            if (e[q] == key[q]) { out[q] = (int)h[q]; break; }
+            if ((unsigned)e[q] == T_EMPTY) break;
+            h[q] = (h[q] + 1) & mask;
+            e[q] = keys[h[q]];
+        }
+    }
+}
+
 struct ImpBuf {
     int32_t *keys, *posx, *posy;  // hash table over N(x) ∪ N(y) minus {x,y}
     int32_t *c1, *c2;             // [dx], [dy]
@@ -284,18 +307,25 @@ __global__ void __launch_bounds__(256) k_imp_count(RowView g, ImpBuf B, int x, u
     const int i = g.col[rx.x + a];
     const int2 ri = g.rowinfo[i];
     int c = 0;
-    for (int base = 0; base < ri.y; base += 64) {
-        const int t = base + lane;
-        bool hit = false;
-        if (t < ri.y) {
-            const int w = g.col[ri.x + t];
-            const int h = g_find(B.keys, mask, w);
-            if (h >= 0 && B.posx[h] < 0) {  // in N(y) only (x and y are never in the table)
-                hit = true;
-                atomicAdd(&B.c2[B.posy[h]], 1);
-            }
+    for (int base = 0; base < ri.y; base += 256) {
+        int w[4], h[4];
+        bool in[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = base + 64 * q + lane;
+            in[q] = t < ri.y;
+            w[q] = in[q] ? g.col[ri.x + t] : -1;
         }
-        c += __popcll(__ballot(hit));
+        g_find4(B.keys, mask, w, in, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bool hit = false;
+            if (h[q] >= 0 && B.posx[h[q]] < 0) {  // in N(y) only (x and y are never in the table)
+                hit = true;
+                atomicAdd(&B.c2[B.posy[h[q]]], 1);
+            }
+            c += __popcll(__ballot(hit));
+        }
     }
     if (lane == 0) B.c1[a] = c;
 }
@@ -430,14 +460,21 @@ __global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int 
     const int32_t *cnt_other = isB ? B.c1 : B.c2;  // counters of the side that loses edges
     const int max_other = isB ? st.max1 : st.max2;
     int n_dec0 = 0, n_maxadj = 0;
-    for (int base = 0; base < rn.y; base += 64) {
-        const int t = base + lane;
-        bool dec0 = false, mxa = false;
-        if (t < rn.y) {
-            const int w = g.col[rn.x + t];
-            const int h = g_find(B.keys, mask, w);
-            if (h >= 0) {
-                const int px = B.posx[h], py = B.posy[h];
+    for (int base = 0; base < rn.y; base += 256) {
+        int w[4], h[4];
+        bool in[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = base + 64 * q + lane;
+            in[q] = t < rn.y;
+            w[q] = in[q] ? g.col[rn.x + t] : -1;
+        }
+        g_find4(B.keys, mask, w, in, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bool dec0 = false, mxa = false;
+            if (h[q] >= 0) {
+                const int px = B.posx[h[q]], py = B.posy[h[q]];
                 const bool other_only = isB ? (px >= 0 && py < 0) : (py >= 0 && px < 0);
                 if (other_only) {
                     const int c = cnt_other[isB ? px : py];
@@ -445,9 +482,9 @@ __global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int 
                     mxa = (c == max_other);
                 }
             }
+            n_dec0 += __popcll(__ballot(dec0));
+            n_maxadj += __popcll(__ballot(mxa));
         }
-        n_dec0 += __popcll(__ballot(dec0));
-        n_maxadj += __popcll(__ballot(mxa));
     }
     if (lane != 0) return;
     int s1, s2, m1, m2, d1, d2;
@@ -567,31 +604,23 @@ __global__ void __launch_bounds__(256) k_imp_emit(RowView g, ImpBuf B, int x, in
     const int64_t row_base = B.rowoff[a];
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
+    // one thread per candidate position b (256 per round): its place in the output is the number of admitted positions
+    // before it (ballots inside the wave, wave totals through LDS).  (One thread per 32-bit bitmap word, as this kernel
+    // first did it, leaves 5 of 256 threads busy for a typical 150-neighbour endpoint, 32 closing expressions each.)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int wbase = 0; wbase < words; wbase += 256) {
-        const int w = wbase + threadIdx.x;
-        uint32_t ok = 0u;
-        if (w < words) {
-            const int lo = w * 32;
-            const uint32_t live = (nb - lo >= 32) ? 0xFFFFFFFFu : ((1u << (nb - lo)) - 1u);
-            ok = ~B.adjbits[(size_t)a * words + w] & live;
-        }
-        const int v = __popc(ok);
-        int incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wsum[wid] = incl;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int bbase = 0; bbase < nb; bbase += 256) {
+        const int b = bbase + threadIdx.x;
+        bool ok = false;
+        if (b < nb) ok = ((B.adjbits[(size_t)a * words + (b >> 5)] >> (b & 31)) & 1u) == 0u;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wsum[wid] = __popcll(m);
         __syncthreads();
         int woff = 0;
         for (int q = 0; q < wid; ++q) woff += wsum[q];
         const int carry = carry_sh;
-        int64_t o = row_base + carry + woff + incl - v;
-        while (ok) {
-            const int bit = __ffs((int)ok) - 1;
-            ok &= ok - 1u;
-            const int b = w * 32 + bit;
+        if (ok) {
+            const int64_t o = row_base + carry + woff + __popcll(m & lt);
             const int j = b < st.dy ? g.col[ry.x + b] : y;
             double val;
             if (a == st.dx) {
@@ -600,9 +629,9 @@ __global__ void __launch_bounds__(256) k_imp_emit(RowView g, ImpBuf B, int x, in
                 val = B.impc[a];  // j == y: admitted only for i in DX
             } else if (curv_type == DCR_CURV_BFC && cls_a == 0 && B.clsy[b] == 0) {
                 const int c2b = B.c2[b];
-                const int m = (c1a + 1 > c2b + 1 ? c1a + 1 : c2b + 1);
+                const int mm = (c1a + 1 > c2b + 1 ? c1a + 1 : c2b + 1);
                 const double after = bfc_value(st.dx, st.dy, st.T, st.s1 + (c1a == 0), st.s2 + (c2b == 0),
-                                               m > gam ? m : gam);
+                                               mm > gam ? mm : gam);
                 val = after - st.before;
             } else {
                 val = 0.0;
@@ -610,10 +639,9 @@ __global__ void __launch_bounds__(256) k_imp_emit(RowView g, ImpBuf B, int x, in
             out[o] = val;
             ci[o] = i < j ? i : j;  // sorted((i, j)), sdrf_no_cuda.py:37
             cj[o] = i < j ? j : i;
-            ++o;
         }
         __syncthreads();
-        if (threadIdx.x == 255) carry_sh = carry + woff + incl;
+        if (threadIdx.x == 0) carry_sh = carry + wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
 }
