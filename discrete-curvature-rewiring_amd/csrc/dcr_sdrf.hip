@@ -95,18 +95,35 @@ __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_tot
     Ext best;
     best.val = 0.0;
     best.slot = -1;
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap_total;
-         s += (int64_t)gridDim.x * blockDim.x) {
-        const int u = g.slot_row[s];
-        const int2 ru = g.rowinfo[u];
-        if ((int)(s - ru.x) >= ru.y) continue;
-        const int v = g.col[s];
-        if (v <= u) continue;
-        if (u == excl_u && v == excl_v) continue;
-        Ext c;
-        c.val = curv[s];
-        c.slot = (int32_t)s;
-        best = ext_better(best, c, want_max);
+    // four slots per thread and round, their chains of dependent loads (owner row -> row extent -> neighbour ->
+    // value) in flight together; slots are visited in increasing order per thread, so "first" extremum is preserved by
+    // ext_better's (value, slot) order
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < cap_total; s0 += 4 * stride) {
+        int u[4], v[4];
+        int2 ru[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t s = s0 + q * stride;
+            ok[q] = s < cap_total;
+            u[q] = ok[q] ? g.slot_row[s] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t s = s0 + q * stride;
+            ru[q] = ok[q] ? g.rowinfo[u[q]] : make_int2(0, 0);
+            v[q] = ok[q] ? g.col[s] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t s = s0 + q * stride;
+            if (!ok[q] || (int)(s - ru[q].x) >= ru[q].y || v[q] <= u[q] || (u[q] == excl_u && v[q] == excl_v)) continue;
+            Ext c;
+            c.val = curv[s];
+            c.slot = (int32_t)s;
+            best = ext_better(best, c, want_max);
+        }
     }
     best = ext_block_reduce(best, want_max, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = best;
@@ -158,7 +175,7 @@ __global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int np
     if (threadIdx.x == 0) res->imp_argmax = best.slot;
 }
 
-constexpr int ARGEXT_BLOCKS = 1024;
+constexpr int ARGEXT_BLOCKS = 1024;  // (8192 blocks: 92 us instead of 33 on S100k, the per-block reduction dominates)
 
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
     g->amax_valid = false;  // the ext fields of the result block are about to be overwritten
