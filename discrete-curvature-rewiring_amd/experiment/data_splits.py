@@ -21,6 +21,20 @@ def get_mask(idx, num_nodes):
     return mask
 
 
+def _shuffled(items, seed):
+    """``items`` permuted by ``random.shuffle`` under ``random.seed(seed)`` (the generator the reference uses here)."""
+    order = list(items)
+    random.seed(seed)
+    random.shuffle(order)
+    return order
+
+
+def _install_masks(data, num_nodes, train_idx, val_idx, test_idx):
+    for name, idx in (('train_mask', train_idx), ('val_mask', val_idx), ('test_mask', test_idx)):
+        setattr(data, name, get_mask(idx, num_nodes))
+    return data
+
+
 def set_train_val_test_split(seed, data, num_development=1500, num_per_class=20):
     """Planetoid-style split (data_splits.py:45-63): a development set of ``num_development`` nodes drawn with the
     fixed development seed, everything else is test; per class up to ``num_per_class`` development nodes (at most 70 %
@@ -43,34 +57,21 @@ def set_train_val_test_split(seed, data, num_development=1500, num_per_class=20)
     in_train[train_idx] = True
     val_idx = dev[~in_train[dev]]
 
-    data.train_mask = get_mask(train_idx, num_nodes)
-    data.val_mask = get_mask(val_idx, num_nodes)
-    data.test_mask = get_mask(test_idx, num_nodes)
-    return data
+    return _install_masks(data, num_nodes, train_idx, val_idx, test_idx)
 
 
 def set_train_val_test_split_frac(seed, data, val_frac, test_frac):
     """Fractional split (data_splits.py:15-42): the test nodes are the head of a shuffle with the development seed
-    (the same test set for every seed); the rest is shuffled with ``seed`` and cut into train and validation."""
+    (the same test set for every seed); the rest, in the order that first shuffle left it, is shuffled with ``seed``
+    and cut into train and validation."""
     num_nodes = int(data.y.shape[0])
-    val_size = ceil(val_frac * num_nodes)
-    test_size = ceil(test_frac * num_nodes)
-    train_size = num_nodes - val_size - test_size
+    n_val, n_test = ceil(val_frac * num_nodes), ceil(test_frac * num_nodes)
+    n_train = num_nodes - n_val - n_test
 
-    nodes = list(range(num_nodes))
-    random.seed(development_seed)
-    random.shuffle(nodes)
-    test_idx = nodes[:test_size]
-    chosen = set(test_idx)
-    nodes = [x for x in nodes if x not in chosen]  # order after the first shuffle is what the second one permutes
-
-    random.seed(seed)
-    random.shuffle(nodes)
-    train_idx = nodes[:train_size]
-    val_idx = nodes[train_size:]
-    assert len(train_idx) + len(val_idx) + len(test_idx) == num_nodes
-
-    data.train_mask = get_mask(train_idx, num_nodes)
-    data.val_mask = get_mask(val_idx, num_nodes)
-    data.test_mask = get_mask(test_idx, num_nodes)
-    return data
+    first = _shuffled(range(num_nodes), development_seed)
+    test_idx, rest = first[:n_test], first[n_test:]   # (the reference filters the test nodes out again: same list)
+    second = _shuffled(rest, seed)
+    train_idx, val_idx = second[:n_train], second[n_train:]
+    if len(train_idx) + len(val_idx) + len(test_idx) != num_nodes:
+        raise AssertionError('split sizes do not add up')
+    return _install_masks(data, num_nodes, train_idx, val_idx, test_idx)

@@ -313,38 +313,34 @@ class GCNConv(torch.nn.Module):
 
 
 class GCN(torch.nn.Module):
+    """The reference's model (models/gcn.py:12-44) on the kernels of this package: GCNConv layers of widths
+    [features] + hidden + [classes], ReLU and dropout between them, log-softmax at the end.  Attribute names, the
+    two optimiser groups (weight decay on the first layer only, save_models.py:78-82) and the ``state_dict`` keys
+    (``layers.{i}.bias``, ``layers.{i}.lin.weight``) are the reference's."""
+
     def __init__(self, dataset, hidden: List[int] = [64], dropout: float = 0.5):
-        super(GCN, self).__init__()
-
-        num_features = [dataset.data.x.shape[1]] + hidden + [dataset.num_classes]
-        layers = []
-        for in_features, out_features in zip(num_features[:-1], num_features[1:]):
-            layers.append(GCNConv(in_features, out_features))
-        self.layers = ModuleList(layers)
-        layers[0].propagate_input_first = True   # its input is data.x, constant over the run
-
-        self.reg_params = list(layers[0].parameters())
-        self.non_reg_params = list([p for l in layers[1:] for p in l.parameters()])
-
+        super().__init__()
+        widths = [dataset.data.x.shape[1], *hidden, dataset.num_classes]
+        self.layers = ModuleList([GCNConv(w_in, w_out) for w_in, w_out in zip(widths, widths[1:])])
+        first = self.layers[0]
+        first.propagate_input_first = True   # its input is data.x, constant over the run
+        self.reg_params = list(first.parameters())
+        self.non_reg_params = [p for conv in list(self.layers)[1:] for p in conv.parameters()]
         self.dropout = Dropout(p=dropout)
         self.act_fn = ReLU()
 
     def reset_parameters(self):
-        for layer in self.layers:
-            layer.reset_parameters()
+        for conv in self.layers:
+            conv.reset_parameters()
 
     def forward(self, data):
-        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
-
-        for i, layer in enumerate(self.layers):
-            x = layer(x, edge_index, edge_weight=edge_attr)
-
-            if i == len(self.layers) - 1:
-                break
-
-            x = relu_dropout(x, self.act_fn, self.dropout)
-
-        return torch.nn.functional.log_softmax(x, dim=1)
+        h = data.x
+        last = len(self.layers) - 1
+        for depth, conv in enumerate(self.layers):
+            h = conv(h, data.edge_index, edge_weight=data.edge_attr)
+            if depth < last:
+                h = relu_dropout(h, self.act_fn, self.dropout)
+        return torch.nn.functional.log_softmax(h, dim=1)
 
 
 def dense_reference_logits(model, x, edge_index, num_nodes):
