@@ -100,14 +100,14 @@ def run(datasets, curvatures, **kwargs):
     """The reference's ``__main__`` loop (save_models.py:91-106): every dataset x curvature, failures reported and
     skipped, one pickle of state dicts per pair."""
     out_dir = kwargs.get('out_dir', '.')
-    for name in datasets:
-        print(f'{name}:')
-        for curvature in curvatures:
+    for dname in datasets:
+        print(f'{dname}:')
+        for curv in curvatures:
+            target = os.path.join(out_dir, 'state_dicts', dname, f'state_dicts_{curv}.pk')
             try:
-                sd = save_models(name, curvature, **kwargs)
-                _dump(sd, os.path.join(out_dir, 'state_dicts', name, f'state_dicts_{curvature}.pk'))
-            except Exception as e:  # the reference prints and carries on
-                print(str(name), str(curvature), str(e))
+                _dump(save_models(dname, curv, **kwargs), target)
+            except Exception as err:  # noqa: BLE001 - the reference prints the failure and carries on
+                print(f'{dname} {curv} {err}')
             print()
         print()
 

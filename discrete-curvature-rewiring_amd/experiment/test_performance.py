@@ -57,16 +57,17 @@ def summary_cell(mean, std):
 def run(datasets, curvatures, **kwargs):
     """The reference's ``__main__`` table (test_performance.py:89-107), returned as {dataset: [cell per curvature]}
     and written as CSV (the reference writes results.xlsx through pandas/openpyxl)."""
-    result = {d: [] for d in datasets}
-    for name in datasets:
-        for curvature in curvatures:
+    table = {dname: [] for dname in datasets}
+    for dname in datasets:
+        for curv in curvatures:
             try:
-                _, mean, std = test_performance(name, curvature, **kwargs)
-                cell = summary_cell(mean, std)
-            except Exception:  # a missing pickle is recorded, as in the reference
-                cell = 'ERROR'
-            result[name].append(cell)
-            print(name, curvature, cell)
+                _, mean, std = test_performance(dname, curv, **kwargs)
+                entry = summary_cell(mean, std)
+            except Exception:  # noqa: BLE001 - a missing pickle is recorded as the reference records it
+                entry = 'ERROR'
+            table[dname].append(entry)
+            print(dname, curv, entry)
+    result = table
     with open(os.path.join(kwargs.get('out_dir', '.'), 'results.csv'), 'w') as f:
         f.write('curvature,' + ','.join(datasets) + '\n')
         for j, c in enumerate(curvatures):
