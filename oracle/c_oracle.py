@@ -147,13 +147,14 @@ def bfc_formula(d1, d2, T, s1, s2, gamma):
 
 
 def softmax(a, tau=1):
-    """utils/softmax.py:4-10."""
+    """Restates utils/softmax.py:4-10: for tau = inf the indicator of the first arg-max, else exp(a * tau) over its
+    (pairwise, numpy) sum; no max-subtraction, as in the reference."""
     if tau == float('inf'):
-        r = np.zeros(len(a))
-        r[np.argmax(a)] = 1
-        return r
-    exp_a = np.exp(a * tau)
-    return exp_a / exp_a.sum()
+        indicator = np.zeros(len(a))
+        indicator[np.argmax(a)] = 1
+        return indicator
+    weights = np.exp(a * tau)
+    return weights / weights.sum()
 
 
 def sdrf(edge_index, num_nodes, curv_type, loops, remove_edges, removal_bound, tau, trace=None, nthreads=1):

@@ -151,13 +151,14 @@ def curvature_graph(G, curv_type):
 
 
 def softmax(a, tau=1):
-    """utils/softmax.py:4-10."""
+    """Restates utils/softmax.py:4-10: for tau = inf the indicator of the first arg-max, else exp(a * tau) over its
+    (pairwise, numpy) sum; no max-subtraction, as in the reference."""
     if tau == float('inf'):
-        r = np.zeros(len(a))
-        r[np.argmax(a)] = 1
-        return r
-    exp_a = np.exp(a * tau)
-    return exp_a / exp_a.sum()
+        indicator = np.zeros(len(a))
+        indicator[np.argmax(a)] = 1
+        return indicator
+    weights = np.exp(a * tau)
+    return weights / weights.sum()
 
 
 def sdrf(edge_index, num_nodes, curv_type, loops, remove_edges, removal_bound, tau, trace=None):
