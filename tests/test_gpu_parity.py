@@ -676,3 +676,34 @@ def test_hub_edges_swept_from_the_hub_side(dcr, oracle):
     oc = C.curv_all('bfc', nthreads=8)[2]
     bad = np.nonzero(cv != oc)[0]
     assert bad.size == 0, (bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:6]])
+
+
+def test_hub_path_boundaries(dcr, oracle):
+    """Degrees exactly at the limits that route an edge: a hub with 8,191 neighbours (one above the largest table), its
+    edges to nodes with 1,022 neighbours (hub-side sweep) and 1,023 (owned by that node), and a second node with exactly
+    8,190 neighbours (the largest table class) adjacent to the hub."""
+    n = 30000
+    rng = np.random.Generator(np.random.PCG64(13))
+    pool = np.arange(10, n)
+    src, dst = [], []
+
+    def star(center, deg, must=()):
+        leaves = rng.choice(np.setdiff1d(pool, np.array(list(must) + [center])), size=deg - len(must), replace=False)
+        for k in list(must) + leaves.tolist():
+            src.append(center); dst.append(int(k))
+
+    star(1, 1022, must=(0,))
+    star(2, 1023, must=(0,))
+    star(3, 8190, must=(0,))
+    star(0, 8191 - 3)          # + the three edges above = 8,191
+    from dcr import synthetic
+    ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
+    G = dcr(ei, n)
+    C = oracle.CGraph(ei, n)
+    assert (G.degree(0), G.degree(1), G.degree(2), G.degree(3)) == (8191, 1022, 1023, 8190)
+    for ct in ('bfc', 'augmented'):
+        eu, ev, cv = G.curvature_all(ct)
+        ou, ov, oc = C.curv_all(ct, nthreads=8)
+        assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
+        bad = np.nonzero(cv != oc)[0]
+        assert bad.size == 0, (ct, bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:6]])
