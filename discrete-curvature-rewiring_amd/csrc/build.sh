@@ -13,6 +13,11 @@ for f in dcr_graph dcr_bfc dcr_bfc_nc dcr_bfc_giant dcr_sdrf dcr_gcn dcr_gemm; d
   fi
   OBJS="$OBJS $f.o"
 done
+# host-only helper (exact vectorised cumsum of the SDRF draw): plain C++, no fast-math, no contraction
+if [ ! -f dcr_host_draw.o ] || [ dcr_host_draw.cpp -nt dcr_host_draw.o ] || [ ../../include/dcr.h -nt dcr_host_draw.o ]; then
+  g++ -O2 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -Wall -c dcr_host_draw.cpp -o dcr_host_draw.o &
+fi
+OBJS="$OBJS dcr_host_draw.o"
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o libdcr_hip.so $OBJS
 echo "built $(pwd)/libdcr_hip.so"

@@ -960,17 +960,4 @@ static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_rem
     return DCR_OK;
 }
 
-int dcr_host_cdf_from_exp(const double *e, int64_t n, double S, double *cdf, double *out_total) {
-    if (!e || !cdf || !out_total || n <= 0) DCR_FAIL(DCR_EINVAL, "bad argument");
-    // p = e / S (numpy true_divide), cdf = cumsum(p): sequential float64 adds, exactly numpy's loop
-    double acc = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double p = e[i] / S;
-        acc = acc + p;
-        cdf[i] = acc;
-    }
-    *out_total = cdf[n - 1];
-    return DCR_OK;
-}
-
 }  // extern "C"

@@ -136,6 +136,10 @@ int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes);
  * pass with numpy's operations in numpy's order, and return cdf[n-1].  The caller validates the total, draws ONE uniform
  * from the legacy stream and bisects cdf / total exactly as RandomState.choice does.  Plain host code, no GPU. */
 int dcr_host_cdf_from_exp(const double *e, int64_t n, double S, double *out_cdf, double *out_total);
+/* The same through the plain sequential loop only.  dcr_host_cdf_from_exp evaluates the recurrence eight elements at a
+ * time in integer-valued float64 arithmetic where that is exact (csrc/dcr_host_draw.cpp) and falls back to this loop
+ * elsewhere; the two must agree bit for bit (tests/test_host_cpu.py). */
+int dcr_host_cdf_from_exp_plain(const double *e, int64_t n, double S, double *out_cdf, double *out_total);
 
 /* ---- GCN aggregation (device pointers, caller's stream) --------------------
  * Replaces the propagate/scatter step of torch_geometric GCNConv (third-party,

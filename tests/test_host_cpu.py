@@ -140,3 +140,63 @@ def test_draw_index_matches_numpy_choice():
             assert got == want and state_got[1] == state_want[1] and np.array_equal(state_got[0], state_want[0])
     with pytest.raises(ValueError):
         draw_index(np.array([800.0, 1.0]), 163.0)      # exp overflows: numpy's NaN error, stream untouched
+
+
+def test_vectorised_cdf_is_numpy_cumsum():
+    """csrc/dcr_host_draw.cpp evaluates numpy's sequential cumsum(e / S) eight elements at a time where integer-valued
+    float64 arithmetic makes that exact, and falls back to the plain loop at ties, binade crossings and unusual values.
+    Bit-compared with numpy.cumsum itself (the contract of np.random.choice) and with the plain loop."""
+    import ctypes
+    from dcr import _lib
+    L = _lib.lib()
+    f64p = _lib._f64p
+
+    def run(fn, e, S):
+        e = np.ascontiguousarray(e, dtype=np.float64)
+        out = np.empty_like(e)
+        tot = ctypes.c_double()
+        assert fn(e.ctypes.data_as(f64p), e.shape[0], float(S), out.ctypes.data_as(f64p), ctypes.byref(tot)) == 0
+        assert tot.value == out[-1] or (np.isnan(tot.value) and np.isnan(out[-1]))
+        return out
+
+    def check(e, S, label):
+        with np.errstate(all='ignore'):
+            want = (np.asarray(e, dtype=np.float64) / S).cumsum()
+        for fn in (L.dcr_host_cdf_from_exp, L.dcr_host_cdf_from_exp_plain):
+            got = run(fn, e, S)
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan), label
+            assert np.array_equal(got[~nan].view(np.uint64), want[~nan].view(np.uint64)), label
+
+    rng = np.random.Generator(np.random.PCG64(1))
+    for trial in range(400):
+        n = int(rng.integers(64, 5000))
+        kind = trial % 10
+        a = (rng.normal(0, 0.01, n) * 163 if kind == 0 else rng.normal(0, 0.5, n) * 163 if kind == 1 else
+             rng.choice([-0.1, 0.0, 0.02, 0.03], n) * 163 if kind == 2 else rng.uniform(-700, 700, n) if kind == 3 else
+             np.sort(rng.normal(0, 0.2, n) * 50) if kind == 4 else -np.sort(rng.normal(0, 0.2, n) * 50) if kind == 5 else
+             np.zeros(n) if kind == 6 else np.log(rng.integers(1, 4, n).astype(float)) if kind == 7 else
+             rng.normal(0, 3, n) if kind == 8 else rng.normal(0, 1e-6, n))
+        with np.errstate(all='ignore'):
+            e = np.exp(a)
+            check(e, e.sum(), (trial, kind))
+    for n in (64, 257, 1000):                      # crafted ties and binade crossings
+        for base in (1.0, 0.5, 3.0, 1e-5, 7e10):
+            check(np.full(n, base), 1.0, ('const', n, base))
+            check(base * 2.0 ** (-rng.integers(0, 60, n).astype(float)), 1.0, ('pow2', n, base))
+            check(base * (1.0 + 2.0 ** (-rng.integers(1, 53, n).astype(float))), 3.0, ('near', n, base))
+    for label, mod in (('inf', lambda e: e.__setitem__(100, np.inf)), ('nan', lambda e: e.__setitem__(7, np.nan)),
+                       ('negative', lambda e: e.__setitem__(300, -0.25))):
+        e = rng.random(500)
+        mod(e)
+        check(e, 1.0, label)
+    check(np.zeros(300), 1.0, 'zeros')
+    check(rng.random(300) * 1e-310, 1.0, 'subnormal')
+    check(rng.random(300) * 1e300, 1e-5, 'overflow')
+    # the draw built on it still agrees with numpy's choice
+    np.random.seed(3)
+    a = rng.normal(0, 0.01, 5000)
+    want = np.random.choice(5000, p=np.exp(a * 163) / np.exp(a * 163).sum())
+    np.random.seed(3)
+    from rewiring.sdrf_no_cuda import draw_index
+    assert draw_index(a, 163.0) == want
