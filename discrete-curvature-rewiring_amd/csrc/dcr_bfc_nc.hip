@@ -68,6 +68,9 @@ __device__ inline bool nc_owns(int a, int da, int b, int db, bool trivial_rule) 
 // wave-instruction needed a second and a third probe, and that loop alone was 15 % of the pass.
 // A free slot.  Not 0xFFFFFFFF: that is what the slack behind a row holds, and the fast test below compares raw row
 // pieces (slack included) with the bucket contents.
+#ifndef NC_Q
+#define NC_Q 3  // pieces per lane and round of the streaming loops (S100k / S1M pass ms: 1: 2.05 / 23.4, 2: 1.98 / 22.0, 3: 1.97 / 21.8, 4: 2.04 / 22.4)
+#endif
 constexpr unsigned NC_EMPTY = 0xFFFFFFFDu;
 
 template <int SLOTS>
@@ -325,11 +328,11 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
         sc->rowcnt[lane] = 0;
         if (lane == 0) sc->poff[64] = P;
         wave_sync();
-        for (int j0 = 0; j0 < P; j0 += 256) {
-            int4 w[4];
-            int rr[4], aa[4];
+        for (int j0 = 0; j0 < P; j0 += 64 * NC_Q) {
+            int4 w[NC_Q];
+            int rr[NC_Q], aa[NC_Q];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NC_Q; ++q) {
                 const int j = j0 + 64 * q + lane;
                 rr[q] = -1;
                 aa[q] = 0;
@@ -346,7 +349,7 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NC_Q; ++q) {
                 if (rr[q] >= 0) {
                     const int2 d = sc->desc[rr[q]];
                     const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], piece_mask(aa[q], d.x, d.x + d.y), s1, gam, ovf,
@@ -469,11 +472,11 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
     sc->rowcnt[lane] = 0;
     if (lane == 0) sc->poff[64] = P;
     wave_sync();
-    for (int j0 = 0; j0 < P; j0 += 256) {
-        int4 w[4];
-        int rr[4], aa[4];
+    for (int j0 = 0; j0 < P; j0 += 64 * NC_Q) {
+        int4 w[NC_Q];
+        int rr[NC_Q], aa[NC_Q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NC_Q; ++q) {
             const int j = j0 + 64 * q + lane;
             rr[q] = -1;
             aa[q] = 0;
@@ -490,7 +493,7 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NC_Q; ++q) {
             const int gr = (rr[q] < 0 ? 0 : rr[q]) / G;
             const unsigned vgr = (unsigned)__shfl(v, gr * G);  // the edge this row belongs to (all lanes converged here)
             if (rr[q] >= 0) {

@@ -9,6 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-ma
 for f in dcr_graph dcr_bfc dcr_bfc_nc dcr_bfc_giant dcr_sdrf dcr_gcn dcr_gemm; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o variants/$name/$f.o &
 done
+g++ -O2 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -Wall -c dcr_host_draw.cpp -o variants/$name/dcr_host_draw.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libdcr_hip_$name.so variants/$name/*.o
 rm -rf variants/$name
