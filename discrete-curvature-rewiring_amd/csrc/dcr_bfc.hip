@@ -530,7 +530,7 @@ __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total,
     if ((int)(s - ru.x) >= ru.y) return -1;
     const int v = g.col[s];
     if (v <= u) return -1;
-    if (g.dirty && !(g.dirty[u] | g.dirty[v])) return -1;  // untouched neighbourhood: the stored value is still exact
+    if (g.dirty && !edge_dirty(g.dirty[u], g.dirty[v])) return -1;  // no edit can have changed it: the stored value is still exact
     const int dv = g.rowinfo[v].y, du = ru.y;
     if (g.nc_handles && (nc_takes(du, dv) || hub_takes(du, dv))) return -1;  // the node-centric / hub kernels own this edge
     if (mode != MODE_BYTES && curv_type == DCR_CURV_1D) {
@@ -767,6 +767,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     DCR_TRY(launch_curvature_pass(g, curv_type, incremental));
     DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
     g->dirty_tracked = true;
+    g->pending_edits = 0;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
     if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));  // first minimum in G.edges order, same host sync
     DCR_TRY(sync_result(g));

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_hub_edges(View g, int h, const int32_t 
         if (v < 0 || v >= g.n || v == h) continue;
         const int2 rv = g.rowinfo[v];
         if (!row_ok(g, rv, 31, v, h) || rv.y < 1 || rv.y > HUB_OTHER_MAX) continue;  // other paths take the rest
-        if (g.dirty && !(g.dirty[h] | g.dirty[v])) continue;
+        if (g.dirty && !edge_dirty(g.dirty[h], g.dirty[v])) continue;
         // sweep N(v): where h sits in row v, triangles (flagged in the counters), descriptors of the rows of DY
         int T = 0, posh = -1, nrows = 0, nt = 0;
         for (int base = 0; base < rv.y; base += 64) {

@@ -552,7 +552,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
             rv = g.rowinfo[v];
             if (!row_ok(g, rv, 12, v, u)) rv = make_int2(0, 0);
             own = rv.y > 0 && nc_owns(u, ru.y, v, rv.y, curv_type == DCR_CURV_BFC);
-            if (own && g.dirty) own = (g.dirty[u] | g.dirty[v]) != 0;
+            if (own && g.dirty) own = edge_dirty(g.dirty[u], g.dirty[v]);
         }
     }
     const bool trivial = curv_type == DCR_CURV_BFC && (ru.y < rv.y ? ru.y : rv.y) == 1;  // bfc_naive.py:18-19
@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
     int bkt = -1, d = 0;
     if (u < g.n) {
         d = g.rowinfo[u].y;
-        if (d > 0 && d <= NC_MAXD && (!g.dirty || g.dirty[u] || touch[u])) bkt = nc_bucket_of(d);
+        if (d > 0 && d <= NC_MAXD && (!g.dirty || touch[u])) bkt = nc_bucket_of(d);
     }
     const int cls = bkt < 0 ? -1 : nc_bucket_class(bkt);
     const int L_ = cls < 0 ? 16 : nc_lanes(cls);
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
     }
 }
 
-// incremental pass: nodes with a flagged neighbour own edges that must be recomputed too
+// incremental pass: the nodes with at least one edge that an edit can have changed (either endpoint may own it)
 __global__ void __launch_bounds__(256) k_nc_touch(View g, uint8_t *touch) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= g.cap_total) return;
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(256) k_nc_touch(View g, uint8_t *touch) {
     const int2 ru = g.rowinfo[u];
     if ((int)(s - ru.x) >= ru.y) return;
     const int v = g.col[s];
-    if (v >= 0 && v < g.n && g.dirty[v]) touch[u] = 1;
+    if (v >= 0 && v < g.n && edge_dirty(g.dirty[u], g.dirty[v])) touch[u] = 1;
 }
 
 __global__ void k_nc_clear(DevResult *res) {

@@ -129,35 +129,42 @@ __global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *
     }
 }
 
-// Incremental curvature: BFC(a,b) depends on N(a), N(b) and on the rows of their members, so an edit of edge
-// (u,v) can change exactly the edges that have an endpoint in {u,v} ∪ N(u) ∪ N(v).
+// Incremental curvature: the per-node flags behind edge_dirty() (dcr_bfc_common.h).  Edit number `edit` (0..2) of the
+// edge {u,v}: endpoint flag on u and v, bit A on the members of N(u), bit B on those of N(v); later edits: the coarse
+// flag on all of them.  A node can be in both rows, so the bytes are OR-ed atomically (through their 32-bit words).
+__device__ inline void dirty_or(uint8_t *dirty, int k, unsigned bits) {
+    atomicOr(reinterpret_cast<unsigned *>(dirty) + (k >> 2), bits << ((k & 3) * 8));
+}
 __device__ inline void dev_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u, int32_t v,
-                                      int tid, int nthreads) {
+                                      int edit, int tid, int nthreads) {
     if (u < 0 || v < 0) return;
+    const bool exact = edit >= 0 && edit < dcr::DIRTY_EDITS;
+    const unsigned bit_u = exact ? 1u << (2 * edit) : dcr::DIRTY_COARSE, bit_v = exact ? 2u << (2 * edit) : dcr::DIRTY_COARSE;
+    const unsigned bit_end = exact ? dcr::DIRTY_ENDPOINT : dcr::DIRTY_COARSE;
     const int2 ru = rowinfo[u], rv = rowinfo[v];
-    for (int i = tid; i < ru.y; i += nthreads) dirty[col[ru.x + i]] = 1;
-    for (int i = tid; i < rv.y; i += nthreads) dirty[col[rv.x + i]] = 1;
+    for (int i = tid; i < ru.y; i += nthreads) dirty_or(dirty, col[ru.x + i], bit_u);
+    for (int i = tid; i < rv.y; i += nthreads) dirty_or(dirty, col[rv.x + i], bit_v);
     if (tid == 0) {
-        dirty[u] = 1;
-        dirty[v] = 1;
+        dirty_or(dirty, u, bit_end);
+        dirty_or(dirty, v, bit_end);
     }
 }
 
 __global__ void __launch_bounds__(256) k_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u,
-                                                     int32_t v, const DevResult *res) {
+                                                     int32_t v, int edit, const DevResult *res) {
     if (u == -2) {
         u = res->cand_i;
         v = res->cand_j;
     }
-    dev_mark_dirty(rowinfo, col, dirty, u, v, threadIdx.x, blockDim.x);
+    dev_mark_dirty(rowinfo, col, dirty, u, v, edit, threadIdx.x, blockDim.x);
 }
 
 // the edge the tail is about to remove (it is only known on the device)
 __global__ void __launch_bounds__(256) k_mark_dirty_ext(const int2 *rowinfo, const int32_t *col, uint8_t *dirty,
-                                                         const DevResult *res, double bound) {
+                                                         const DevResult *res, double bound, int edit) {
     if (res->add_status == 1) return;
     if (res->ext_slot >= 0 && res->ext_val > bound)
-        dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, threadIdx.x, blockDim.x);
+        dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit, threadIdx.x, blockDim.x);
 }
 
 __global__ void __launch_bounds__(64) k_has_edge(const int2 *rowinfo, const int32_t *col, int32_t u, int32_t v,
@@ -198,15 +205,16 @@ void launch_add_edge(dcr_graph *g, int32_t u, int32_t v) {
     hipLaunchKernelGGL(k_add_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->rowcap, g->col, u, v, g->dres);
 }
 
-void launch_remove_if_above(dcr_graph *g, double bound) {
+void launch_remove_if_above(dcr_graph *g, double bound, int edit) {
     // flag the neighbourhood while the edge is still there, then remove it
-    hipLaunchKernelGGL(k_mark_dirty_ext, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, g->dres, bound);
+    hipLaunchKernelGGL(k_mark_dirty_ext, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, g->dres, bound,
+                       edit);
     hipLaunchKernelGGL(k_remove_if_above, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->dres, bound);
 }
 
-void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v) {
+void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit) {
     if (u != -2 && (u < 0 || v < 0)) return;
-    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v, g->dres);
+    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v, edit, g->dres);
 }
 
 int sync_result(dcr_graph *g) {
@@ -373,7 +381,7 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_TRY(alloc_layout(g, tot));
     DCR_TRY(dev_alloc(&g->dres, 1));
     DCR_TRY(dev_alloc(&g->imp_stats, 1));
-    DCR_TRY(dev_alloc(&g->dirty, n));
+    DCR_TRY(dev_alloc(&g->dirty, n + 4));  // OR-ed through 32-bit words
     DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(n > 0 ? n : 1), g->stream));
     DCR_HIP(hipHostMalloc((void **)&g->hres, sizeof(DevResult), hipHostMallocDefault));
     std::memset(g->hres, 0, sizeof(DevResult));
@@ -453,7 +461,7 @@ int dcr_graph_add_edge(dcr_graph *g, int32_t u, int32_t v) {
         if (g->hres->add_status == 0) {
             g->n_edges++;
             g->max_deg_bound++;
-            launch_mark_dirty(g, u, v);
+            launch_mark_dirty(g, u, v, g->pending_edits++);
             return DCR_OK;
         }
         if (g->hres->add_status == 2) return DCR_OK;  // networkx: adding an existing edge changes nothing
@@ -467,7 +475,7 @@ int dcr_graph_remove_edge(dcr_graph *g, int32_t u, int32_t v) {
     DCR_HIP(hipSetDevice(g->device));
     g->am_valid = false;
     g->amax_valid = false;
-    launch_mark_dirty(g, u, v);
+    launch_mark_dirty(g, u, v, g->pending_edits++);
     hipLaunchKernelGGL(k_remove_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, u, v, g->dres);
     DCR_HIP(hipGetLastError());
     DCR_TRY(sync_result(g));

@@ -67,6 +67,19 @@ struct DevResult {
     int32_t misc[8];  // scratch: has_edge/remove status, and the kernels' invariant guard record
 };
 
+// Incremental pass: which edges an edit can have changed.  BFC(a,b) is a function of deg a, deg b, N(a) ∩ N(b) and the
+// adjacency between DX = N(a) \ N(b) and DY = N(b) \ N(a).  Adding or removing the edge {x,l} changes the first three
+// only for edges incident to x or l, and that adjacency only for the pair {x,l} itself, i.e. only for edges {a,b} with
+// a in N(x) and b in N(l) (or the other way round).  Per node, one byte: DIRTY_ENDPOINT on x and l, bit A_e on the
+// members of N(x) and B_e on those of N(l) for the e-th edit since the last pass (three edits fit; dcr_sdrf_tail makes
+// two); further edits fall back to DIRTY_COARSE on {x,l} ∪ N(x) ∪ N(l) (every edge with a flagged endpoint).
+constexpr unsigned DIRTY_COARSE = 0x80u, DIRTY_ENDPOINT = 0x40u;
+constexpr int DIRTY_EDITS = 3;
+__device__ __host__ inline bool edge_dirty(unsigned du, unsigned dv) {
+    if ((du | dv) & (DIRTY_COARSE | DIRTY_ENDPOINT)) return true;
+    return ((((du >> 1) & dv) | ((dv >> 1) & du)) & 0x15u) != 0u;  // some edit has its A bit on one side, its B bit on the other
+}
+
 struct ImpStats {  // per (x,y) statistics for the improvement kernels; lives in device memory
     int32_t x, y, dx, dy;
     int32_t T, s1, s2;
@@ -103,6 +116,7 @@ struct dcr_graph {
     bool curv_valid = false;
     uint8_t *dirty = nullptr;    // [n] node flags: an incident edge was added/removed at this node or a neighbour
     bool dirty_tracked = false;  // flags cover every edit since the last pass
+    int pending_edits = 0;       // edits flagged since the last pass (the first DIRTY_EDITS get exact flags)
 
     // node-centric pass (dcr_bfc_nc.hip): unit lists per degree class
     int2 *nc_units[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // {node, first sub-unit}
@@ -176,8 +190,8 @@ int ensure_scan(dcr_graph *g, int64_t n);
 int relayout(dcr_graph *g);
 int sync_result(dcr_graph *g);  // D2H of DevResult + stream sync
 void launch_add_edge(dcr_graph *g, int32_t u, int32_t v);          // u < 0: no-op that clears add_status
-void launch_remove_if_above(dcr_graph *g, double bound);           // acts on the last argext result
-void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v);         // flag {u,v} ∪ N(u) ∪ N(v)
+void launch_remove_if_above(dcr_graph *g, double bound, int edit);  // acts on the last argext result
+void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit);  // flag the edges edit number `edit` can change (>= 3: coarse)
 
 // dcr_sdrf.hip
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v);

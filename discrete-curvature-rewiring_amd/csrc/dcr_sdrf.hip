@@ -941,12 +941,15 @@ static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_rem
     g->am_valid = false;
     const bool have_amax = g->amax_valid;  // computed on this graph before the add: nothing to exclude
     g->amax_valid = false;
+    // edit numbers for the incremental pass's flags (edge_dirty): the add, then the removal
+    const int edit_add = g->pending_edits, edit_rem = g->pending_edits + (adding ? 1 : 0);
+    g->pending_edits += (adding ? 1 : 0) + (do_remove ? 1 : 0);
     for (int attempt = 0; attempt < 2; ++attempt) {
         launch_add_edge(g, add_k, add_l);
-        launch_mark_dirty(g, add_k, add_l);  // after the append: the new neighbours are flagged too
+        launch_mark_dirty(g, add_k, add_l, edit_add);  // after the append: the new neighbours are flagged too
         if (do_remove) {
             if (!(have_amax && attempt == 0)) DCR_TRY(launch_argext(g, 1, adding ? add_k : -1, adding ? add_l : -1));
-            launch_remove_if_above(g, removal_bound);
+            launch_remove_if_above(g, removal_bound, edit_rem);
         }
         DCR_HIP(hipGetLastError());
         DCR_TRY(sync_result(g));
