@@ -90,7 +90,8 @@ __device__ inline void team_sync() {
 
 struct Ingredients {
     int du, dv, T, s1, s2, gamma;
-    double bytes;
+    double bytes;   // both difference sets charged
+    double bytes1;  // the same with only the cheaper side's rows charged (what a one-sided count has to read)
 };
 
 // Whole team cooperates; the result is valid in thread 0.
@@ -238,6 +239,9 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
         if (MODE == MODE_BYTES) {
             // rows of u and v, the row of every non-triangle neighbour, row-pointer pairs, output
             out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)(len_u + len_v) + 8.0 * (double)(2 + n_u + n_v) + 8.0;
+            const bool cheap_u = len_u <= len_v;
+            out.bytes1 = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)(cheap_u ? len_u : len_v) +
+                         8.0 * (double)(2 + (cheap_u ? n_u : n_v)) + 8.0;
             return out;
         }
         // ---- stream the cheaper side ---------------------------------------------------------------------------
@@ -376,8 +380,13 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
                 if (!row_ok(g, rk, 9, k, p)) rk = make_int2(0, 0);
                 if (MODE == MODE_BYTES) {
                     if (lane == 0) {
-                        len_u += rk.y;
-                        n_u += 1;
+                        if (side == 0) {
+                            len_u += rk.y;
+                            n_u += 1;
+                        } else {
+                            len_v += rk.y;
+                            n_v += 1;
+                        }
                     }
                     continue;
                 }
@@ -405,6 +414,8 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
         if (!ONE_SIDED) {
             n_u += __shfl_xor(n_u, off);
             len_u += __shfl_xor(len_u, off);
+            n_v += __shfl_xor(n_v, off);
+            len_v += __shfl_xor(len_v, off);
         }
     }
     if (NW > 1) {
@@ -431,12 +442,32 @@ __device__ inline Ingredients edge_ingredients(const View &g, int u, int v, unsi
             len_u = ll;
         }
         team_sync<TEAM>();
+        if (!ONE_SIDED && MODE == MODE_BYTES) {  // the other side's totals, through the same scratch
+            if (lane == 0) {
+                red[3 * NW + wid] = n_v;
+                ((long long *)(red + 4 * NW))[wid] = len_v;
+            }
+            team_sync<TEAM>();
+            nn = 0;
+            ll = 0;
+            for (int w = 0; w < NW; ++w) {
+                nn += red[3 * NW + w];
+                ll += ((long long *)(red + 4 * NW))[w];
+            }
+            n_v = nn;
+            len_v = ll;
+            team_sync<TEAM>();
+        }
     }
     out.s1 = rows_are_u ? s_rows : s_slots;  // |sq1| (u's side), |sq2| (v's side)
     out.s2 = rows_are_u ? s_slots : s_rows;
     out.gamma = gam;
-    if (!ONE_SIDED && MODE == MODE_BYTES)
-        out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)len_u + 8.0 * (double)(2 + n_u) + 8.0;
+    if (!ONE_SIDED && MODE == MODE_BYTES) {
+        out.bytes = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)(len_u + len_v) + 8.0 * (double)(2 + n_u + n_v) + 8.0;
+        const bool cheap_u = len_u <= len_v;
+        out.bytes1 = 4.0 * (double)(ru.y + rv.y) + 4.0 * (double)(cheap_u ? len_u : len_v) +
+                     8.0 * (double)(2 + (cheap_u ? n_u : n_v)) + 8.0;
+    }
     return out;
 }
 
@@ -459,6 +490,7 @@ __device__ inline void pass_item(const View &g, int item, int count, const int32
             curv[s] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - q.du - q.dv + 3 * q.T) : (double)q.T;
         } else {
             atomicAdd(bytes_total, q.bytes);
+            atomicAdd(bytes_total + 1, q.bytes1);
         }
     }
 }
@@ -539,7 +571,10 @@ __device__ inline int classify_slot(const View &g, int64_t s, int64_t cap_total,
     }
     if (curv_type == DCR_CURV_BFC && (du < dv ? du : dv) == 1) {
         if (finish_trivial) {
-            if (mode == MODE_BYTES) atomicAdd(bytes_total, 24.0);
+            if (mode == MODE_BYTES) {
+                atomicAdd(bytes_total, 24.0);
+                atomicAdd(bytes_total + 1, 24.0);
+            }
             else curv[s] = 0.0;
         }
         return -1;
@@ -840,15 +875,14 @@ int dcr_curvature_edge(dcr_graph *g, int32_t u, int32_t v, int curv_type, double
     return DCR_OK;
 }
 
-int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes) {
-    if (!g || !out_bytes) DCR_FAIL(DCR_EINVAL, "null argument");
+static int algorithmic_bytes(dcr_graph *g, double out2[2]) {
     DCR_HIP(hipSetDevice(g->device));
     double *d_total = nullptr;
-    DCR_TRY(dev_alloc(&d_total, 1));
-    DCR_HIP(hipMemsetAsync(d_total, 0, sizeof(double), g->stream));
+    DCR_TRY(dev_alloc(&d_total, 2));
+    DCR_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(double), g->stream));
     int rc = run_pass<MODE_BYTES>(g, DCR_CURV_BFC, d_total);
     if (rc == DCR_OK) {
-        hipError_t e = hipMemcpyAsync(out_bytes, d_total, sizeof(double), hipMemcpyDeviceToHost, g->stream);
+        hipError_t e = hipMemcpyAsync(out2, d_total, 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         if (e != hipSuccess) {
             set_error(hipGetErrorString(e));
@@ -857,6 +891,22 @@ int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes) {
     }
     (void)hipFree(d_total);
     return rc;
+}
+
+int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes) {
+    if (!g || !out_bytes) DCR_FAIL(DCR_EINVAL, "null argument");
+    double b[2];
+    DCR_TRY(algorithmic_bytes(g, b));
+    *out_bytes = b[0];
+    return DCR_OK;
+}
+
+int dcr_bfc_algorithmic_bytes_one_sided(dcr_graph *g, double *out_bytes) {
+    if (!g || !out_bytes) DCR_FAIL(DCR_EINVAL, "null argument");
+    double b[2];
+    DCR_TRY(algorithmic_bytes(g, b));
+    *out_bytes = b[1];
+    return DCR_OK;
 }
 
 }  // extern "C"

@@ -40,21 +40,31 @@ __device__ inline int wave_find(const int32_t *row, int deg, int32_t key, int la
     return found;
 }
 
-__device__ inline void wave_erase(int32_t *row, int deg, int pos, int lane) {
-    // delete row[pos], shifting the tail left by one (keeps insertion order)
+__device__ inline void wave_erase(int32_t *row, double *crow, int deg, int pos, int lane) {
+    // delete row[pos], shifting the tail left by one (keeps insertion order).  The slot-keyed curvature values move
+    // with their edges: the buffer of the last pass stays readable per edge after a removal, like the reference's
+    // edge-keyed curv_dict (sdrf_no_cuda.py:57-61).
     for (int base = pos; base < deg - 1; base += 64) {
         int i = base + lane;
         int32_t t = 0;
-        if (i < deg - 1) t = row[i + 1];
+        double c = 0.0;
+        if (i < deg - 1) {
+            t = row[i + 1];
+            c = crow[i + 1];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        if (i < deg - 1) row[i] = t;
+        if (i < deg - 1) {
+            row[i] = t;
+            crow[i] = c;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-__device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, int32_t u, int32_t v, int lane, int *status) {
+__device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32_t u, int32_t v, int lane,
+                                int *status) {
     int2 ru = rowinfo[u], rv = rowinfo[v];
     int pu = wave_find(col + ru.x, ru.y, v, lane);
     int pv = wave_find(col + rv.x, rv.y, u, lane);
@@ -62,8 +72,8 @@ __device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, int32_t u, int32_t 
         if (lane == 0) *status = 1;
         return;
     }
-    wave_erase(col + ru.x, ru.y, pu, lane);
-    wave_erase(col + rv.x, rv.y, pv, lane);
+    wave_erase(col + ru.x, curv + ru.x, ru.y, pu, lane);
+    wave_erase(col + rv.x, curv + rv.x, rv.y, pv, lane);
     if (lane == 0) {
         rowinfo[u] = make_int2(ru.x, ru.y - 1);
         rowinfo[v] = make_int2(rv.x, rv.y - 1);
@@ -101,15 +111,16 @@ __global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *r
     res->add_status = 0;
 }
 
-__global__ void __launch_bounds__(64) k_remove_edge(int2 *rowinfo, int32_t *col, int32_t u, int32_t v,
+__global__ void __launch_bounds__(64) k_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32_t u, int32_t v,
                                                     DevResult *res) {
     int st = 0;
-    dev_remove_edge(rowinfo, col, u, v, threadIdx.x, &st);
+    dev_remove_edge(rowinfo, col, curv, u, v, threadIdx.x, &st);
     if (threadIdx.x == 0) res->misc[0] = st;
 }
 
 // tail of an SDRF iteration: remove the arg-max edge iff its (stale) curvature exceeds the bound
-__global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *col, DevResult *res, double bound) {
+__global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *col, double *curv, DevResult *res,
+                                                        double bound) {
     if (res->add_status == 1) return;  // add overflowed: host re-lays out and replays the tail
     int lane = threadIdx.x;
     int32_t u = res->ext_u, v = res->ext_v;
@@ -122,7 +133,7 @@ __global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *
         return;
     }
     int st = 0;
-    dev_remove_edge(rowinfo, col, u, v, lane, &st);
+    dev_remove_edge(rowinfo, col, curv, u, v, lane, &st);
     if (lane == 0) {
         res->removed_u = u;
         res->removed_v = v;
@@ -209,7 +220,7 @@ void launch_remove_if_above(dcr_graph *g, double bound, int edit) {
     // flag the neighbourhood while the edge is still there, then remove it
     hipLaunchKernelGGL(k_mark_dirty_ext, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, g->dres, bound,
                        edit);
-    hipLaunchKernelGGL(k_remove_if_above, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->dres, bound);
+    hipLaunchKernelGGL(k_remove_if_above, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->curv, g->dres, bound);
 }
 
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit) {
@@ -476,7 +487,7 @@ int dcr_graph_remove_edge(dcr_graph *g, int32_t u, int32_t v) {
     g->am_valid = false;
     g->amax_valid = false;
     launch_mark_dirty(g, u, v, g->pending_edits++);
-    hipLaunchKernelGGL(k_remove_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, u, v, g->dres);
+    hipLaunchKernelGGL(k_remove_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->curv, u, v, g->dres);
     DCR_HIP(hipGetLastError());
     DCR_TRY(sync_result(g));
     if (g->hres->misc[0] != 0) DCR_FAIL(DCR_ENOTFOUND, "edge not in graph");

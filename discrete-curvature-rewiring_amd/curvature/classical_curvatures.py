@@ -13,20 +13,37 @@ CURV_TYPES = ('1d', 'augmented', 'haantjes', 'bfc')
 
 
 def as_dcr_graph(G, device=0):
+    """``G`` as a device-resident graph whose adjacency rows are in the SAME order as ``G.adj[u]`` for every node, so
+    that ``G.edges`` order, and with it every first-extremum tie-break (sdrf_no_cuda.py:27,59,61), is networkx's.
+
+    networkx appends v to adj[u] and u to adj[v] in one ``add_edge``, so the rows of any real graph are the projections
+    of one edge-insertion sequence; that sequence is recovered here by merging the rows (an edge is emitted once it is
+    the next one in the rows of both its endpoints) and replayed into the container.  Node labels must be 0..n-1 in
+    insertion order, as curvature/bfc_naive.py:34-37 (positional rows of ``nx.adj_matrix``) needs them too.
+    """
     if isinstance(G, DcrGraph):
         return G
-    # networkx-like: nodes must be 0..n-1; adjacency order is taken as is
     import numpy as np
     n = G.number_of_nodes()
+    if list(G.nodes) != list(range(n)):
+        raise ValueError('node labels must be 0..n-1 in insertion order')
+    rows = [[v for v in G.adj[u] if v != u] for u in range(n)]  # (self-loops carry no curvature; none in the reference's use)
+    nxt = [0] * n
     src, dst = [], []
-    seen = set()
-    for u in G.nodes:
-        for v in G.adj[u]:
-            if v not in seen:
-                # (max, min) so that the row order of both endpoints follows G's insertion order
-                src.append(max(u, v))
-                dst.append(min(u, v))
-        seen.add(u)
+    stack = list(range(n - 1, -1, -1))
+    while stack:
+        u = stack.pop()
+        while nxt[u] < len(rows[u]):
+            v = rows[u][nxt[u]]
+            if rows[v][nxt[v]] != u:
+                break           # (u, v) waits for earlier edges of v; v's turn will come back to it
+            nxt[u] += 1
+            nxt[v] += 1
+            src.append(max(u, v))
+            dst.append(min(u, v))
+            stack.append(v)     # v's next edge may now be ready
+    if any(nxt[u] != len(rows[u]) for u in range(n)):
+        raise ValueError('adjacency rows are not the projections of one edge sequence (not a networkx.Graph?)')
     return DcrGraph(np.array([src, dst], dtype=np.int64).reshape(2, -1), n, device=device)
 
 

@@ -236,7 +236,9 @@ class DcrGraph:
         check(lib().dcr_profile_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
-    def bfc_algorithmic_bytes(self):
+    def bfc_algorithmic_bytes(self, one_sided=False):
+        """SURVEY §8(d) bytes of one BFC pass; ``one_sided``: only the cheaper difference set's rows per edge."""
         out = ctypes.c_double()
-        check(lib().dcr_bfc_algorithmic_bytes(self._h, ctypes.byref(out)))
+        fn = lib().dcr_bfc_algorithmic_bytes_one_sided if one_sided else lib().dcr_bfc_algorithmic_bytes
+        check(fn(self._h, ctypes.byref(out)))
         return out.value

@@ -271,6 +271,7 @@ class GCNConv(torch.nn.Module):
             self.register_parameter('bias', None)
         self._cache_key = None
         self._cache_csr = None
+        self._cache_ref = None   # the tensors the cache is keyed on (held: their storage cannot be recycled meanwhile)
         # Â·(X·Wᵀ) = (Â·X)·Wᵀ: when the layer's input is a constant of the run (the node features, for the first layer
         # of a GCN) Â·X is computed ONCE and the layer becomes a plain GEMM: no aggregation in the forward pass, none in
         # the backward pass, and in the data-parallel model no exchange step for this layer.  GCN switches it on for
@@ -278,30 +279,43 @@ class GCNConv(torch.nn.Module):
         self.propagate_input_first = False
         self._ax_key = None
         self._ax = None
+        self._ax_ref = None
 
     def reset_parameters(self):
         self.lin.reset_parameters()
         if self.bias is not None:
             with torch.no_grad():
                 self.bias.zero_()
-        self._cache_key = self._cache_csr = None
-        self._ax_key = self._ax = None
+        self.invalidate()
 
     def propagated_input(self, x, csr):
-        """Â·x, cached while x (same storage, same version) and the graph stay the same."""
-        key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device), self._cache_key)
+        """Â·x, cached while x (same storage, same version) and the graph stay the same.  The cache holds a reference
+        to the tensor it is keyed on: its storage cannot be freed and handed to another tensor while the entry lives,
+        so an equal (address, version, shape) key always means the same values."""
+        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), str(x.device), self._cache_key)
         if key != self._ax_key:
             with torch.no_grad():
                 self._ax = spmm(csr.rowptr, csr.col, csr.val, x.contiguous(), csr.n_rows)
             self._ax_key = key
+            self._ax_ref = x
         return self._ax
 
+    def invalidate(self):
+        """Drop the cached Â and Â·x (they are rebuilt at the next forward)."""
+        self._cache_key = self._cache_csr = self._cache_ref = None
+        self._ax_key = self._ax = self._ax_ref = None
+
     def norm_csr(self, edge_index, edge_weight, num_nodes):
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
-               None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version), str(edge_index.device))
+        # (PyG 2.0.3 with cached=False renormalises at every call; same result, the graph is a constant of a training
+        #  run.  The keyed tensors are held, see propagated_input.)
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
+               int(num_nodes),
+               None if edge_weight is None else (edge_weight.data_ptr(), edge_weight._version, tuple(edge_weight.shape)),
+               str(edge_index.device))
         if key != self._cache_key:
             self._cache_csr = gcn_norm_csr(edge_index, edge_weight, num_nodes, self.add_self_loops)
             self._cache_key = key
+            self._cache_ref = (edge_index, edge_weight)
         return self._cache_csr
 
     def forward(self, x, edge_index, edge_weight=None):

@@ -95,13 +95,15 @@ class ShardedGCN(torch.nn.Module):
 
     def propagated_input_local(self, x_local):
         """Rows of Â·X owned by this rank, computed once per (x_local, graph): all-gather X, one local SpMM."""
-        key = (x_local.data_ptr(), x_local._version, tuple(x_local.shape))
+        # (the keyed tensor is held in _ax_ref: its storage cannot be recycled while the entry lives)
+        key = (x_local.data_ptr(), x_local._version, tuple(x_local.shape), tuple(x_local.stride()))
         if key != getattr(self, '_ax_key', None):
             with torch.no_grad():
                 x_full = _GatherRows.apply(x_local.contiguous(), self.n, self.per, self.group)
                 from models.gcn import spmm
                 self._ax = spmm(self.csr.rowptr, self.csr.col, self.csr.val, x_full.contiguous(), self.csr.n_rows)
             self._ax_key = key
+            self._ax_ref = x_local
         return self._ax
 
     def allreduce_grads(self):
@@ -125,8 +127,8 @@ class ShardedGCN(torch.nn.Module):
             cache = self._sel_cache = {}
         if key not in cache:
             idx = mask_local.nonzero().squeeze(1)
-            cache[key] = (idx, y_local.index_select(0, idx), int(idx.numel()))
-        return cache[key]
+            cache[key] = (idx, y_local.index_select(0, idx), int(idx.numel()), (mask_local, y_local))  # refs held
+        return cache[key][:3]
 
     def train_step(self, optimizer, x_local, y_local, train_mask_local, n_train_global):
         self.train()

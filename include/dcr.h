@@ -127,8 +127,12 @@ int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double rem
  * handle's stream) of the curvature-pass kernels since the last reset. */
 int dcr_profile_reset(dcr_graph *g);
 int dcr_profile_read(dcr_graph *g, double *pass_ms_total, int64_t *pass_count);
-/* SURVEY §8(d) algorithmic bytes of one BFC pass on the current graph. */
+/* SURVEY §8(d) algorithmic bytes of one BFC pass on the current graph (both difference sets of every edge charged). */
 int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes);
+/* The same with only the cheaper difference set's rows charged per edge: 4(d_u+d_v) + 4*sum of the row lengths of that
+ * side + 8(2 + its size) + 8.  sq1, sq2 and gamma (bfc_naive.py:26-29,36-37) are degree statistics of ONE bipartite
+ * graph, so a pass has to read one side only; this is the byte count bench.py's roofline fraction is quoted on. */
+int dcr_bfc_algorithmic_bytes_one_sided(dcr_graph *g, double *out_bytes);
 
 /* ---- host helper for np.random.choice(n, p=softmax(a, tau)) — sdrf_no_cuda.py:49-50, utils/softmax.py:9-10
  * Given e = exp(a * tau) and its sum S (both computed by the caller's numpy: their rounding is part of the bit-exact

@@ -707,3 +707,35 @@ def test_hub_path_boundaries(dcr, oracle):
         assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
         bad = np.nonzero(cv != oc)[0]
         assert bad.size == 0, (ct, bad.size, [(int(eu[i]), int(ev[i]), cv[i], oc[i]) for i in bad[:6]])
+
+
+def test_stale_buffer_stays_edge_keyed_after_removal(dcr, oracle):
+    """sdrf_no_cuda.py:57-61 reads a curv_dict keyed by EDGE after the graph has been edited.  The buffer here is keyed
+    by adjacency slot and remove_edge shifts the row tails left, so the values have to shift with their edges: after
+    removing edges from the middle of rows, curvature_read and argext must still pair every remaining edge with the
+    value the last pass computed for it."""
+    from dcr import synthetic
+    ei, n = synthetic.powerlaw_graph(600, 5, seed=11)
+    G = dcr(ei, n)
+    eu, ev, cv = G.curvature_all('bfc')
+    stale = {(int(u), int(v)): float(c) for u, v, c in zip(eu, ev, cv)}
+    C = oracle.CGraph(ei, n)
+    ou, ov, oc = C.curv_all('bfc', nthreads=2)
+    assert stale == {(int(u), int(v)): float(c) for u, v, c in zip(ou, ov, oc)}
+    rng = np.random.Generator(np.random.PCG64(5))
+    for _ in range(12):
+        eu, ev = G.edges()
+        # an edge whose slot is not the last of its rows: pick among the first neighbours of a high-degree node
+        hub = int(np.bincount(eu).argmax())
+        nb = G.neighbors(hub)
+        w = int(nb[int(rng.integers(0, max(1, len(nb) // 2)))])
+        a, b = min(hub, w), max(hub, w)
+        G.remove_edge(a, b)
+        del stale[(a, b)]
+        ru, rv, rc = G.curvature_read()
+        assert {(int(u), int(v)): float(c) for u, v, c in zip(ru, rv, rc)} == stale
+        # first maximum / minimum over the stale values in the new G.edges order
+        vals = np.array([stale[(int(u), int(v))] for u, v in zip(ru, rv)])
+        for want_max, pick in ((True, int(np.argmax(vals))), (False, int(np.argmin(vals)))):
+            u, v, val = G.argext(want_max)
+            assert (u, v, val) == (int(ru[pick]), int(rv[pick]), float(vals[pick]))
