@@ -741,7 +741,13 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incre
 }
 
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental) {
+    g->last_engine = 2;
+    if (g->pass_impl == 0 && h2_can_take(g, curv_type, incremental)) {  // full Balanced Forman pass: two-hop kernels
+        g->last_engine = 0;
+        return launch_curvature_pass_h2(g);
+    }
     if (curv_type == DCR_CURV_1D || g->pass_impl == 1) {
+        g->last_engine = 1;
         if (curv_type == DCR_CURV_BFC || curv_type == DCR_CURV_1D)
             return run_pass<MODE_BFC>(g, curv_type, nullptr, incremental);
         return run_pass<MODE_TRI>(g, curv_type, nullptr, incremental);
@@ -806,6 +812,21 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
     if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));  // first minimum in G.edges order, same host sync
     DCR_TRY(sync_result(g));
+    if (g->last_engine == 0) {
+        for (int c = 0; c < 3; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
+        if (g->hres->h2_status != 0 && g->hres->misc[0] == 0) {
+            // a table of the two-hop pass filled up (keys of a split node hashed unevenly) or a unit list overflowed:
+            // nothing it wrote is kept, the node-centric kernels redo the whole pass
+            const int keep = g->pass_impl;
+            g->pass_impl = 2;
+            const int rc = launch_curvature_pass(g, curv_type, false);
+            g->pass_impl = keep;
+            DCR_TRY(rc);
+            if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
+            if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));
+            DCR_TRY(sync_result(g));
+        }
+    }
     if (g->profile) {
         float ms = 0.f;
         DCR_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
@@ -823,6 +844,12 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
         DCR_FAIL(DCR_ECAPACITY, "more than 65536 edges with deg(u)+deg(v)+2 > 16384 (beyond every LDS table) in one pass");
     g->curv_type_last = curv_type;
     g->curv_valid = true;
+    return DCR_OK;
+}
+
+int dcr_pass_engine(dcr_graph *g, int *out) {
+    if (!g || !out) DCR_FAIL(DCR_EINVAL, "null argument");
+    *out = g->last_engine;
     return DCR_OK;
 }
 

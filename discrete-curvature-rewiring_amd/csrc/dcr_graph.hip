@@ -373,7 +373,8 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     g->n_edges = (int64_t)keep.size();
     for (int64_t u = 0; u < n; ++u)
         if (deg[(size_t)u] > g->max_deg_bound) g->max_deg_bound = deg[(size_t)u];
-    if (const char *impl = getenv("DCR_PASS")) g->pass_impl = (std::string(impl) == "edge") ? 1 : 0;
+    if (const char *impl = getenv("DCR_PASS"))
+        g->pass_impl = (std::string(impl) == "edge") ? 1 : (std::string(impl) == "nc") ? 2 : 0;
     *out = g;  // caller destroys on failure
     DCR_HIP(hipStreamCreate(&g->stream));
     DCR_HIP(hipEventCreate(&g->ev0));
@@ -420,7 +421,8 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
                         g->imp_stats, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
                         g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
-                        g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt};
+                        g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
+                        g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_rec};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)

@@ -65,6 +65,11 @@ struct DevResult {
     int64_t imp_argmax;
     int32_t cand_i, cand_j;
     int32_t misc[8];  // scratch: has_edge/remove status, and the kernels' invariant guard record
+    // two-hop pass (dcr_bfc_h2.hip): units per (class, weight bucket), placement cursors, units per class
+    int32_t h2_bucket[24];
+    int32_t h2_fill[24];
+    int32_t h2_count[3];
+    int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels)
 };
 
 // Incremental pass: which edges an edit can have changed.  BFC(a,b) is a function of deg a, deg b, N(a) ∩ N(b) and the
@@ -126,7 +131,18 @@ struct dcr_graph {
     uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
     int64_t nc_touch_cap = 0;
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
-    int pass_impl = 0;            // 0: node-centric (default), 1: edge-centric kernels only (DCR_PASS=edge)
+    int pass_impl = 0;            // 0: two-hop pass for full BFC passes, node-centric otherwise (default); 1: edge-centric
+                                  // kernels only (DCR_PASS=edge); 2: node-centric, never the two-hop pass (DCR_PASS=nc)
+    int last_engine = -1;         // which implementation ran the last pass: 0 two-hop, 1 edge-centric, 2 node-centric
+
+    // two-hop pass (dcr_bfc_h2.hip)
+    int32_t *h2_weight = nullptr;     // [n] sum of the neighbours' degrees
+    int2 *h2_units[3] = {nullptr, nullptr, nullptr};  // per class {node, partitions << 16 | partition}
+    int64_t h2_units_cap[3] = {0, 0, 0};
+    uint4 *h2_rec = nullptr;          // [cap_total] per directed slot {|sq| on the far side, max count, triangles, reverse slot}
+    int64_t h2_rec_cap = 0;
+    int64_t h2_weight_cap = 0;
+    int32_t h2_last_count[3] = {-1, -1, -1};  // units per class of the previous pass (sizes the next grids)
 
     // edges beyond every LDS table (dcr_bfc_giant.hip): records {slot, u, v, deg u, deg v}; position map over all ids
     int32_t *giant_list = nullptr;
@@ -203,6 +219,9 @@ int giant_edge(dcr_graph *g, int u, int v, int du, int dv, int64_t slot, int cur
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental);
 // dcr_bfc_nc.hip
 int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental);
+// dcr_bfc_h2.hip
+bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental);
+int launch_curvature_pass_h2(dcr_graph *g);
 
 template <typename T>
 int dev_alloc(T **p, int64_t count) {

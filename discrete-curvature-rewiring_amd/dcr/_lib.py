@@ -51,6 +51,7 @@ SIGNATURES = {
     'dcr_profile_read': (ctypes.c_int, [_vp, _f64p, _i64p]),
     'dcr_bfc_algorithmic_bytes': (ctypes.c_int, [_vp, _f64p]),
     'dcr_bfc_algorithmic_bytes_one_sided': (ctypes.c_int, [_vp, _f64p]),
+    'dcr_pass_engine': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     'dcr_host_cdf_from_exp': (ctypes.c_int, [_f64p, _i64, _f64, _f64p, _f64p]),
     'dcr_host_cdf_from_exp_plain': (ctypes.c_int, [_f64p, _i64, _f64, _f64p, _f64p]),
     'dcr_spmm_csr_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),

@@ -236,6 +236,12 @@ class DcrGraph:
         check(lib().dcr_profile_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
 
+    def pass_engine(self):
+        """Which kernels ran the last curvature pass (all produce the same bits)."""
+        out = ctypes.c_int()
+        check(lib().dcr_pass_engine(self._h, ctypes.byref(out)))
+        return {0: 'two-hop', 1: 'edge-centric', 2: 'node-centric'}.get(out.value, 'none')
+
     def bfc_algorithmic_bytes(self, one_sided=False):
         """SURVEY §8(d) bytes of one BFC pass; ``one_sided``: only the cheaper difference set's rows per edge."""
         out = ctypes.c_double()
