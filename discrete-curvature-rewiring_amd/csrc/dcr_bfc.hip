@@ -742,7 +742,7 @@ static int run_pass(dcr_graph *g, int curv_type, double *bytes_total, bool incre
 
 int launch_curvature_pass(dcr_graph *g, int curv_type, bool incremental) {
     g->last_engine = 2;
-    if (g->pass_impl == 0 && h2_can_take(g, curv_type, incremental)) {  // full Balanced Forman pass: two-hop kernels
+    if (h2_can_take(g, curv_type, incremental)) {  // DCR_PASS=h2: full Balanced Forman passes by the two-hop kernels
         g->last_engine = 0;
         return launch_curvature_pass_h2(g);
     }
@@ -818,7 +818,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
             // a table of the two-hop pass filled up (keys of a split node hashed unevenly) or a unit list overflowed:
             // nothing it wrote is kept, the node-centric kernels redo the whole pass
             const int keep = g->pass_impl;
-            g->pass_impl = 2;
+            g->pass_impl = 0;
             const int rc = launch_curvature_pass(g, curv_type, false);
             g->pass_impl = keep;
             DCR_TRY(rc);

@@ -1,4 +1,7 @@
-// Two-hop curvature pass of libdcr_hip.so: the default implementation of a FULL Balanced Forman pass.
+// Two-hop curvature pass of libdcr_hip.so: an ALTERNATIVE implementation of a full Balanced Forman pass (DCR_PASS=h2).
+// Same bits as the node-centric kernels, 9x fewer adjacency entries streamed, but slower on MI355X as built (3.0 ms against
+// 1.98 ms on the bench graph, DESIGN.md §4.1b has the counters): the map of a node grows with its 2-HOP neighbourhood, so
+// LDS admits 8 waves per CU where the node-centric kernels run 24, and every visit pays an LDS atomic.
 //
 // Replaces compute_curvature_graph(G, 'bfc') at rewiring/sdrf_no_cuda.py:24, i.e. E calls of bfc_naive.bfc_edge
 // (curvature/bfc_naive.py:7-40), with the same integers and the same float64 closing expression as the other two
@@ -22,12 +25,24 @@
 // Each node writes, per adjacency slot u->v, {|sq| on v's side, max count, T, reverse slot}; a final kernel joins the two
 // records of an edge and evaluates the float64 closing expression in the reference's order (bfc_naive.py:31-40).
 //
+// The map.  96 % of the 2-hop entries occur once, and what is rare per lane (a second occurrence, a collision) happens in
+// nearly every 64-lane instruction, so the common case must be branch-free and the rest must not run at 1/64 occupancy:
+//   * a direct-mapped FRONT table takes the first key that hashes to a slot with ONE compare-and-swap (phase A) and
+//     answers "seen exactly once, not a neighbour" with ONE read (phase B);
+//   * everything else — later occurrences, keys whose front slot is taken by another key, the flagged members of N(u) —
+//     lives in an OVERFLOW table (4-slot buckets, 15-bit counters, as in dcr_bfc_nc.hip); M_u(w) = its counter, plus
+//     one if w also holds its front slot;
+//   * lanes that need the overflow table do not walk it on the spot: they queue (key, row) in LDS and the wave works the
+//     queue off 64 items at a time.
+// (First cut, bucket table only, every lane walking it in line: 720 M vector instructions per pass, as many as the
+// node-centric kernels execute for nine times the entries.)
+//
 // Nodes are grouped by K = deg + 1 + Σ neighbour degrees (an upper bound of the keys of M_u): up to 1,280 keys a wave
-// owns a node and a private 2,048-slot table; up to 5,120 (10,240) a workgroup of 8 (16) waves shares a table of 8,192
-// (16,384) slots; beyond that the KEYS of a node are split by a second hash into P partitions, each a unit of its own
-// (every unit streams all rows but keeps only its share; results meet in the record through integer atomics), which
-// also spreads a hub over P workgroups.  Units are laid out heaviest first.  Bounds: HBM / L2 row streaming
-// (2 x 4 B x Σ d² per pass) and LDS atomics; no MFMA (integer set counting).
+// owns a node and private tables (2,048 front slots); up to 5,120 (10,240) a workgroup of 4 (8) waves shares tables of
+// 8,192 (16,384) front slots; beyond that the KEYS of a node are split by a second hash into P partitions, each a unit
+// of its own (every unit streams all rows but keeps only its share; results meet in the record through integer
+// atomics), which also spreads a hub over P workgroups.  Units are laid out heaviest first.  Bounds: HBM / L2 row
+// streaming (2 x 4 B x Σ d² per pass) and LDS atomics; no MFMA (integer set counting).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -44,11 +59,20 @@ constexpr int H2_WB = 8;         // weight buckets per class (units are laid out
 #define H2_Q 2                   // 16-byte pieces per lane in flight in the streaming loops
 #endif
 
-__host__ __device__ constexpr int h2_cap(int c) { return c == 0 ? 2048 : c == 1 ? 8192 : 16384; }
+__host__ __device__ constexpr int h2_capd(int c) { return c == 0 ? 2048 : c == 1 ? 8192 : 16384; }  // front slots
+__host__ __device__ constexpr int h2_cap(int c) { return h2_capd(c) / 2; }                            // overflow slots
 __host__ __device__ constexpr int h2_maxkeys(int c) { return c == 0 ? 1280 : c == 1 ? 5120 : 10240; }
-__host__ __device__ constexpr int h2_waves(int c) { return c == 0 ? 1 : c == 1 ? 8 : 16; }
+#ifndef H2_W1
+#define H2_W1 4
+#endif
+#ifndef H2_W2
+#define H2_W2 8
+#endif
+__host__ __device__ constexpr int h2_waves(int c) { return c == 0 ? 1 : c == 1 ? H2_W1 : H2_W2; }
 __host__ __device__ constexpr int h2_ecap(int c) { return c == 0 ? 128 : 256; }
 constexpr int H2_WPB0 = 2;  // waves (= nodes in flight) per workgroup of the wave class
+constexpr unsigned H2_FLAG = 0x80000000u;  // on a front entry: the key also has an overflow entry (node ids stay below 2^30)
+constexpr int H2_QCAP = 192;               // queued overflow items per wave (worked off when fewer than 64 slots are left)
 
 __device__ inline void h2_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -67,6 +91,13 @@ __device__ inline unsigned h2_bucket(unsigned key) {
     constexpr int BITS = __builtin_ctz(CAP / 4);
     unsigned prod;  // Fibonacci hashing of the low 24 bits with the full-rate 24-bit multiply (see dcr_bfc_nc.hip)
     asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(prod) : "v"(key));
+    return (prod >> (24 - BITS)) & ((1u << BITS) - 1);
+}
+template <int CAPD>
+__device__ inline unsigned h2_dslot(unsigned key) {  // front slot: another 24-bit multiplier than the bucket hash
+    constexpr int BITS = __builtin_ctz(CAPD);
+    unsigned prod;
+    asm("v_mul_u32_u24 %0, 0x85ebcb, %1" : "=v"(prod) : "v"(key));
     return (prod >> (24 - BITS)) & ((1u << BITS) - 1);
 }
 // which partition of a split node a key belongs to: a hash independent of the bucket hash
@@ -131,9 +162,32 @@ struct H2Scratch {
     int2 desc[64];   // {start, length} of the rows of the current batch
     int poff[66];    // exclusive prefix of their piece counts; poff[64] = total
     int rowT[64], rowPos[64], rowMx[64], rowRev[64];  // phase B accumulators per row of the batch
-    unsigned ekey[ECAP];  // step C: the positive candidates of one edge ...
-    unsigned eval[ECAP];  // ... count << 16 | triangle partners adjacent to it
+    unsigned ekey[ECAP];  // step C: candidate ids and counts ...
+    unsigned eval[ECAP];  // ... triangle partners and corrections
+    unsigned qw[H2_QCAP];       // queued overflow work: key ...
+    unsigned char qr[H2_QCAP];  // ... and row of the batch
 };
+
+// the three LDS arrays of a unit
+struct H2Tab {
+    unsigned *front;  // [CAPD] direct-mapped: key, | H2_FLAG once the key has an overflow entry
+    unsigned *key;    // [CAP]  overflow keys, 4-slot buckets
+    unsigned *cnt;    // [CAP / 2] their state, 16 bits each
+};
+
+// M_u(w) and whether w is a member of N(u); {0, false} for a key this unit does not hold
+template <int CAPD, int CAP>
+__device__ inline int h2_query(const H2Tab t, unsigned w, bool &nbr) {
+    nbr = false;
+    const unsigned e = t.front[h2_dslot<CAPD>(w)];
+    if (e == w) return 1;
+    if (e == H2_EMPTY) return 0;  // every key that was ever touched found its front slot taken, or took it
+    const int s = h2_find<CAP>(t.key, w);
+    if (s < 0) return 0;
+    const unsigned c16 = h2_cnt_get(t.cnt, s);
+    nbr = (c16 & 0x8000u) != 0u;
+    return (int)(c16 & 0x7FFFu) + ((e & ~H2_FLAG) == w ? 1 : 0);
+}
 
 __device__ inline unsigned h2_piece_mask(int a, int lo, int hi) {
     const int s = lo - a, t = hi - a;
@@ -164,110 +218,104 @@ __device__ inline unsigned h2_ehash(unsigned key) {
     return (key * 0x9E3779B1u) >> (32 - BITS);
 }
 
+// ---- the edge set: every undirected edge as one 64-bit key in an open-addressing table in device memory -------------------
+// Rebuilt by every pass (one CAS per edge).  Step C asks it "is w adjacent to t?" a few times per edge with triangles,
+// where the first cut streamed the whole (hub) row of every triangle partner: 2.3 ms of a 4.7 ms pass on the bench graph.
+constexpr unsigned long long H2_ESET_EMPTY = ~0ull;
+__device__ inline unsigned long long h2_edge_key(int a, int b) {
+    return a < b ? ((unsigned long long)(unsigned)a << 32) | (unsigned)b : ((unsigned long long)(unsigned)b << 32) | (unsigned)a;
+}
+__device__ inline unsigned long long h2_eset_slot(unsigned long long key, int bits) {
+    return (key * 0x9E3779B97F4A7C15ull) >> (64 - bits);
+}
+struct H2EdgeSet {
+    unsigned long long *tab;
+    int bits;
+};
+__device__ inline bool h2_eset_has(const H2EdgeSet es, int a, int b) {
+    const unsigned long long key = h2_edge_key(a, b), mask = (1ull << es.bits) - 1ull;
+    unsigned long long h = h2_eset_slot(key, es.bits);
+    for (unsigned long long walk = 0; walk <= mask; ++walk) {
+        const unsigned long long k = es.tab[h];
+        if (k == key) return true;
+        if (k == H2_ESET_EMPTY) return false;
+        h = (h + 1) & mask;
+    }
+    return false;
+}
+__global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int32_t *status) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= g.cap_total) return;
+    const int u = g.slot_row[s];
+    if (u < 0 || u >= g.n) return;
+    const int2 ru = g.rowinfo[u];
+    if (s < ru.x || (int)(s - ru.x) >= ru.y) return;
+    const int v = g.col[s];
+    if (v <= u || v >= g.n) return;
+    const unsigned long long key = h2_edge_key(u, v), mask = (1ull << es.bits) - 1ull;
+    unsigned long long h = h2_eset_slot(key, es.bits);
+    for (unsigned long long walk = 0; walk <= mask; ++walk) {
+        const unsigned long long old = atomicCAS(&es.tab[h], H2_ESET_EMPTY, key);
+        if (old == H2_ESET_EMPTY || old == key) return;
+        h = (h + 1) & mask;
+    }
+    *status = 1;
+}
+
 // ---- step C: one edge {u,v} with triangles and positive counts, by one wave ------------------------------------------
 // Returns {|{w : c(w) > 0}|, max c(w)} over the w of row v that live in this unit's table, c(w) = M_u(w) - 1 - |N(w) ∩ Tset|.
-template <int CAP, int ECAP>
-__device__ inline int2 h2_edge_with_triangles(const View &g, int u, int2 rv, const unsigned *key, const unsigned *cnt,
+// One sweep of row v lists the candidates (w outside N(u) with M_u(w) >= 2) and the triangle partners (flagged w); every
+// (candidate, partner) pair is then one probe of the edge set.  Lists longer than LCAP are taken LCAP at a time.
+template <int CAPD, int CAP, int ECAP>
+__device__ inline int2 h2_edge_with_triangles(const View &g, const H2EdgeSet es, int u, int2 rv, const H2Tab t,
                                               H2Scratch<ECAP> *sc, int32_t *status) {
+    constexpr int LCAP = ECAP / 2;  // candidates: ekey[0..LCAP) ids, ekey[LCAP..) counts; partners: eval[0..LCAP); corrections: eval[LCAP..)
     const int lane = threadIdx.x & 63;
     const int32_t *rowv = g.col + rv.x;
-    // how many positive candidates does the row hold?  They are handled ECAP / 4 at a time (table load <= 1/4).
-    int nheavy = 0;
-    for (int base = 0; base < rv.y; base += 64) {
-        const int i = base + lane;
-        const int w = i < rv.y ? rowv[i] : -1;
-        bool hv = false;
-        if (w >= 0 && w != u) {
-            const int s = h2_find<CAP>(key, (unsigned)w);
-            if (s >= 0) {
-                const unsigned c16 = h2_cnt_get(cnt, s);
-                hv = !(c16 & 0x8000u) && (c16 & 0x7FFFu) >= 2u;
-            }
-        }
-        nheavy += __popcll(__ballot(hv));
-    }
-    const int rounds = (nheavy + ECAP / 4 - 1) / (ECAP / 4);
+    const unsigned long long below = (1ull << lane) - 1ull;
     int pos = 0, mx = 0;
-    for (int rd = 0; rd < rounds; ++rd) {
-        for (int i = lane; i < ECAP; i += 64) {
-            sc->ekey[i] = H2_EMPTY;
-            sc->eval[i] = 0u;
-        }
-        h2_wave_sync();
-        for (int base = 0; base < rv.y; base += 64) {
-            const int i = base + lane;
-            const int w = i < rv.y ? rowv[i] : -1;
-            if (w >= 0 && w != u) {
-                const int s = h2_find<CAP>(key, (unsigned)w);
-                if (s >= 0) {
-                    const unsigned c16 = h2_cnt_get(cnt, s);
-                    const bool hv = !(c16 & 0x8000u) && (c16 & 0x7FFFu) >= 2u;
-                    if (hv && (rounds == 1 || (int)(((unsigned)w * 0xC2B2AE35u) >> 8) % rounds == rd)) {
-                        unsigned e = h2_ehash<ECAP>((unsigned)w);
-                        bool placed = false;
-                        for (int walk = 0; walk < ECAP; ++walk) {
-                            const unsigned old = atomicCAS(&sc->ekey[e], H2_EMPTY, (unsigned)w);
-                            if (old == H2_EMPTY || old == (unsigned)w) {
-                                sc->eval[e] = (c16 & 0x7FFFu) << 16;  // (a row holds each id once: one writer per slot)
-                                placed = true;
-                                break;
-                            }
-                            e = (e + 1) & (ECAP - 1);
-                        }
-                        if (!placed) *status = 1;
-                    }
+    int ncand_total = 0, npart_total = 0;
+    for (int cbase = 0, first = 1; first || cbase < ncand_total; cbase += LCAP, first = 0) {
+        for (int pbase = 0, pfirst = 1; pfirst || pbase < npart_total; pbase += LCAP, pfirst = 0) {
+            // sweep row v: candidates number cbase.. and partners number pbase.. go to the lists
+            int nc = 0, np = 0;  // running totals (uniform)
+            for (int base = 0; base < rv.y; base += 64) {
+                const int i = base + lane;
+                const int w = i < rv.y ? rowv[i] : -1;
+                bool isC = false, isT = false;
+                int M = 0;
+                if (w >= 0 && w != u) {
+                    M = h2_query<CAPD, CAP>(t, (unsigned)w, isT);
+                    isC = !isT && M >= 2;
                 }
-            }
-        }
-        h2_wave_sync();
-        // the rows of the triangle partners t (flagged members of row v), one after the other, against the small table
-        for (int base = 0; base < rv.y; base += 64) {
-            const int i = base + lane;
-            const int w = i < rv.y ? rowv[i] : -1;
-            bool isT = false;
-            if (w >= 0 && w != u) {
-                const int s = h2_find<CAP>(key, (unsigned)w);
-                isT = s >= 0 && (h2_cnt_get(cnt, s) & 0x8000u);
-            }
-            unsigned long long mT = __ballot(isT);
-            while (mT) {
-                const int b = __ffsll((long long)mT) - 1;
-                mT &= mT - 1;
-                const int t = __shfl(w, b);
-                int2 rt = make_int2(0, 0);
-                if (t >= 0 && t < g.n) rt = g.rowinfo[t];
-                if (!row_ok(g, rt, 31, t, u)) rt = make_int2(0, 0);
-                const int hi = rt.x + rt.y;
-                for (int a = (rt.x & ~3) + 4 * lane; a < hi; a += 256) {
-                    const int4 p = load_piece(g.col, a);
-                    const unsigned m = h2_piece_mask(a, rt.x, hi);
-                    const unsigned x[4] = {(unsigned)p.x, (unsigned)p.y, (unsigned)p.z, (unsigned)p.w};
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        if (!((m >> jj) & 1u)) continue;
-                        unsigned e = h2_ehash<ECAP>(x[jj]);
-                        for (int walk = 0; walk < ECAP; ++walk) {
-                            const unsigned kx = sc->ekey[e];
-                            if (kx == x[jj]) {
-                                atomicAdd(&sc->eval[e], 1u);
-                                break;
-                            }
-                            if (kx == H2_EMPTY) break;
-                            e = (e + 1) & (ECAP - 1);
-                        }
-                    }
+                const unsigned long long mC = __ballot(isC), mT = __ballot(isT);
+                const int ic = nc + __popcll(mC & below) - cbase, it = np + __popcll(mT & below) - pbase;
+                if (isC && ic >= 0 && ic < LCAP) {
+                    sc->ekey[ic] = (unsigned)w;
+                    sc->ekey[LCAP + ic] = (unsigned)(M - 1);
+                    if (pbase == 0) sc->eval[LCAP + ic] = 0u;  // corrections accumulate over the partner rounds
                 }
+                if (isT && it >= 0 && it < LCAP) sc->eval[it] = (unsigned)w;
+                nc += __popcll(mC);
+                np += __popcll(mT);
             }
+            ncand_total = nc;
+            npart_total = np;
+            h2_wave_sync();
+            const int ncl = nc - cbase < LCAP ? nc - cbase : LCAP, npl = np - pbase < LCAP ? np - pbase : LCAP;
+            const int pairs = (ncl > 0 && npl > 0) ? ncl * npl : 0;
+            for (int p = lane; p < pairs; p += 64) {
+                const int ci = p / npl, tj = p - ci * npl;
+                if (h2_eset_has(es, (int)sc->ekey[ci], (int)sc->eval[tj])) atomicAdd(&sc->eval[LCAP + ci], 1u);
+            }
+            h2_wave_sync();
         }
-        h2_wave_sync();
-        for (int e = lane; e < ECAP; e += 64) {
-            if (sc->ekey[e] != H2_EMPTY) {
-                const unsigned val = sc->eval[e];
-                const int c = (int)(val >> 16) - 1 - (int)(val & 0xFFFFu);
-                if (c > 0) {
-                    ++pos;
-                    mx = c > mx ? c : mx;
-                }
+        const int ncl = ncand_total - cbase < LCAP ? ncand_total - cbase : LCAP;
+        for (int ci = lane; ci < ncl; ci += 64) {
+            const int c = (int)sc->ekey[LCAP + ci] - (int)sc->eval[LCAP + ci];
+            if (c > 0) {
+                ++pos;
+                mx = c > mx ? c : mx;
             }
         }
         h2_wave_sync();
@@ -277,18 +325,58 @@ __device__ inline int2 h2_edge_with_triangles(const View &g, int u, int2 rv, con
         const int o = __shfl_xor(mx, off);
         mx = o > mx ? o : mx;
     }
+    (void)status;
     return make_int2(pos, mx);
 }
 
 // ---- phases A and B: the rows of the neighbours of u, in batches of 64 rows per wave --------------------------------
+// the queued overflow work of one wave (see the file comment): n is uniform and lives in a register
+template <int CAPD, int CAP, int ECAP, int PHASE>
+__device__ inline void h2_drain(const H2Tab t, H2Scratch<ECAP> *sc, int &n, int32_t *status) {
+    const int lane = threadIdx.x & 63;
+    h2_wave_sync();
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i >= n) continue;
+        const unsigned w = sc->qw[i];
+        const unsigned ds = h2_dslot<CAPD>(w);
+        const unsigned e = t.front[ds];
+        const bool in_front = (e & ~H2_FLAG) == w;
+        if (PHASE == 0) {
+            if (in_front && !(e & H2_FLAG)) atomicOr(&t.front[ds], H2_FLAG);  // a second occurrence of the slot's own key
+            const int s = h2_insert<CAP>(t.key, w);
+            if (s < 0) *status = 1;
+            else h2_cnt_add(t.cnt, s);
+        } else {
+            const int s = h2_find<CAP>(t.key, w);
+            if (s >= 0) {
+                const int r = sc->qr[i];
+                const unsigned c16 = h2_cnt_get(t.cnt, s);
+                if (c16 & 0x8000u) {
+                    atomicAdd(&sc->rowT[r], 1);
+                } else {
+                    const int c = (int)(c16 & 0x7FFFu) + (in_front ? 1 : 0) - 1;
+                    if (c > 0) {
+                        atomicAdd(&sc->rowPos[r], 1);
+                        atomicMax(&sc->rowMx[r], c);
+                    }
+                }
+            }
+        }
+    }
+    h2_wave_sync();
+    n = 0;
+}
+
 // Wave `wid` of NW takes the rows i = wid, wid + NW, ... of row u (strided: a hub's heaviest rows, adjacent at the
 // front of its row, spread over the waves); lane l of the batch starting at `base` stands for row base + l * NW + wid.
-template <int CAP, int NW, int ECAP, bool PARTS, int PHASE>
-__device__ inline void h2_stream(const View &g, int u, int2 ru, int part, int nparts, unsigned *key, unsigned *cnt,
+template <int CAPD, int CAP, int NW, int ECAP, bool PARTS, int PHASE>
+__device__ inline void h2_stream(const View &g, const H2EdgeSet es, int u, int2 ru, int part, int nparts, const H2Tab t,
                                  H2Scratch<ECAP> *sc, uint4 *rec, int32_t *status) {
     const int lane = threadIdx.x & 63;
     const int wid = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
-    const uint4 *tb = reinterpret_cast<const uint4 *>(key);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int qn = 0;  // queued overflow items (uniform)
     for (int base = 0; base < ru.y; base += 64 * NW) {
         const int i = base + lane * NW + wid;
         int k = -1;
@@ -306,8 +394,8 @@ __device__ inline void h2_stream(const View &g, int u, int2 ru, int part, int np
         int incl = np;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+            const int tt = __shfl_up(incl, off);
+            if (lane >= off) incl += tt;
         }
         const int P = __shfl(incl, 63);
         if (P == 0) continue;  // uniform: no row in this wave's share of the batch
@@ -344,57 +432,62 @@ __device__ inline void h2_stream(const View &g, int u, int2 ru, int part, int np
             }
 #pragma unroll
             for (int q = 0; q < H2_Q; ++q) {
-                if (rr[q] < 0) continue;
-                const int2 d = sc->desc[rr[q]];
-                const unsigned vm = h2_piece_mask(aa[q], d.x, d.x + d.y);
-                const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
-                bool take[4];
-                unsigned b[4];
-                uint4 e[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    take[jj] = ((vm >> jj) & 1u) && kk[jj] != (unsigned)u && kk[jj] < (unsigned)g.n;
-                    if (PHASE == 0 && PARTS) take[jj] = take[jj] && h2_part(kk[jj], nparts) == part;
-                    if (PHASE == 1 && ((vm >> jj) & 1u) && kk[jj] == (unsigned)u) sc->rowRev[rr[q]] = aa[q] + jj;
-                    b[jj] = h2_bucket<CAP>(kk[jj]);
-                    e[jj] = take[jj] ? tb[b[jj]] : make_uint4(0u, 0u, 0u, 0u);
+                if (j0 + 64 * q >= P) continue;  // uniform
+                unsigned vm = 0u;
+                if (rr[q] >= 0) {
+                    const int2 d = sc->desc[rr[q]];
+                    vm = h2_piece_mask(aa[q], d.x, d.x + d.y);
                 }
+                const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+                bool slow[4];
+                // the common case, branch-free: one compare-and-swap (A) or one read (B) on the front table per entry
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    if (!take[jj]) continue;
-                    if (PHASE == 0) {
-                        const int s = h2_insert_from<CAP>(key, b[jj], e[jj], kk[jj]);
-                        if (s < 0) *status = 1;
-                        else h2_cnt_add(cnt, s);
-                    } else {
-                        const int s = h2_find_from<CAP>(key, b[jj], e[jj], kk[jj]);
-                        if (s >= 0) {
-                            const unsigned c16 = h2_cnt_get(cnt, s);
-                            if (c16 & 0x8000u) {
-                                atomicAdd(&sc->rowT[rr[q]], 1);
-                            } else {
-                                const int c = (int)(c16 & 0x7FFFu) - 1;
-                                if (c > 0) {
-                                    atomicAdd(&sc->rowPos[rr[q]], 1);
-                                    atomicMax(&sc->rowMx[rr[q]], c);
-                                }
-                            }
+                    const bool in = (vm >> jj) & 1u;
+                    bool take = in && kk[jj] != (unsigned)u && kk[jj] < (unsigned)g.n;
+                    if (PHASE == 0 && PARTS) take = take && h2_part(kk[jj], nparts) == part;
+                    if (PHASE == 1 && in && kk[jj] == (unsigned)u) sc->rowRev[rr[q]] = aa[q] + jj;
+                    slow[jj] = false;
+                    if (take) {
+                        unsigned *fs = &t.front[h2_dslot<CAPD>(kk[jj])];
+                        if (PHASE == 0) {
+                            slow[jj] = atomicCAS(fs, H2_EMPTY, kk[jj]) != H2_EMPTY;
+                        } else {
+                            const unsigned e = *fs;
+                            slow[jj] = e != kk[jj] && e != H2_EMPTY;
                         }
                     }
                 }
+                // whatever needs the overflow table is queued
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned long long m = __ballot(slow[jj]);
+                    if (m == 0) continue;  // uniform
+                    if (qn > H2_QCAP - 64) h2_drain<CAPD, CAP, ECAP, PHASE>(t, sc, qn, status);
+                    if (slow[jj]) {
+                        const int idx = qn + __popcll(m & below);
+                        sc->qw[idx] = kk[jj];
+                        if (PHASE == 1) sc->qr[idx] = (unsigned char)rr[q];
+                    }
+                    qn += __popcll(m);
+                }
             }
         }
+        if (PHASE == 1) h2_drain<CAPD, CAP, ECAP, PHASE>(t, sc, qn, status);  // the row totals are read next
         h2_wave_sync();
         if (PHASE == 1) {
             int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
             const int rev = sc->rowRev[lane];
             // triangles AND positive counts: the counts of this edge still include the triangle partners (step C)
             unsigned long long todo = __ballot(k >= 0 && T > 0 && pos > 0);
+#ifdef H2_NO_STEPC  // timing-only build (results wrong)
+            todo = 0;
+#endif
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const int2 rv = make_int2(__shfl(rk.x, l), __shfl(rk.y, l));
-                const int2 pm = h2_edge_with_triangles<CAP, ECAP>(g, u, rv, key, cnt, sc, status);
+                const int2 pm = h2_edge_with_triangles<CAPD, CAP, ECAP>(g, es, u, rv, t, sc, status);
                 if (lane == l) {
                     pos = pm.x;
                     mx = pm.y;
@@ -419,39 +512,48 @@ __device__ inline void h2_stream(const View &g, int u, int2 ru, int part, int np
             h2_wave_sync();
         }
     }
+    if (qn > 0) h2_drain<CAPD, CAP, ECAP, PHASE>(t, sc, qn, status);  // (after the loop: a wave's last batches may be empty)
 }
 
-// one unit: node u, key partition `part` of `nparts`, by NW waves sharing `key` / `cnt`
-template <int CAP, int NW, int ECAP, bool PARTS>
-__device__ inline void h2_node(const View &g, int u, int2 ru, int part, int nparts, unsigned *key, unsigned *cnt,
+// one unit: node u, key partition `part` of `nparts`, by NW waves sharing the tables `t`
+template <int CAPD, int CAP, int NW, int ECAP, bool PARTS>
+__device__ inline void h2_node(const View &g, const H2EdgeSet es, int u, int2 ru, int part, int nparts, const H2Tab t,
                                H2Scratch<ECAP> *sc, uint4 *rec, int32_t *status) {
     const int tid = NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     constexpr int NT = 64 * NW;
-    uint4 *k4 = reinterpret_cast<uint4 *>(key);
-    uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+    uint4 *f4 = reinterpret_cast<uint4 *>(t.front);
+    uint4 *k4 = reinterpret_cast<uint4 *>(t.key);
+    uint4 *c4 = reinterpret_cast<uint4 *>(t.cnt);
+    for (int i = tid; i < CAPD / 4; i += NT) f4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
     for (int i = tid; i < CAP / 4; i += NT) k4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
     for (int i = tid; i < CAP / 8; i += NT) c4[i] = make_uint4(0u, 0u, 0u, 0u);
     h2_sync<NW>();
-    for (int i = tid; i < ru.y; i += NT) {  // the members of N(u), flagged (in every partition's table)
+    for (int i = tid; i < ru.y; i += NT) {  // the members of N(u): flagged overflow entries (in every partition's tables)
         const int k = g.col[ru.x + i];
         if (k >= 0 && k < g.n && k != u) {
-            const int s = h2_insert<CAP>(key, (unsigned)k);
+            const int s = h2_insert<CAP>(t.key, (unsigned)k);
             if (s < 0) *status = 1;
-            else h2_cnt_flag(cnt, s);
+            else h2_cnt_flag(t.cnt, s);
+            atomicCAS(&t.front[h2_dslot<CAPD>((unsigned)k)], H2_EMPTY, (unsigned)k | H2_FLAG);  // (taken: k stays overflow-only)
         }
     }
     h2_sync<NW>();
-    h2_stream<CAP, NW, ECAP, PARTS, 0>(g, u, ru, part, nparts, key, cnt, sc, rec, status);
+#ifndef H2_NO_PHASEA
+    h2_stream<CAPD, CAP, NW, ECAP, PARTS, 0>(g, es, u, ru, part, nparts, t, sc, rec, status);
+#endif
     h2_sync<NW>();
-    h2_stream<CAP, NW, ECAP, PARTS, 1>(g, u, ru, part, nparts, key, cnt, sc, rec, status);
-    h2_sync<NW>();  // the table is rewritten by the next unit
+#ifndef H2_NO_PHASEB
+    h2_stream<CAPD, CAP, NW, ECAP, PARTS, 1>(g, es, u, ru, part, nparts, t, sc, rec, status);
+#endif
+    h2_sync<NW>();  // the tables are rewritten by the next unit
 }
 
 // ---- kernels -----------------------------------------------------------------------------------------------------------
 // wave class: a wave owns a unit and its private table; units are taken grid-stride (heaviest first in the list)
-template <int CAP, int ECAP>
-__global__ void __launch_bounds__(64 * H2_WPB0) k_h2_wave(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+template <int CAPD, int CAP, int ECAP>
+__global__ void __launch_bounds__(64 * H2_WPB0) k_h2_wave(View g, H2EdgeSet es, const int2 *units, const int32_t *count, int64_t unit_cap,
                                                           uint4 *rec, int32_t *status) {
+    __shared__ __attribute__((aligned(16))) unsigned front_all[H2_WPB0][CAPD];
     __shared__ __attribute__((aligned(16))) unsigned key_all[H2_WPB0][CAP];
     __shared__ __attribute__((aligned(16))) unsigned cnt_all[H2_WPB0][CAP / 2];
     __shared__ H2Scratch<ECAP> sc_all[H2_WPB0];
@@ -470,14 +572,16 @@ __global__ void __launch_bounds__(64 * H2_WPB0) k_h2_wave(View g, const int2 *un
         }
         const int2 ru = g.rowinfo[u];
         if (!row_ok(g, ru, 36, u, (int)it) || ru.y <= 0 || ru.y > H2_MAXDEG) continue;
-        h2_node<CAP, 1, ECAP, false>(g, u, ru, 0, 1, key_all[wid], cnt_all[wid], &sc_all[wid], rec, status);
+        h2_node<CAPD, CAP, 1, ECAP, false>(g, es, u, ru, 0, 1, H2Tab{front_all[wid], key_all[wid], cnt_all[wid]}, &sc_all[wid],
+                                           rec, status);
     }
 }
 
 // block classes: a workgroup of W waves shares one table per unit
-template <int CAP, int W, int ECAP, bool PARTS>
-__global__ void __launch_bounds__(64 * W) k_h2_block(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+template <int CAPD, int CAP, int W, int ECAP, bool PARTS>
+__global__ void __launch_bounds__(64 * W) k_h2_block(View g, H2EdgeSet es, const int2 *units, const int32_t *count, int64_t unit_cap,
                                                       uint4 *rec, int32_t *status) {
+    __shared__ __attribute__((aligned(16))) unsigned front[CAPD];
     __shared__ __attribute__((aligned(16))) unsigned key[CAP];
     __shared__ __attribute__((aligned(16))) unsigned cnt[CAP / 2];
     __shared__ H2Scratch<ECAP> sc_all[W];
@@ -498,7 +602,7 @@ __global__ void __launch_bounds__(64 * W) k_h2_block(View g, const int2 *units, 
             ok = row_ok(g, ru, 38, u, (int)it) && ru.y > 0 && ru.y <= H2_MAXDEG;
         }
         if (!ok) continue;
-        h2_node<CAP, W, ECAP, PARTS>(g, u, ru, part, nparts, key, cnt, &sc_all[wid], rec, status);
+        h2_node<CAPD, CAP, W, ECAP, PARTS>(g, es, u, ru, part, nparts, H2Tab{front, key, cnt}, &sc_all[wid], rec, status);
     }
 }
 
@@ -640,6 +744,9 @@ __global__ void k_h2_clear(DevResult *res) {
 __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= g.cap_total) return;
+#ifdef H2_NO_PHASEB  // timing-only build: there are no records to join
+    return;
+#endif
     const int u = g.slot_row[s];
     if (u < 0 || u >= g.n) return;
     const int2 ru = g.rowinfo[u];
@@ -668,12 +775,21 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental) {
-    return curv_type == DCR_CURV_BFC && !incremental && g->max_deg_bound <= H2_MAXDEG && g->cap_total < (int64_t)1 << 31;
+    return g->pass_impl == 3 && curv_type == DCR_CURV_BFC && !incremental && g->max_deg_bound <= H2_MAXDEG && g->cap_total < (int64_t)1 << 31;
 }
 
 static int ensure_h2(dcr_graph *g) {
     DCR_TRY(dev_regrow(&g->h2_weight, &g->h2_weight_cap, g->n + 64));
     DCR_TRY(dev_regrow(&g->h2_rec, &g->h2_rec_cap, g->cap_total + 64));
+    // edge set: at most cap_total / 2 undirected edges, load <= 1/4
+    int bits = 10;
+    while ((1ll << bits) < 2 * g->cap_total) ++bits;
+    if (g->h2_eset_bits != bits || !g->h2_eset) {
+        if (g->h2_eset) (void)hipFree(g->h2_eset);
+        g->h2_eset = nullptr;
+        DCR_TRY(dev_alloc(&g->h2_eset, (int64_t)1 << bits));
+        g->h2_eset_bits = bits;
+    }
     const int64_t need[H2_CLASSES] = {g->n + 64, g->n + 64, g->n + g->cap_total / 4 + 64};
     for (int c = 0; c < H2_CLASSES; ++c) DCR_TRY(dev_regrow(&g->h2_units[c], &g->h2_units_cap[c], need[c]));
     return DCR_OK;
@@ -717,6 +833,9 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         hipLaunchKernelGGL(k_h2_plan<1>, dim3((unsigned)pblocks), dim3(H2_PLAN_THREADS), 0, g->stream, vw, g->h2_weight, L,
                            g->dres);
     }
+    const H2EdgeSet es{g->h2_eset, g->h2_eset_bits};
+    DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, g->stream));
+    if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, es, status);
     // records of split nodes are accumulated with atomics: start from zero
     DCR_HIP(hipMemsetAsync(g->h2_rec, 0, sizeof(uint4) * (size_t)(g->cap_total > 0 ? g->cap_total : 1), g->stream));
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
@@ -728,14 +847,14 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         s2 = g->side[1];
     }
     // heaviest class first on the main stream; the classes are independent
-    hipLaunchKernelGGL((k_h2_block<h2_cap(2), h2_waves(2), h2_ecap(2), true>), dim3(h2_grid(g, 2, 1)),
-                       dim3(64 * h2_waves(2)), 0, g->stream, vw, g->h2_units[2], &g->dres->h2_count[2], g->h2_units_cap[2],
+    hipLaunchKernelGGL((k_h2_block<h2_capd(2), h2_cap(2), h2_waves(2), h2_ecap(2), true>), dim3(h2_grid(g, 2, 1)),
+                       dim3(64 * h2_waves(2)), 0, g->stream, vw, es, g->h2_units[2], &g->dres->h2_count[2], g->h2_units_cap[2],
                        g->h2_rec, status);
-    hipLaunchKernelGGL((k_h2_block<h2_cap(1), h2_waves(1), h2_ecap(1), false>), dim3(h2_grid(g, 1, 1)),
-                       dim3(64 * h2_waves(1)), 0, s1, vw, g->h2_units[1], &g->dres->h2_count[1], g->h2_units_cap[1],
+    hipLaunchKernelGGL((k_h2_block<h2_capd(1), h2_cap(1), h2_waves(1), h2_ecap(1), false>), dim3(h2_grid(g, 1, 1)),
+                       dim3(64 * h2_waves(1)), 0, s1, vw, es, g->h2_units[1], &g->dres->h2_count[1], g->h2_units_cap[1],
                        g->h2_rec, status);
-    hipLaunchKernelGGL((k_h2_wave<h2_cap(0), h2_ecap(0)>), dim3(h2_grid(g, 0, H2_WPB0)),
-                       dim3(64 * H2_WPB0), 0, s2, vw, g->h2_units[0], &g->dres->h2_count[0], g->h2_units_cap[0], g->h2_rec,
+    hipLaunchKernelGGL((k_h2_wave<h2_capd(0), h2_cap(0), h2_ecap(0)>), dim3(h2_grid(g, 0, H2_WPB0)),
+                       dim3(64 * H2_WPB0), 0, s2, vw, es, g->h2_units[0], &g->dres->h2_count[0], g->h2_units_cap[0], g->h2_rec,
                        status);
     if (!serial) {
         for (int b = 0; b < 2; ++b) {

@@ -374,7 +374,7 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     for (int64_t u = 0; u < n; ++u)
         if (deg[(size_t)u] > g->max_deg_bound) g->max_deg_bound = deg[(size_t)u];
     if (const char *impl = getenv("DCR_PASS"))
-        g->pass_impl = (std::string(impl) == "edge") ? 1 : (std::string(impl) == "nc") ? 2 : 0;
+        g->pass_impl = (std::string(impl) == "edge") ? 1 : (std::string(impl) == "h2") ? 3 : 0;
     *out = g;  // caller destroys on failure
     DCR_HIP(hipStreamCreate(&g->stream));
     DCR_HIP(hipEventCreate(&g->ev0));
@@ -422,7 +422,7 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->imp_stats, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
                         g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
                         g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
-                        g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_rec};
+                        g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_rec, g->h2_eset};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)

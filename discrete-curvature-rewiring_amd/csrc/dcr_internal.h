@@ -131,8 +131,8 @@ struct dcr_graph {
     uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
     int64_t nc_touch_cap = 0;
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
-    int pass_impl = 0;            // 0: two-hop pass for full BFC passes, node-centric otherwise (default); 1: edge-centric
-                                  // kernels only (DCR_PASS=edge); 2: node-centric, never the two-hop pass (DCR_PASS=nc)
+    int pass_impl = 0;            // 0: node-centric (default); 1: edge-centric kernels only (DCR_PASS=edge); 3: two-hop
+                                  // kernels for full Balanced Forman passes, node-centric otherwise (DCR_PASS=h2)
     int last_engine = -1;         // which implementation ran the last pass: 0 two-hop, 1 edge-centric, 2 node-centric
 
     // two-hop pass (dcr_bfc_h2.hip)
@@ -142,6 +142,8 @@ struct dcr_graph {
     uint4 *h2_rec = nullptr;          // [cap_total] per directed slot {|sq| on the far side, max count, triangles, reverse slot}
     int64_t h2_rec_cap = 0;
     int64_t h2_weight_cap = 0;
+    unsigned long long *h2_eset = nullptr;  // every undirected edge as one 64-bit key (open addressing), rebuilt per pass
+    int h2_eset_bits = 0;
     int32_t h2_last_count[3] = {-1, -1, -1};  // units per class of the previous pass (sizes the next grids)
 
     // edges beyond every LDS table (dcr_bfc_giant.hip): records {slot, u, v, deg u, deg v}; position map over all ids

@@ -123,9 +123,9 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
 int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int32_t out_added[2],
                      int32_t out_removed[2], double *out_max_val);
 
-/* Which implementation ran the last curvature pass: 0 two-hop kernels (csrc/dcr_bfc_h2.hip, full Balanced Forman passes),
- * 1 edge-centric kernels, 2 node-centric kernels (incremental passes, classical curvatures, degrees beyond the two-hop
- * tables); -1 before the first pass.  All three produce the same bits; DCR_PASS=nc|edge in the environment pins one. */
+/* Which implementation ran the last curvature pass: 2 node-centric kernels (csrc/dcr_bfc_nc.hip, the default), 1 edge-centric
+ * kernels (DCR_PASS=edge when the graph is created), 0 two-hop kernels (csrc/dcr_bfc_h2.hip, DCR_PASS=h2, full Balanced
+ * Forman passes only); -1 before the first pass.  All three produce the same bits. */
 int dcr_pass_engine(dcr_graph *g, int *out);
 
 /* Timing hooks for bench.py: accumulated device time (HIP events on the

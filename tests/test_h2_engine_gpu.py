@@ -1,0 +1,104 @@
+"""The alternative curvature-pass engine (csrc/dcr_bfc_h2.hip, selected with DCR_PASS=h2 when the graph is created):
+row u of A.A as an LDS hash map instead of per-edge neighbourhood streaming.  Same bits as the default engine, the CPU
+oracle and the reference's fixtures (curvature/bfc_naive.py:7-40)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def h2graph(monkeypatch):
+    monkeypatch.setenv('DCR_PASS', 'h2')
+    from dcr.graph import DcrGraph
+
+    def make(ei, n):
+        G = DcrGraph(ei, n)
+        return G
+    return make
+
+
+def _check_against_oracle(G, ei, n, nthreads=8):
+    from oracle import c_oracle
+    eu, ev, cv = G.curvature_all('bfc')
+    assert G.pass_engine() == 'two-hop'
+    C = c_oracle.CGraph(ei, n)
+    ou, ov, oc = C.curv_all('bfc', nthreads=nthreads)
+    assert np.array_equal(eu, ou) and np.array_equal(ev, ov)
+    bad = np.flatnonzero(cv != oc)
+    assert bad.size == 0, (bad[:5], eu[bad[:5]], ev[bad[:5]], cv[bad[:5]], oc[bad[:5]])
+
+
+def test_reference_fixtures(h2graph):
+    for fname in ('fullpass_small.json', 'fullpass_sampled.json'):
+        for name, rec in load_golden(fname)['graphs'].items():
+            G = h2graph(np.array(rec['edge_index']), rec['num_nodes'])
+            eu, ev, cv = G.curvature_all('bfc')
+            assert G.pass_engine() == 'two-hop'
+            got = {(u, v): c for u, v, c in zip(eu.tolist(), ev.tolist(), cv.tolist())}
+            for (u, v), h in zip(rec['edges'], rec['bfc']):
+                assert got[(u, v)] == float.fromhex(h), (name, u, v)
+
+
+@pytest.mark.parametrize('n,m,seed', [(3000, 4, 1), (1500, 12, 2), (400, 40, 3), (20000, 10, 4)])
+def test_power_law_graphs(h2graph, n, m, seed):
+    from dcr import synthetic
+    ei, n = synthetic.powerlaw_graph(n, m, seed=seed)
+    _check_against_oracle(h2graph(ei, n), ei, n)
+
+
+@pytest.mark.parametrize('n,p,seed', [(300, 0.5, 0), (600, 0.15, 1), (1200, 0.05, 2)])
+def test_dense_random_graphs_many_triangles(h2graph, n, p, seed):
+    """Nearly every 2-hop key repeats and every edge has triangle partners: overflow table, queue and step C all busy."""
+    from dcr import synthetic
+    ei, n = synthetic.erdos_renyi_graph(n, p, seed=seed)
+    _check_against_oracle(h2graph(ei, n), ei, n)
+
+
+def test_hubs_split_into_key_partitions(h2graph):
+    """Hubs whose 2-hop neighbourhoods exceed the largest table: their keys are split over several units."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = 30000
+    src, dst = [], []
+    hubs = [0, 1, 2]
+    for h in hubs:                       # three adjacent hubs with ~4,000 neighbours each, overlapping
+        nb = rng.choice(np.arange(3, n), size=4000, replace=False)
+        src += [h] * len(nb)
+        dst += nb.tolist()
+    src += [0, 0, 1]
+    dst += [1, 2, 2]
+    a = rng.integers(3, n, size=60000)   # background edges: the hubs' neighbours have neighbours of their own
+    b = rng.integers(3, n, size=60000)
+    src += a.tolist()
+    dst += b.tolist()
+    from dcr import synthetic
+    ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
+    _check_against_oracle(h2graph(ei, n), ei, n, nthreads=16)
+
+
+def test_engines_agree_on_the_bench_graph_and_after_edits(h2graph, monkeypatch):
+    from dcr import synthetic
+    from dcr.graph import DcrGraph
+    ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    H = h2graph(ei, n)
+    monkeypatch.delenv('DCR_PASS')
+    D = DcrGraph(ei, n)
+    rng = np.random.Generator(np.random.PCG64(3))
+    for rnd in range(3):
+        hu, hv, hc = H.curvature_all('bfc')
+        du, dv, dc = D.curvature_all('bfc')
+        assert H.pass_engine() == 'two-hop' and D.pass_engine() == 'node-centric'
+        assert np.array_equal(hu, du) and np.array_equal(hv, dv) and np.array_equal(hc, dc), rnd
+        for _ in range(20):              # edits at hubs and elsewhere, the same on both
+            a, b = int(rng.integers(0, 200)), int(rng.integers(0, n))
+            if a != b and not D.has_edge(a, b):
+                H.add_edge(a, b)
+                D.add_edge(a, b)
+        eu, ev = D.edges()
+        for j in rng.integers(0, len(eu), size=20):
+            a, b = int(eu[j]), int(ev[j])
+            if D.has_edge(a, b):
+                H.remove_edge(a, b)
+                D.remove_edge(a, b)
