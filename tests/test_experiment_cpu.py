@@ -126,3 +126,13 @@ def test_npz_and_synthetic_sources(tmp_path):
     assert base.data.num_nodes == 6 and base.data.edge_attr.shape[0] == 6 and base.num_classes == 3
     syn = DataLoader('synthetic:300:3:8:4', use_lcc=True, undirected=True)
     assert syn.data.x.shape == (300, 8) and syn.num_classes == 4
+
+
+def test_training_loop_reproduces_the_reference_run():
+    """the per-epoch (loss, val_acc) sequence, the stopping epoch and the returned weights of the
+    reference's own training_loop (experiment/training_loop.py:22-37), recorded in the build container."""
+    import training_loop_fixture as fx
+    torch.set_num_threads(1)
+    for case in fx.cases():
+        model, data, losses, accs = fx.run_recorded(case)
+        fx.check(case, model, data, losses, accs)

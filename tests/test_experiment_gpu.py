@@ -131,3 +131,18 @@ def test_graphed_epochs_equal_eager_epochs():
     m4 = GCN(Dataset(data, 5), hidden=[32], dropout=0.0).to(dev)
     o4 = torch.optim.Adam(m4.parameters(), lr=0.01)
     assert not isinstance(make_epoch(m4, o4, data), GraphedEpoch)
+
+
+@pytest.mark.parametrize('graphed', [False, True])
+def test_training_loop_reproduces_the_reference_run_on_the_gpu(graphed, monkeypatch):
+    """The same fixture (reference experiment/training_loop.py:22-37) through the eager epoch and through the two
+    captured HIP graphs per epoch (GraphedEpoch); float64 model, so only the BLAS summation order differs from the CPU
+    run that recorded it."""
+    import training_loop_fixture as fx
+    import experiment.training_loop as tl
+    monkeypatch.setenv('DCR_HIP_GRAPH', '1' if graphed else '0')
+    for case in fx.cases():
+        model, data, losses, accs = fx.run_recorded(case, device='cuda:0', capturable=graphed)
+        fx.check(case, model, data, losses, accs, tol=1e-7)
+        assert (not losses) == graphed  # the graphed epoch does not go through train() at all
+        assert tl.GraphedEpoch.supported(model, torch.optim.Adam(model.parameters(), capturable=True), data) == graphed

@@ -98,7 +98,89 @@ def lcc_cases():
     return cases
 
 
+def tiny_model(n_feat, hidden, n_cls):
+    """The plain-torch model the training-loop fixture is recorded on (float64: rounding differences between machines
+    stay far below the gaps that decide an arg-max)."""
+    return torch.nn.Sequential(torch.nn.Linear(n_feat, hidden), torch.nn.ReLU(), torch.nn.Linear(hidden, n_cls),
+                               torch.nn.LogSoftmax(dim=1)).double()
+
+
+class _OnX(torch.nn.Module):
+    """model(data) -> log-probabilities, as experiment/training_loop.py calls it."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, data):
+        return self.net(data.x)
+
+
+def training_loop_cases():
+    """Drive the reference's own experiment/training_loop.py (imported unmodified; its only PyG use is the ``Data`` type
+    annotation, served by the stand-in above) and record what it does: per epoch the training loss and the validation
+    accuracy (harness-side wrappers around its ``train`` / ``evaluate``), the epoch whose weights it returns, how many
+    epochs it ran and the returned weights."""
+    import experiment.training_loop as ref_tl  # (reference)
+    assert ref_tl.__file__.startswith(REF)
+    torch.set_num_threads(1)
+    cases = []
+    for case_id, (n, n_feat, hidden, n_cls, lr, wd, epochs, patience, seed) in enumerate((
+            (160, 8, 6, 3, 0.05, 5e-4, 120, 6, 0),      # stops early
+            (160, 8, 6, 3, 0.01, 0.0, 25, 100, 1),       # runs out of epochs
+            (90, 5, 4, 2, 0.2, 1e-3, 200, 3, 2))):       # two classes, coarse accuracies: many ties (>= moves the checkpoint)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, n_feat, generator=g, dtype=torch.float64)
+        w_true = torch.randn(n_feat, n_cls, generator=g, dtype=torch.float64)
+        y = (x @ w_true + 1.5 * torch.randn(n, n_cls, generator=g, dtype=torch.float64)).argmax(1)
+        r = torch.rand(n, generator=g)
+        train_mask, val_mask, test_mask = r < 0.3, (r >= 0.3) & (r < 0.6), r >= 0.6
+        torch.manual_seed(seed)
+        model = _OnX(tiny_model(n_feat, hidden, n_cls))
+        init = {k: v.clone() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+        data = Data(x=x, y=y, train_mask=train_mask, val_mask=val_mask, test_mask=test_mask, num_nodes=n)
+        losses, accs = [], []
+        orig_train, orig_eval = ref_tl.train, ref_tl.evaluate
+
+        def rec_train(m, o, d):
+            v = orig_train(m, o, d)
+            losses.append(v)
+            return v
+
+        def rec_eval(m, d, test):
+            v = orig_eval(m, d, test)
+            accs.append(v['val_acc'])
+            return v
+        ref_tl.train, ref_tl.evaluate = rec_train, rec_eval
+        try:
+            out = ref_tl.training_loop(model, opt, data, epochs, patience)
+        finally:
+            ref_tl.train, ref_tl.evaluate = orig_train, orig_eval
+        assert out is model
+        best = max(range(len(accs)), key=lambda e: (accs[e], e))  # the last epoch holding the maximum (>= rule)
+        final_eval = orig_eval(model, data, True)
+        cases.append({
+            'n': n, 'n_feat': n_feat, 'hidden': hidden, 'n_cls': n_cls, 'lr': lr, 'weight_decay': wd, 'epochs': epochs,
+            'patience': patience, 'seed': seed,
+            'x': x.tolist(), 'y': y.tolist(), 'train': idx(train_mask), 'val': idx(val_mask), 'test': idx(test_mask),
+            'init': {k: v.tolist() for k, v in init.items()},
+            'losses': [float(v).hex() for v in losses], 'val_accs': accs, 'epochs_run': len(losses), 'best_epoch': best,
+            'final': {k: v.tolist() for k, v in model.state_dict().items()},
+            'final_val_acc': final_eval['val_acc'], 'final_test_acc': final_eval['test_acc']})
+        print(f'training_loop case {case_id}: ran {len(losses)} of {epochs} epochs, best epoch {best}, '
+              f'val {final_eval["val_acc"]:.4f} test {final_eval["test_acc"]:.4f}, distinct accs {len(set(accs))}')
+    return cases
+
+
 def main():
+    tl = {'_about': 'what the reference experiment/training_loop.py does on a plain-torch float64 model '
+                    '(tools/make_golden_experiment.py::training_loop_cases): inputs, initial weights, per-epoch training loss '
+                    '(float64 hex) and validation accuracy, epochs run, epoch of the returned weights, returned weights',
+          'torch': torch.__version__, 'cases': training_loop_cases()}
+    with open(os.path.join(GOLDEN, 'training_loop_reference.json'), 'w') as f:
+        json.dump(tl, f, separators=(',', ':'))
+    print('wrote training_loop_reference.json', os.path.getsize(os.path.join(GOLDEN, 'training_loop_reference.json')), 'bytes')
     out = {'_about': 'outputs of the reference experiment/data_splits.py and experiment/data_loader.py helpers '
                      '(tools/make_golden_experiment.py)',
            'development_seed': int(ref_seeds.development_seed),
