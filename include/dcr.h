@@ -139,6 +139,22 @@ int dcr_bfc_algorithmic_bytes(dcr_graph *g, double *out_bytes);
  * graph, so a pass has to read one side only; this is the byte count bench.py's roofline fraction is quoted on. */
 int dcr_bfc_algorithmic_bytes_one_sided(dcr_graph *g, double *out_bytes);
 
+/* ---- dense float32 Balanced Forman curvature: the numerics of the reference's numba path (device pointers, caller's
+ * stream).  curvature/bfc_cuda.py computes a different number from curvature/bfc_naive.py (float32 dense formula, other
+ * 4-cycle term, no degree-1 rule) and it is what rewire('bfc') runs in the reference (rewiring/rewire.py:8-10), so results
+ * obtained with the reference can only be reproduced with these.  A, A2 = A·A, C: row-major N x N float32; d_in / d_out:
+ * column / row sums of A; pairs: the (i, j) of the non-zero entries of A as int64 [nnz][2] (C must be zero elsewhere:
+ * the caller clears it).  Float64 closing expression rounded to float32 twice, as numba types the kernel.
+ *   dcr_bfc_dense_f32_dev              replaces _balanced_forman_curvature   (curvature/bfc_cuda.py:11-48, launch :64)
+ *   dcr_bfc_dense_post_delta_f32_dev   replaces _balanced_forman_post_delta  (curvature/bfc_cuda.py:68-141, launch :157):
+ *       D[I][J] = curvature of (x, y) once (i_neighbors[I], j_neighbors[J]) is added; -1000 where the two are equal or
+ *       already adjacent (:77-79); d_in_x = A[:, x].sum(), d_out_y = A[y].sum() (:147-148). */
+int dcr_bfc_dense_f32_dev(const float *A_dev, const float *A2_dev, const float *d_in_dev, const float *d_out_dev, int64_t N,
+                          const int64_t *pairs_dev, int64_t nnz, float *C_dev, void *hip_stream);
+int dcr_bfc_dense_post_delta_f32_dev(const float *A_dev, const float *A2_dev, float d_in_x, float d_out_y, int64_t N,
+                                     float *D_dev, int32_t x, int32_t y, const int32_t *i_neighbors_dev,
+                                     const int32_t *j_neighbors_dev, int64_t dim_i, int64_t dim_j, void *hip_stream);
+
 /* ---- host helper for np.random.choice(n, p=softmax(a, tau)) — sdrf_no_cuda.py:49-50, utils/softmax.py:9-10
  * Given e = exp(a * tau) and its sum S (both computed by the caller's numpy: their rounding is part of the bit-exact
  * contract), fill cdf[i] = the SEQUENTIAL float64 running sum of p_i = e_i / S, i.e. numpy.cumsum(e / S), in one fused

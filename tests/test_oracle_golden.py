@@ -153,3 +153,58 @@ def test_north_star_graph_values_of_the_reference():
     ev = np.array([r[1] for r in ref['values']], dtype=np.int32)
     want = np.array([fh(r[2]) for r in ref['values']])
     assert np.array_equal(C.curv_edges(eu, ev, 'bfc', nthreads=4), want)
+
+
+# ---- the reference's dense float32 path (curvature/bfc_cuda.py, rewiring/sdrf_cuda_bfc.py) -----------------------------
+def _dense(case):
+    ei = np.array(case['edge_index'], dtype=np.int64)
+    n = case['num_nodes']
+    A = np.zeros((n, n), dtype=np.float32)
+    A[ei[0], ei[1]] = 1.0
+    if case['symmetric']:
+        A[ei[1], ei[0]] = 1.0
+    return A
+
+
+def _f32hex(a):
+    return [float(v).hex() for v in np.asarray(a, dtype=np.float32).ravel().tolist()]
+
+
+def test_bfc_cuda_oracle_matches_reference_kernels():
+    from oracle import bfc_cuda_oracle as bo
+    for case in load_golden('bfc_cuda_curvature.json')['cases']:
+        A = _dense(case)
+        assert _f32hex(bo.balanced_forman_curvature(A)) == case['C'], case['graph']
+        for pd in case['post_delta']:
+            D = bo.balanced_forman_post_delta(A, pd['x'], pd['y'], pd['i_neighbors'], pd['j_neighbors'])
+            assert _f32hex(D) == pd['D'], (case['graph'], pd['x'], pd['y'])
+
+
+def check_bfc_cuda_sdrf_case(case, run):
+    """``run(edge_index, num_nodes, loops, remove_edges, removal_bound, tau, is_undirected, trace)`` -> edge_index;
+    shared with the GPU test of the product's compatibility mode."""
+    tau = float('inf') if case['tau'] == 'inf' else case['tau']
+    trace = []
+    np.random.seed(case['seed'])
+    final = run(np.array(case['edge_index'], dtype=np.int64), case['num_nodes'], case['loops'], case['remove_edges'],
+                case['removal_bound'], tau, case['is_undirected'], trace)
+    label = (case['graph'], case['is_undirected'], case['seed'])
+    assert len(trace) == len(case['iterations']), label
+    for it, (a, b) in enumerate(zip(trace, case['iterations'])):
+        N = b['N']
+        assert a['argmin'] == [b['C_argmin'] // N, b['C_argmin'] % N], (label, it)
+        if b['argmin'] is not None:
+            assert a['argmin'] == b['argmin'] and a['x_neighbors'] == b['x_neighbors'] and a['y_neighbors'] == b['y_neighbors'], (label, it)
+        assert (a['n_candidates'] or None) == b.get('n_candidates'), (label, it)
+        if b['improvements'] is not None:
+            assert [float(v).hex() for v in a['improvements']] == b['improvements'], (label, it)
+        assert a['choice'] == b['choice'], (label, it)
+        assert [list(e) for e in a['events']] == [list(e) for e in b['events']], (label, it)
+    assert np.asarray(final).tolist() == case['final_edge_index'], label
+
+
+def test_bfc_cuda_oracle_matches_reference_sdrf_runs():
+    from oracle import bfc_cuda_oracle as bo
+    for case in load_golden('bfc_cuda_sdrf.json')['cases']:
+        assert case['error'] is None
+        check_bfc_cuda_sdrf_case(case, bo.sdrf_cuda_bfc)

@@ -1,0 +1,389 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/bfc_cuda_*.json by RUNNING THE REFERENCE's curvature/bfc_cuda.py and rewiring/sdrf_cuda_bfc.py
+(build container only: no GPU, no numba, no PyG here).
+
+Both files are imported unmodified.  Harness-side glue only:
+
+  1. a stand-in ``numba`` module whose ``cuda.jit(signature)`` returns a launcher: ``kernel[grid, block](*args)`` calls
+     the undecorated Python function once per (block, thread) with ``cuda.grid(2)`` returning that thread's indices.
+     Arguments are converted the way numba's typing would see them for the declared signature: ``float32[:,:]`` /
+     ``float32[:]`` arrays become views whose element READS return Python floats and whose element WRITES round to
+     float32; ``float32`` scalars become Python floats; ``int32`` scalars / arrays stay integers.  That reproduces the
+     arithmetic numba compiles for these kernels: int64 and float32 operands unify to float64 (``2 / d_max``,
+     ``lambda_ij = 0`` later assigned a float32, ``d_in_x += 1``), so every expression is evaluated in float64 on
+     float32-valued inputs and rounded to float32 only where it is stored into ``C`` / ``D`` (twice: the base expression,
+     then ``+=`` of the 4-cycle term).  Not reproduced: NVVM may contract ``a * b + c`` into one FMA, which can change a
+     float32 result only when the float64 intermediate lies within 2^-29 of a float32 rounding boundary.
+  2. ``torch.Tensor.cuda`` patched to the identity (tensors stay on the CPU; the kernels see numpy views of them);
+  3. a stand-in ``torch_geometric`` with PyG-2.0.3 semantics of ``to_undirected`` (symmetrise + coalesce, sorted),
+     ``remove_self_loops``, ``to_dense_adj``, ``to_networkx`` (DiGraph, edges in edge_index order) and ``from_networkx``.
+
+Only numbers are written: inputs (edge lists, parameters, seeds) and outputs (C, D as float32 hex, traces, edge lists).
+
+Usage:  python tools/make_golden_cuda_compat.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, os.path.join(REPO, 'discrete-curvature-rewiring_amd'))
+
+import networkx as nx  # noqa: E402
+import torch  # noqa: E402
+
+from dcr.data import Data  # noqa: E402
+from dcr import synthetic  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. numba.cuda stand-in
+# ---------------------------------------------------------------------------------------------------------------------
+class F32View:
+    """float32 array as numba code sees it next to int64 literals: reads take part in float64 arithmetic, writes round
+    to float32."""
+
+    def __init__(self, arr):
+        self.a = arr  # numpy float32, shared with the torch tensor
+
+    def __getitem__(self, ix):
+        return float(self.a[ix])
+
+    def __setitem__(self, ix, v):
+        self.a[ix] = np.float32(v)
+
+
+class _Launcher:
+    def __init__(self, fn, sig):
+        self.fn = fn
+        args = sig[sig.index('(') + 1:sig.rindex(')')]
+        self.types = [t.strip() for t in _split_top(args)]
+
+    def __getitem__(self, cfg):
+        grid, block = cfg
+
+        def launch(*args):
+            conv = []
+            for a, t in zip(args, self.types):
+                if t.startswith('float32['):
+                    arr = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+                    assert arr.dtype == np.float32
+                    conv.append(F32View(arr))
+                elif t == 'float32':
+                    conv.append(float(np.float32(float(a))))
+                elif t.startswith('int32['):
+                    conv.append(np.asarray(a).astype(np.int64))
+                elif t == 'int32':
+                    conv.append(int(a))
+                else:
+                    raise TypeError(t)
+            nx_, ny_ = grid[0] * block[0], grid[1] * block[1]
+            for i in range(nx_):
+                for j in range(ny_):
+                    _cuda.thread = (i, j)
+                    self.fn(*conv)
+        return launch
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ''
+    for ch in s:
+        if ch == '[':
+            depth += 1
+        if ch == ']':
+            depth -= 1
+        if ch == ',' and depth == 0:
+            out.append(cur)
+            cur = ''
+        else:
+            cur += ch
+    out.append(cur)
+    return out
+
+
+_cuda = types.SimpleNamespace(thread=(0, 0))
+_cuda.grid = lambda nd: _cuda.thread
+_cuda.jit = lambda sig: (lambda fn: _Launcher(fn, sig))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. torch_geometric stand-in (PyG 2.0.3 semantics, restated)
+# ---------------------------------------------------------------------------------------------------------------------
+def _to_undirected(edge_index):
+    row, col = edge_index
+    row, col = torch.cat([row, col]), torch.cat([col, row])
+    n = int(max(row.max(), col.max())) + 1 if row.numel() else 0
+    key = torch.unique(row * n + col)  # coalesce: sorted by (row, col), duplicates merged
+    return torch.stack([key // n, key % n])
+
+
+def _remove_self_loops(edge_index, edge_attr=None):
+    mask = edge_index[0] != edge_index[1]
+    return edge_index[:, mask], edge_attr
+
+
+def _to_dense_adj(edge_index, batch=None, edge_attr=None, max_num_nodes=None):
+    n = int(edge_index.max()) + 1 if edge_index.numel() else 0
+    adj = torch.zeros(1, n, n)
+    # scatter-add of ones: duplicates would add up; the callers pass coalesced or simple edge lists
+    adj[0].index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.shape[1]), accumulate=True)
+    return adj
+
+
+EVENTS = None  # while a run is traced: list receiving ('add' | 'rm', u, v)
+
+
+class TracingGraph(nx.Graph):
+    def add_edge(self, u, v, **attr):
+        if EVENTS is not None and getattr(self, 'live', False):
+            EVENTS.append(('add', int(u), int(v)))
+        return super().add_edge(u, v, **attr)
+
+    def remove_edge(self, u, v):
+        if EVENTS is not None:
+            EVENTS.append(('rm', int(u), int(v)))
+        return super().remove_edge(u, v)
+
+
+class TracingDiGraph(nx.DiGraph):
+    def add_edge(self, u, v, **attr):
+        if EVENTS is not None and getattr(self, 'live', False):
+            EVENTS.append(('add', int(u), int(v)))
+        return super().add_edge(u, v, **attr)
+
+    def remove_edge(self, u, v):
+        if EVENTS is not None:
+            EVENTS.append(('rm', int(u), int(v)))
+        return super().remove_edge(u, v)
+
+    def to_undirected_class(self):
+        return TracingGraph
+
+
+def _to_networkx(data, node_attrs=None, edge_attrs=None, to_undirected=False, remove_self_loops=False):
+    G = TracingGraph() if to_undirected else TracingDiGraph()
+    G.add_nodes_from(range(data.num_nodes))
+    for (u, v) in data.edge_index.t().tolist():
+        if to_undirected and v > u:
+            continue
+        if remove_self_loops and u == v:
+            continue
+        G.add_edge(u, v)
+    return G
+
+
+def _from_networkx(G):
+    G = nx.convert_node_labels_to_integers(G)
+    G = G.to_directed() if not nx.is_directed(G) else G
+    ei = torch.tensor(list(G.edges), dtype=torch.long).t().contiguous().view(2, -1)
+    return Data(edge_index=ei, num_nodes=G.number_of_nodes())
+
+
+def install_shims():
+    nb = types.ModuleType('numba')
+    nb.cuda = _cuda
+    sys.modules['numba'] = nb
+    tg = types.ModuleType('torch_geometric')
+    tgu = types.ModuleType('torch_geometric.utils')
+    tgd = types.ModuleType('torch_geometric.data')
+    tgd.Data = Data
+    for name, fn in (('to_undirected', _to_undirected), ('remove_self_loops', _remove_self_loops),
+                     ('to_dense_adj', _to_dense_adj), ('to_networkx', _to_networkx), ('from_networkx', _from_networkx)):
+        setattr(tgu, name, fn)
+    tg.utils, tg.data = tgu, tgd
+    sys.modules.update({'torch_geometric': tg, 'torch_geometric.utils': tgu, 'torch_geometric.data': tgd})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    tq = types.ModuleType('tqdm')
+    tq.tqdm = lambda it, *a, **k: it
+    sys.modules['tqdm'] = tq
+    sys.path.insert(0, REF)
+
+
+install_shims()
+for m in [k for k in sys.modules if k.split('.')[0] in ('curvature', 'rewiring', 'utils')]:
+    del sys.modules[m]
+import curvature.bfc_cuda as ref_cuda  # noqa: E402  (reference)
+import rewiring.sdrf_cuda_bfc as ref_sdrf  # noqa: E402  (reference)
+
+assert ref_cuda.__file__.startswith(REF) and ref_sdrf.__file__.startswith(REF)
+
+
+def f32hex(t):
+    return [float(v).hex() for v in np.asarray(t, dtype=np.float32).ravel().tolist()]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# graphs
+# ---------------------------------------------------------------------------------------------------------------------
+def catalog():
+    cat = {}
+
+    def und(G):
+        G = nx.convert_node_labels_to_integers(G, ordering='sorted')
+        src = [u for u, v in G.edges()]
+        dst = [v for u, v in G.edges()]
+        return synthetic.coalesced_edge_index(src, dst, G.number_of_nodes()), G.number_of_nodes()
+    cat['C5'] = und(nx.cycle_graph(5))
+    cat['K4'] = und(nx.complete_graph(4))
+    cat['K33'] = und(nx.complete_bipartite_graph(3, 3))
+    cat['petersen'] = und(nx.petersen_graph())
+    cat['star6'] = und(nx.star_graph(6))
+    cat['grid4x4'] = und(nx.grid_2d_graph(4, 4))
+    cat['karate'] = und(nx.karate_club_graph())
+    cat['pa60'] = synthetic.powerlaw_graph(60, 3, seed=5)
+    cat['er40'] = synthetic.erdos_renyi_graph(40, 0.15, seed=3)
+    return cat
+
+
+def directed_catalog():
+    """Directed simple graphs (no self-loops, sorted edge lists): a random orientation + some reciprocal pairs."""
+    out = {}
+    for name, n, p, seed in (('d20', 20, 0.18, 1), ('d36', 36, 0.10, 2)):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        m = rng.random((n, n)) < p
+        np.fill_diagonal(m, False)
+        src, dst = np.nonzero(m)
+        out[name] = (np.stack([src, dst]).astype(np.int64), n)
+    return out
+
+
+def dense_from(ei, n, symmetric):
+    e = torch.from_numpy(ei)
+    if symmetric:
+        e = _to_undirected(e)
+    A = torch.zeros(n, n)
+    A[e[0], e[1]] = 1.0
+    return A
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------------------------------------------------
+def curvature_cases():
+    cases = []
+    for name, (ei, n) in list(catalog().items()) + list(directed_catalog().items()):
+        symmetric = name not in directed_catalog()
+        A = dense_from(ei, n, symmetric)
+        C = ref_cuda.balanced_forman_curvature(A.clone())
+        rec = {'graph': name, 'num_nodes': n, 'edge_index': ei.tolist(), 'symmetric': symmetric, 'C': f32hex(C), 'post_delta': []}
+        # post-delta matrices for a few (x, y) with the neighbour lists sdrf_cuda_bfc.py:44-49 builds
+        G = _to_networkx(Data(edge_index=torch.from_numpy(ei), num_nodes=n))
+        if symmetric:
+            G = G.to_undirected()
+        pairs = [(int(u), int(v)) for u, v in zip(*np.nonzero(A.numpy()))]
+        rng = np.random.Generator(np.random.PCG64(17))
+        for t in rng.choice(len(pairs), size=min(3, len(pairs)), replace=False):
+            x, y = pairs[int(t)]
+            if symmetric:
+                xn, yn = list(G.neighbors(x)) + [x], list(G.neighbors(y)) + [y]
+            else:
+                xn, yn = list(G.successors(x)) + [x], list(G.predecessors(y)) + [y]
+            D = ref_cuda.balanced_forman_post_delta(A.clone(), x, y, xn, yn)
+            rec['post_delta'].append({'x': x, 'y': y, 'i_neighbors': [int(t) for t in xn], 'j_neighbors': [int(t) for t in yn],
+                                      'D': f32hex(D)})
+        cases.append(rec)
+        print('curvature', name, n, 'nnz', int(A.sum()))
+    return cases
+
+
+class _Tracer:
+    """Records what sdrf_cuda_bfc does per iteration through wrappers around the names it calls (harness side)."""
+
+    def __init__(self):
+        self.iters = []
+        self.cur = None
+
+    def install(self):
+        t = self
+        orig_curv, orig_delta, orig_choice = ref_sdrf.balanced_forman_curvature, ref_sdrf.balanced_forman_post_delta, np.random.choice
+        orig_softmax = ref_sdrf.softmax
+
+        def softmax(a, tau=1):
+            t.cur['improvements'] = [float(v).hex() for v in a.tolist()]
+            return orig_softmax(a, tau=tau)
+
+        def curv(A, C=None):
+            out = orig_curv(A, C=C)
+            t.cur = {'argmin': None, 'x_neighbors': None, 'y_neighbors': None, 'candidates': None, 'improvements': None,
+                     'choice': None, 'N': int(A.shape[0]), 'C_argmin': int(out.argmin().item()), 'C_argmax': int(out.argmax().item()),
+                     'C_max': float(out.max().item()).hex(), 'C_min': float(out.min().item()).hex()}
+            t.iters.append(t.cur)
+            global EVENTS
+            EVENTS = t.cur['events'] = []
+            TracingGraph.live = TracingDiGraph.live = True   # (construction-time add_edge calls are not logged)
+            return out
+
+        def delta(A, x, y, i_nb, j_nb, D=None):
+            t.cur['argmin'] = [int(x), int(y)]
+            t.cur['x_neighbors'] = [int(v) for v in i_nb]
+            t.cur['y_neighbors'] = [int(v) for v in j_nb]
+            return orig_delta(A, x, y, i_nb, j_nb, D)
+
+        def choice(rng, p=None):
+            idx = orig_choice(rng, p=p)
+            t.cur['choice'] = int(idx)
+            t.cur['n_candidates'] = len(rng)
+            return idx
+        ref_sdrf.balanced_forman_curvature, ref_sdrf.balanced_forman_post_delta = curv, delta
+        ref_sdrf.np.random.choice = choice
+        ref_sdrf.softmax = softmax
+        self._undo = (orig_curv, orig_delta, orig_choice, orig_softmax)
+
+    def remove(self):
+        global EVENTS
+        EVENTS = None
+        (ref_sdrf.balanced_forman_curvature, ref_sdrf.balanced_forman_post_delta, ref_sdrf.np.random.choice,
+         ref_sdrf.softmax) = self._undo
+
+
+def sdrf_cases():
+    cases = []
+    und = catalog()
+    dirg = directed_catalog()
+    plan = [('karate', und['karate'], True, 12, 0.5, 50.0, 0), ('karate', und['karate'], True, 8, 0.3, float('inf'), 1),
+            ('pa60', und['pa60'], True, 10, 0.5, 20.0, 2), ('grid4x4', und['grid4x4'], True, 6, 0.2, 5.0, 3),
+            ('K33', und['K33'], True, 4, 0.5, 10.0, 4),            # every curvature positive: dense arg-min lands on a non-edge
+            ('d20', dirg['d20'], False, 10, 0.3, 30.0, 5), ('d36', dirg['d36'], False, 8, 0.5, float('inf'), 6),
+            ('pa60', und['pa60'], True, 6, 0.5, 20.0, 7, False)]   # remove_edges off
+    for spec in plan:
+        name, (ei, n), undirected, loops, bound, tau, seed = spec[:7]
+        remove_edges = spec[7] if len(spec) > 7 else True
+        data = Data(edge_index=torch.from_numpy(ei), num_nodes=n)
+        tr = _Tracer()
+        TracingGraph.live = TracingDiGraph.live = False
+        tr.install()
+        np.random.seed(seed)
+        err = None
+        try:
+            out = ref_sdrf.sdrf_cuda_bfc(data, loops, remove_edges, bound, tau, undirected)
+        except Exception as ex:  # noqa: BLE001 (the reference raising is part of what is recorded)
+            err, out = f'{type(ex).__name__}: {ex}', None
+        finally:
+            tr.remove()
+        cases.append({'graph': name, 'num_nodes': n, 'edge_index': ei.tolist(), 'is_undirected': undirected, 'loops': loops,
+                      'remove_edges': remove_edges, 'removal_bound': bound, 'tau': 'inf' if tau == float('inf') else tau,
+                      'seed': seed, 'error': err, 'iterations': tr.iters,
+                      'final_edge_index': None if out is None else out.edge_index.tolist()})
+        print('sdrf', name, 'undirected' if undirected else 'directed', 'iterations', len(tr.iters), 'error', err,
+              'edges out', None if out is None else out.edge_index.shape[1])
+    return cases
+
+
+def main():
+    about = ('outputs of the reference curvature/bfc_cuda.py and rewiring/sdrf_cuda_bfc.py executed on the CPU through a '
+             'harness-side numba.cuda stand-in (tools/make_golden_cuda_compat.py); float32 values as hex')
+    with open(os.path.join(GOLDEN, 'bfc_cuda_curvature.json'), 'w') as f:
+        json.dump({'_about': about, 'cases': curvature_cases()}, f, separators=(',', ':'))
+    with open(os.path.join(GOLDEN, 'bfc_cuda_sdrf.json'), 'w') as f:
+        json.dump({'_about': about, 'cases': sdrf_cases()}, f, separators=(',', ':'))
+    for n in ('bfc_cuda_curvature.json', 'bfc_cuda_sdrf.json'):
+        print('wrote', n, os.path.getsize(os.path.join(GOLDEN, n)), 'bytes')
+
+
+if __name__ == '__main__':
+    main()
