@@ -94,7 +94,7 @@ def gcn_bench(args, rank, world, local_rank, dist):
     data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=train_mask, val_mask=val_mask)
     model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
     opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                            {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=dist is None)
+                            {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True)
 
     def sync():
         if dist is not None:
@@ -109,9 +109,13 @@ def gcn_bench(args, rank, world, local_rank, dist):
         xl, yl, tl, vl = sh.shard(x), sh.shard(y), sh.shard(train_mask), sh.shard(val_mask)
         n_train = int(train_mask.sum())
 
-        def epoch():
-            sh.train_step(opt, xl, yl, tl, n_train)
-            sh.eval_correct(xl, yl, vl)
+        from models.gcn_dp import GraphedShardedEpoch
+        if GraphedShardedEpoch.supported(sh, opt, xl):  # RCCL: the epoch replays as two HIP graphs, collectives inside
+            epoch = GraphedShardedEpoch(sh, opt, xl, yl, tl, vl, n_train)
+        else:
+            def epoch():
+                sh.train_step(opt, xl, yl, tl, n_train)
+                sh.eval_correct(xl, yl, vl)
 
     for _ in range(max(args.gcn_warmup, 5)):  # (the graphed epoch captures at its fourth call)
         epoch()
@@ -127,7 +131,7 @@ def gcn_bench(args, rank, world, local_rank, dist):
         el = float(t.item())
     res = {'metric': 'GCN epochs/sec', 'value': args.gcn_epochs / el, 'unit': 'epochs/sec', 'n_gpus': world,
            'epochs': args.gcn_epochs, 'ms_per_epoch': el / args.gcn_epochs * 1e3, 'scaling': 'strong', 'dtype': 'f32',
-           'hip_graph': type(epoch).__name__ == 'GraphedEpoch',
+           'hip_graph': type(epoch).__name__ in ('GraphedEpoch', 'GraphedShardedEpoch'),
            'config': {'workload': f'synthetic preferential-attachment graph N={n} E={ei_np.shape[1] // 2}, F={F}, '
                                   f'hidden={H}, classes={C}, dropout 0.5, Adam; epoch = train step + val forward',
                       'parallelism': f'row-partitioned dp{world}' if world > 1 else 'single GPU'}}

@@ -72,7 +72,15 @@ class ShardedGCN(torch.nn.Module):
         self.csr = gcn_norm_csr(edge_index, None, self.n, add_self_loops=True, row_range=(self.r0, self.r1))
         for p in self.gcn.parameters():  # replicate rank 0's initialisation
             dist.broadcast(p.data, src=0, group=group)
-        self._flat = None
+        # One flat gradient buffer for the whole model, every parameter's .grad a view into it: backward accumulates in
+        # place and the per-step all-reduce is ONE call on memory that never moves (the message is tens of kilobytes:
+        # latency-bound; no torch.cat, no copy-back, and fixed addresses for a captured HIP graph).
+        params = list(self.gcn.parameters())
+        self._flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = self._flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
 
     def shard(self, t):
         return t[self.r0:self.r1]
@@ -106,17 +114,38 @@ class ShardedGCN(torch.nn.Module):
             self._ax_ref = x_local
         return self._ax
 
+    def _grads_are_views(self):
+        base = self._flat.data_ptr()
+        end = base + self._flat.numel() * self._flat.element_size()
+        return all(p.grad is not None and base <= p.grad.data_ptr() < end for p in self.gcn.parameters())
+
+    def zero_grads(self):
+        """Instead of ``optimizer.zero_grad()`` (whose default drops the .grad tensors, and with them the views)."""
+        if not self._grads_are_views():  # someone replaced a .grad (zero_grad(set_to_none=True), load of a checkpoint)
+            off = 0
+            for p in self.gcn.parameters():
+                p.grad = self._flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self._flat.zero_()
+
     def allreduce_grads(self):
-        params = [p for p in self.gcn.parameters() if p.grad is not None]
-        if not params:
+        if not self._grads_are_views():   # (never in train_step; kept correct for callers that manage .grad themselves)
+            off = 0
+            for p in self.gcn.parameters():
+                k = p.numel()
+                if p.grad is not None:
+                    self._flat[off:off + k].copy_(p.grad.reshape(-1))
+                else:
+                    self._flat[off:off + k].zero_()
+                off += k
+            dist.all_reduce(self._flat, group=self.group)
+            off = 0
+            for p in self.gcn.parameters():
+                k = p.numel()
+                p.grad = self._flat[off:off + k].view_as(p)
+                off += k
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        dist.all_reduce(flat, group=self.group)
-        off = 0
-        for p in params:
-            k = p.grad.numel()
-            p.grad.copy_(flat[off:off + k].view_as(p.grad))
-            off += k
+        dist.all_reduce(self._flat, group=self.group)
 
     def _selection(self, mask_local, y_local):
         """Index tensor and labels of a mask, computed once per mask: boolean-mask indexing costs a host sync (and a
@@ -132,7 +161,7 @@ class ShardedGCN(torch.nn.Module):
 
     def train_step(self, optimizer, x_local, y_local, train_mask_local, n_train_global):
         self.train()
-        optimizer.zero_grad()
+        self.zero_grads()
         logp = self(x_local)
         idx, y_sel, count = self._selection(train_mask_local, y_local)
         if count:
@@ -146,11 +175,69 @@ class ShardedGCN(torch.nn.Module):
         return loss.detach()
 
     @torch.no_grad()
-    def eval_correct(self, x_local, y_local, mask_local):
+    def eval_stats(self, x_local, y_local, mask_local):
+        """{correct, count} over all ranks as a 2-element float64 device tensor (no host synchronisation)."""
         self.eval()
         logp = self(x_local)
         idx, y_sel, count = self._selection(mask_local, y_local)
         correct = (logp.index_select(0, idx).argmax(1) == y_sel).sum() if count else logp.new_zeros((), dtype=torch.long)
-        stats = torch.stack([correct.double(), torch.tensor(float(count), dtype=torch.float64, device=logp.device)])
+        stats = torch.stack([correct.double(), torch.full((), float(count), dtype=torch.float64, device=logp.device)])
         dist.all_reduce(stats, group=self.group)
+        return stats
+
+    def eval_correct(self, x_local, y_local, mask_local):
+        stats = self.eval_stats(x_local, y_local, mask_local)
         return (stats[0] / stats[1].clamp(min=1)).item()
+
+
+class GraphedShardedEpoch:
+    """One data-parallel epoch (training step, then validation accuracy) replayed as two captured HIP graphs per rank,
+    the collectives inside (RCCL kernels are stream work like any other and capture with it; gloo moves data on the host
+    and cannot).  At eight ranks an epoch is well under a millisecond of kernels behind ~60 launches and three
+    collectives: launch-bound when run eagerly.  The first ``WARMUP`` calls run eagerly (communicators, library handles,
+    the cached Â_p·X and the Adam state come into being there); every rank must make the same calls in the same order,
+    as with any collective.  Needs ``capturable=True`` on the optimiser."""
+
+    WARMUP = 3
+
+    def __init__(self, sharded, optimizer, x_local, y_local, train_mask_local, val_mask_local, n_train_global):
+        self.sh, self.opt = sharded, optimizer
+        self.args = (x_local, y_local, train_mask_local, n_train_global)
+        self.val = (x_local, y_local, val_mask_local)
+        self.calls = 0
+        self.train_graph = self.eval_graph = None
+        self.stream = torch.cuda.Stream(device=x_local.device)
+
+    @staticmethod
+    def supported(sharded, optimizer, x_local):
+        import os
+        if os.environ.get('DCR_DP_GRAPH', '1') == '0' or not x_local.is_cuda:
+            return False
+        if dist.get_backend(sharded.group) != 'nccl':
+            return False
+        return all(g.get('capturable', False) for g in optimizer.param_groups)
+
+    def _train(self):
+        x, y, m, n_train = self.args
+        return self.sh.train_step(self.opt, x, y, m, n_train)
+
+    def __call__(self):
+        self.calls += 1
+        cur = torch.cuda.current_stream(self.args[0].device)
+        if self.calls <= self.WARMUP:
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self._train()
+                stats = self.sh.eval_stats(*self.val)
+            cur.wait_stream(self.stream)
+            return (stats[0] / stats[1].clamp(min=1)).item()
+        if self.train_graph is None:
+            self.train_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.train_graph, stream=self.stream):
+                self.loss = self._train()
+            self.eval_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.eval_graph, stream=self.stream):
+                self.stats = self.sh.eval_stats(*self.val)
+        self.train_graph.replay()
+        self.eval_graph.replay()
+        return (self.stats[0] / self.stats[1].clamp(min=1)).item()

@@ -74,7 +74,7 @@ def run_recorded(case, device='cpu', capturable=False):
     return model, data, losses, accs
 
 
-def check(case, model, data, losses, accs, tol=LOSS_RTOL, wtol=1e-7):
+def check(case, model, data, losses, accs, tol=LOSS_RTOL, wtol=1e-7, watol=1e-9):
     import experiment.training_loop as tl
     assert len(accs) == case['epochs_run']
     assert accs == case['val_accs']                      # counts over small masks: exact
@@ -85,7 +85,7 @@ def check(case, model, data, losses, accs, tol=LOSS_RTOL, wtol=1e-7):
             assert abs(a - b) <= tol * max(1.0, abs(b)), (e, a, b)
     for k, v in model.state_dict().items():              # the weights of the best epoch (>= rule: the LAST maximum)
         w = torch.tensor(case['final'][k], dtype=torch.float64)
-        assert torch.allclose(v.cpu(), w, rtol=wtol, atol=wtol * 1e-2), k
+        assert torch.allclose(v.cpu(), w, rtol=wtol, atol=watol), k
     ev = tl.evaluate(model, data, True)
     assert ev['val_acc'] == case['final_val_acc'] == case['val_accs'][case['best_epoch']]
     assert ev['test_acc'] == case['final_test_acc']
