@@ -131,14 +131,12 @@ __device__ inline unsigned cnt_add(unsigned *cnt, int h) {
     return (atomicAdd(&cnt[h >> 1], 1u << sh) >> sh) & 0xFFFFu;
 }
 
-// One aligned piece of a streamed row: which of its four entries (those selected by `vmask`) are unflagged members of
-// the table, as a 4-bit mask; s1 / gam pick up what the slot counters say about the node that was hit.
+// One aligned piece of a streamed row: which of its four entries (those selected by `vmask`) may be in the table.
 //
-// Almost every streamed id is NOT in the table, so the common case is kept to the bare minimum: hash, one 16-byte
-// LDS read, four equality compares and a "bucket full" compare per id, whose lane masks are combined on the scalar
-// unit.  Only when some lane of the wave-instruction has a match or a full home bucket does the wave branch into the
-// full lookup for that id: slot position, walk to the next bucket, validity of the entry (pieces are compared raw;
-// ids outside the row, slack included, can only cause a needless visit of the slow path), slot counter update.
+// Almost every streamed id is NOT in the table, so the test is kept to the bare minimum: hash, one 16-byte LDS read, four
+// equality compares and a "bucket full" compare per id (nc_probe_flags).  Pieces are compared raw; ids outside the row,
+// slack included, are masked off afterwards.  What passes the test is queued for the full look-up (slot position, walk
+// to the next bucket, slot counter update), see NC_QCAP below.
 #ifdef NC_STATS  // diagnostic build (tools/build_variant.sh stats -DNC_STATS): how often the fast test fails
 __device__ unsigned long long nc_stats[8];
 #define NC_STATS_COUNT(look_any)                                                             \
@@ -155,18 +153,6 @@ __device__ unsigned long long nc_stats[8];
 #define NC_STATS_COUNT(look_any)
 #endif
 
-template <int SLOTS>
-__device__ inline int nc_find_from(const uint4 *tb, unsigned b, uint4 e, unsigned key) {
-    while (true) {
-        bool go_on;
-        const int pos = bucket_match(e, key, go_on);
-        if (pos >= 0) return (int)(b * 4) + pos;
-        if (!go_on) return -1;
-        b = (b + 1) & (SLOTS / 4 - 1);
-        e = tb[b];
-    }
-}
-
 // ovf (uniform): the table has keys outside their home buckets, so a full home bucket without a match is not yet a miss
 // vskip: the other endpoint v of the edge.  It is in the table (a neighbour of u) and in EVERY streamed row (their nodes
 // are neighbours of v), and it is never counted (flagged): without this test each row would take the slow path once.
@@ -176,41 +162,19 @@ __device__ inline bool bucket_look(const uint4 e, unsigned key, bool ovf, unsign
     return look & (key != vskip);
 }
 
+// which of the four entries of a piece (those selected by vmask) need the full look-up: bit j set = entry j
 template <int SLOTS>
-__device__ inline unsigned nc_probe_piece(const unsigned *tab, unsigned *cnt, const int4 w, unsigned vmask, int &s1,
-                                          int &gam, bool ovf, unsigned vskip) {
+__device__ inline unsigned nc_probe_flags(const unsigned *tab, const int4 w, unsigned vmask, bool ovf, unsigned vskip) {
     const unsigned k[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
     const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
-    unsigned b[4];
     uint4 e[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        b[j] = hash_bucket<SLOTS>(k[j]);
-        e[j] = tb[b[j]];
-    }
-    unsigned m = 0;
-    bool look[4];
+    for (int j = 0; j < 4; ++j) e[j] = tb[hash_bucket<SLOTS>(k[j])];
+    unsigned f = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) look[j] = bucket_look(e[j], k[j], ovf, vskip);
-    NC_STATS_COUNT(look[0] | look[1] | look[2] | look[3])
-    if (!__ballot(look[0] | look[1] | look[2] | look[3])) return 0u;  // uniform; the common case
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (__ballot(look[j])) {  // uniform
-            if (look[j] && ((vmask >> j) & 1u)) {
-                const int h = nc_find_from<SLOTS>(tb, b[j], e[j], k[j]);
-                if (h >= 0) {
-                    const unsigned old = cnt_add(cnt, h);
-                    if (!(old & 0x8000u)) {
-                        m |= 1u << j;
-                        s1 += (old == 0u);
-                        gam = (int)old + 1 > gam ? (int)old + 1 : gam;
-                    }
-                }
-            }
-        }
-    }
-    return m;
+    for (int j = 0; j < 4; ++j) f |= (bucket_look(e[j], k[j], ovf, vskip) ? 1u : 0u) << j;
+    NC_STATS_COUNT((f & vmask) != 0u)
+    return f & vmask;
 }
 
 // which of the four entries of the piece at slot a lie inside the row [lo, hi)
@@ -242,6 +206,14 @@ struct NcEdge {
     int T, s1, s2, gam, posu;
 };
 
+// Full look-ups are not done in line.  A streamed id that may be in the table is rare per lane (1.2 % on the bench graph)
+// but 42 % of the wave-level probes have one in SOME lane, and the look-up (walk, validity, counter update) then ran with
+// ~7 of 64 lanes active: a quarter of the pass's vector instructions.  The lanes queue (id, row) in LDS instead and the
+// wave works the queue off 64 items at a time.
+#ifndef NC_QCAP
+#define NC_QCAP 128
+#endif
+
 // per-wave scratch in LDS
 struct NcScratch {
     int2 desc[64];   // {start, length} of the DY rows of the current batch
@@ -252,7 +224,30 @@ struct NcScratch {
     int res[4][5];   // batch results per edge: T, |sq| table side, |sq| row side, gamma, position of u in row v
     int fin[32][5];  // the same per position of the unit, read back when the closing expressions are evaluated
     int spilled;     // set while the table is built: some key lives outside its home bucket
+    unsigned qk[NC_QCAP];       // queued full look-ups: streamed id ...
+    unsigned char qrow[NC_QCAP];  // ... and its row of the batch
 };
+
+// push the flagged entries of one piece (ALL lanes call this; lanes without a piece pass f = 0).  qn is uniform; `drain`
+// works the queue off and resets qn (called when fewer than 64 slots are left: one entry position adds at most 64 items)
+template <typename Drain>
+__device__ inline void nc_queue_push(NcScratch *sc, int &qn, unsigned f, const int4 w, int row, Drain drain) {
+    const unsigned k[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
+    const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool p = (f >> j) & 1u;
+        const unsigned long long m = __ballot(p);
+        if (m == 0) continue;  // uniform
+        if (qn > NC_QCAP - 64) drain();
+        if (p) {
+            const int idx = qn + __popcll(m & below);
+            sc->qk[idx] = k[j];
+            sc->qrow[idx] = (unsigned char)row;
+        }
+        qn += __popcll(m);
+    }
+}
 
 // One edge {u,v} owned by u, by one wave.  `tab` holds N(u); cnt and sc are this wave's scratch.
 template <int SLOTS, int MODE>
@@ -300,6 +295,26 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
     // the lanes share evenly, whatever the row lengths: lane t takes pieces t, t + 64, ... and keeps four loads in
     // flight; the row of a piece is found by bisection of the prefix sums of the rows' piece counts.
     int s1 = 0, gam = 0, s2 = 0;
+    int qn = 0;  // queued full look-ups (uniform)
+    auto drain = [&]() {
+        wave_sync();
+        for (int qb = 0; qb < qn; qb += 64) {
+            const int qi = qb + lane;
+            if (qi < qn) {
+                const int h = nc_find<SLOTS>(tab, sc->qk[qi]);
+                if (h >= 0) {
+                    const unsigned old = cnt_add(cnt, h);
+                    if (!(old & 0x8000u)) {  // not a member of N(v): a 4-cycle u-z-w-v
+                        atomicAdd(&sc->rowcnt[sc->qrow[qi]], 1);
+                        s1 += (old == 0u);
+                        gam = (int)old + 1 > gam ? (int)old + 1 : gam;
+                    }
+                }
+            }
+        }
+        wave_sync();
+        qn = 0;
+    };
     for (int base = 0; base < rv.y; base += 64) {
         const int i = base + lane;
         int k = k_first;
@@ -350,15 +365,17 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
             }
 #pragma unroll
             for (int q = 0; q < NC_Q; ++q) {
+                if (j0 + 64 * q >= P) continue;  // uniform
+                unsigned f = 0u;
                 if (rr[q] >= 0) {
                     const int2 d = sc->desc[rr[q]];
-                    const unsigned m = nc_probe_piece<SLOTS>(tab, cnt, w[q], piece_mask(aa[q], d.x, d.x + d.y), s1, gam, ovf,
-                                                             (unsigned)v);
-                    if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
+                    f = nc_probe_flags<SLOTS>(tab, w[q], piece_mask(aa[q], d.x, d.x + d.y), ovf, (unsigned)v);
                 }
+                if (__ballot(f != 0u)) nc_queue_push(sc, qn, f, w[q], rr[q], drain);  // uniform; rare per lane, common per wave
                 __builtin_amdgcn_sched_barrier(0);  // one probe sequence live at a time: keeps the wave at 8 per SIMD
             }
         }
+        if (qn > 0) drain();
         wave_sync();
         const int c = sc->rowcnt[lane];
         s2 += __popcll(__ballot(c > 0));
@@ -382,45 +399,6 @@ __device__ inline NcEdge nc_edge(const View &g, int u, int v, int2 rv, const uns
 // edges processed side by side by one wave (their neighbour rows share the 64 lanes): 4 for the smallest class,
 // 2 for the next, 1 (no batching) for the block classes
 __host__ __device__ constexpr int nc_batch_for_slots(int slots) { return slots <= 256 ? 4 : slots <= 512 ? 2 : 1; }
-
-// nc_probe_piece for a batch: the lanes of one wave-instruction work on rows of different edges, so the slot counters
-// (cnt) and the per-edge totals (acc: LDS atomics, hits are rare) are passed per lane
-template <int SLOTS>
-__device__ inline unsigned nc_probe_piece_acc(const unsigned *tab, unsigned *cnt, int *acc, const int4 w, unsigned vmask,
-                                              bool ovf, unsigned vskip) {
-    const unsigned k[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
-    const uint4 *tb = reinterpret_cast<const uint4 *>(tab);
-    unsigned b[4];
-    uint4 e[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        b[j] = hash_bucket<SLOTS>(k[j]);
-        e[j] = tb[b[j]];
-    }
-    unsigned m = 0;
-    bool look[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) look[j] = bucket_look(e[j], k[j], ovf, vskip);
-    NC_STATS_COUNT(look[0] | look[1] | look[2] | look[3])
-    if (!__ballot(look[0] | look[1] | look[2] | look[3])) return 0u;  // uniform; the common case
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (__ballot(look[j])) {  // uniform
-            if (look[j] && ((vmask >> j) & 1u)) {
-                const int h = nc_find_from<SLOTS>(tb, b[j], e[j], k[j]);
-                if (h >= 0) {
-                    const unsigned old = cnt_add(cnt, h);
-                    if (!(old & 0x8000u)) {
-                        m |= 1u << j;
-                        if (old == 0u) atomicAdd(&acc[0], 1);   // a new member of sq on the table side
-                        else atomicMax(&acc[1], (int)old + 1);  // (a first hit's 1 is covered by the row-side maximum)
-                    }
-                }
-            }
-        }
-    }
-    return m;
-}
 
 // B edges {u, v_b} owned by u, by one wave: lane group b (64 / B lanes) sweeps N(v_b); the rows of all the DY sets form
 // one flat piece list.  `v`, `rv` are those of the lane's group (rv.y == 0: the group has no edge; every rv.y <= 64 / B).
@@ -472,6 +450,27 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
     sc->rowcnt[lane] = 0;
     if (lane == 0) sc->poff[64] = P;
     wave_sync();
+    int qn = 0;  // queued full look-ups (uniform); the row of an item tells its edge: group = row / G
+    auto drain = [&]() {
+        wave_sync();
+        for (int qb = 0; qb < qn; qb += 64) {
+            const int qi = qb + lane;
+            if (qi < qn) {
+                const int h = nc_find<SLOTS>(tab, sc->qk[qi]);
+                if (h >= 0) {
+                    const int row = sc->qrow[qi], qg = row / G;
+                    const unsigned old = cnt_add(cnt + qg * (SLOTS / 2), h);
+                    if (!(old & 0x8000u)) {
+                        atomicAdd(&sc->rowcnt[row], 1);
+                        if (old == 0u) atomicAdd(&sc->acc4[qg][0], 1);   // a new member of sq on the table side
+                        else atomicMax(&sc->acc4[qg][1], (int)old + 1);  // (a first hit's 1 is covered by the row-side maximum)
+                    }
+                }
+            }
+        }
+        wave_sync();
+        qn = 0;
+    };
     for (int j0 = 0; j0 < P; j0 += 64 * NC_Q) {
         int4 w[NC_Q];
         int rr[NC_Q], aa[NC_Q];
@@ -494,17 +493,19 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
         }
 #pragma unroll
         for (int q = 0; q < NC_Q; ++q) {
+            if (j0 + 64 * q >= P) continue;  // uniform
             const int gr = (rr[q] < 0 ? 0 : rr[q]) / G;
             const unsigned vgr = (unsigned)__shfl(v, gr * G);  // the edge this row belongs to (all lanes converged here)
+            unsigned f = 0u;
             if (rr[q] >= 0) {
                 const int2 d = sc->desc[rr[q]];
-                const unsigned m = nc_probe_piece_acc<SLOTS>(tab, cnt + gr * (SLOTS / 2), sc->acc4[gr], w[q],
-                                                             piece_mask(aa[q], d.x, d.x + d.y), ovf, vgr);
-                if (m) atomicAdd(&sc->rowcnt[rr[q]], __popc(m));
+                f = nc_probe_flags<SLOTS>(tab, w[q], piece_mask(aa[q], d.x, d.x + d.y), ovf, vgr);
             }
+            if (__ballot(f != 0u)) nc_queue_push(sc, qn, f, w[q], rr[q], drain);  // uniform
             __builtin_amdgcn_sched_barrier(0);  // one probe sequence live at a time
         }
     }
+    if (qn > 0) drain();
     wave_sync();
     const int c = sc->rowcnt[lane];
     const int s2 = __popcll(__ballot(c > 0) & gmask);
