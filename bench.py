@@ -103,7 +103,7 @@ def gcn_bench(args, rank, world, local_rank, dist):
 
     if dist is None:
         from experiment.training_loop import make_epoch
-        epoch = make_epoch(model, opt, data)  # eager for three epochs, then two captured HIP graphs per epoch
+        epoch = make_epoch(model, opt, data, lagged=True)  # one captured HIP graph per epoch (LaggedGraphedEpoch)
     else:
         sh = ShardedGCN(model, ei, n)
         xl, yl, tl, vl = sh.shard(x), sh.shard(y), sh.shard(train_mask), sh.shard(val_mask)
@@ -131,7 +131,8 @@ def gcn_bench(args, rank, world, local_rank, dist):
         el = float(t.item())
     res = {'metric': 'GCN epochs/sec', 'value': args.gcn_epochs / el, 'unit': 'epochs/sec', 'n_gpus': world,
            'epochs': args.gcn_epochs, 'ms_per_epoch': el / args.gcn_epochs * 1e3, 'scaling': 'strong', 'dtype': 'f32',
-           'hip_graph': type(epoch).__name__ in ('GraphedEpoch', 'GraphedShardedEpoch'),
+           'hip_graph': type(epoch).__name__ in ('GraphedEpoch', 'LaggedGraphedEpoch', 'GraphedShardedEpoch'),
+           'epoch_driver': type(epoch).__name__,
            'config': {'workload': f'synthetic preferential-attachment graph N={n} E={ei_np.shape[1] // 2}, F={F}, '
                                   f'hidden={H}, classes={C}, dropout 0.5, Adam; epoch = train step + val forward',
                       'parallelism': f'row-partitioned dp{world}' if world > 1 else 'single GPU'}}
@@ -241,7 +242,7 @@ def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, ep
     opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
                             {'params': model.reg_params, 'weight_decay': wd}], lr=lr, capturable=True)
     # the epoch as experiment/training_loop.py runs it: eager for the first calls, then two captured HIP graphs
-    epoch = make_epoch(model, opt, data)
+    epoch = make_epoch(model, opt, data, lagged=True)
     for _ in range(10):
         epoch()
     torch.cuda.synchronize()
@@ -251,7 +252,7 @@ def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, ep
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return {'metric': 'GCN epochs/sec', 'value': epochs / el, 'unit': 'epochs/sec', 'ms_per_epoch': el / epochs * 1e3,
-            'dtype': 'f32', 'hip_graph': type(epoch).__name__ == 'GraphedEpoch', 'config': {'workload': f'Citeseer-shaped synthetic graph N={n} E={ei_np.shape[1] // 2}, '
+            'dtype': 'f32', 'hip_graph': type(epoch).__name__ in ('GraphedEpoch', 'LaggedGraphedEpoch'), 'epoch_driver': type(epoch).__name__, 'config': {'workload': f'Citeseer-shaped synthetic graph N={n} E={ei_np.shape[1] // 2}, '
                                                    f'F={n_feat}, hidden={hidden}, classes={n_cls}, dropout {dropout}, '
                                                    f'Adam lr {lr} wd {wd}; epoch = train step + val forward'}}
 

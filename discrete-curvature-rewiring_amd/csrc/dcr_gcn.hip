@@ -9,45 +9,56 @@
 
 namespace dcr {
 
-// accumulate non-zeros e0, e0 + stride, ... < e1 of one row into acc (U gathers of B in flight)
-template <int VEC, int U>
+// accumulate non-zeros e0, e0 + stride, ... < e1 of one row into acc (U gathers of B in flight).  NBLK > 1: B holds NBLK
+// column blocks `blk` floats apart (two operands aggregated in one sweep of the indices, models/gcn.py forward_pair);
+// every block is accumulated with exactly the operations, in exactly the order, of a sweep of its own.
+template <int VEC, int U, int NBLK>
 __device__ inline void spmm_accumulate(const int32_t *__restrict__ col, const float *__restrict__ val,
                                        const float *__restrict__ B, int64_t ldb, int f0, int64_t e0, int64_t e1,
-                                       int64_t stride, float (&acc)[VEC]) {
+                                       int64_t stride, int blk, float (&acc)[NBLK][VEC]) {
+    constexpr int UU = NBLK > 1 ? U / 2 : U;  // the same number of gathers in flight
     int64_t e = e0;
-    for (; e + (U - 1) * stride < e1; e += U * stride) {
-        int c[U];
-        float w[U];
-        float b[U][VEC];
+    for (; e + (UU - 1) * stride < e1; e += UU * stride) {
+        int c[UU];
+        float w[UU];
+        float b[UU][NBLK][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             c[u] = col[e + u * stride];
             w[u] = val[e + u * stride];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float *src = B + (int64_t)c[u] * ldb + f0;
-            if (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(src);
-                b[u][0] = t.x; b[u][1 % VEC] = t.y; b[u][2 % VEC] = t.z; b[u][3 % VEC] = t.w;
-            } else if (VEC == 2) {
-                const float2 t = *reinterpret_cast<const float2 *>(src);
-                b[u][0] = t.x; b[u][1 % VEC] = t.y;
-            } else {
-                b[u][0] = src[0];
+        for (int u = 0; u < UU; ++u) {
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) {
+                const float *src = B + (int64_t)c[u] * ldb + f0 + k * blk;
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src);
+                    b[u][k][0] = t.x; b[u][k][1 % VEC] = t.y; b[u][k][2 % VEC] = t.z; b[u][k][3 % VEC] = t.w;
+                } else if (VEC == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(src);
+                    b[u][k][0] = t.x; b[u][k][1 % VEC] = t.y;
+                } else {
+                    b[u][k][0] = src[0];
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < UU; ++u)
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w[u], b[u][q], acc[q]);
+            for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[k][q] = fmaf(w[u], b[u][k][q], acc[k][q]);
     }
     for (; e < e1; e += stride) {
         const int c = col[e];
         const float w = val[e];
-        const float *src = B + (int64_t)c * ldb + f0;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, src[q], acc[q]);
+        for (int k = 0; k < NBLK; ++k) {
+            const float *src = B + (int64_t)c * ldb + f0 + k * blk;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[k][q] = fmaf(w, src[q], acc[k][q]);
+        }
     }
 }
 
@@ -57,11 +68,11 @@ __device__ inline void spmm_accumulate(const int32_t *__restrict__ col, const fl
 // the partial sums are added in group order, so the result is deterministic.
 constexpr int SPMM_LONG = 96;
 
-template <int LPR, int VEC>
+template <int LPR, int VEC, int NBLK>
 __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const float *__restrict__ val, const float *__restrict__ B,
                                                    float *__restrict__ C, int64_t n_rows, int n_feat, int64_t ldb,
-                                                   int64_t ldc, const float *__restrict__ bias, int relu) {
+                                                   int64_t ldc, const float *__restrict__ bias, int relu, int blk) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     constexpr int G = ROWS_PER_BLOCK;        // lane groups per workgroup
     constexpr int U = LPR <= 8 ? 8 : 4;      // narrow rows of B: more gathers in flight per group
@@ -80,17 +91,22 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
             if (sl == 0) long_rows[atomicAdd(&n_long, 1)] = sub;
         } else {
             for (int f0 = sl * VEC; f0 < n_feat; f0 += LPR * VEC) {
-                float acc[VEC];
+                float acc[NBLK][VEC];
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-                spmm_accumulate<VEC, U>(col, val, B, ldb, f0, e0, e1, 1, acc);
-                float *dst = C + row * ldc + f0;
+                for (int k = 0; k < NBLK; ++k)
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    float r = acc[q];
-                    if (bias) r += bias[f0 + q];
-                    if (relu) r = r > 0.f ? r : 0.f;
-                    dst[q] = r;
+                    for (int q = 0; q < VEC; ++q) acc[k][q] = 0.f;
+                spmm_accumulate<VEC, U, NBLK>(col, val, B, ldb, f0, e0, e1, 1, blk, acc);
+#pragma unroll
+                for (int k = 0; k < NBLK; ++k) {
+                    float *dst = C + row * ldc + f0 + k * blk;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float r = acc[k][q];
+                        if (bias) r += bias[f0 + q];
+                        if (relu) r = r > 0.f ? r : 0.f;
+                        dst[q] = r;
+                    }
                 }
             }
         }
@@ -102,55 +118,66 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
         const int64_t e0 = rowptr[lrow], e1 = rowptr[lrow + 1];
         for (int fb = 0; fb < n_feat; fb += LPR * VEC) {  // uniform trip count
             const int f0 = fb + sl * VEC;
-            float acc[VEC];
+            float acc[NBLK][VEC];
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-            if (f0 < n_feat) spmm_accumulate<VEC, U>(col, val, B, ldb, f0, e0 + sub, e1, G, acc);
+            for (int k = 0; k < NBLK; ++k)
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) red[threadIdx.x * VEC + q] = acc[q];
-            __syncthreads();
-            if (sub == 0 && f0 < n_feat) {
-                float *dst = C + lrow * ldc + f0;
+                for (int q = 0; q < VEC; ++q) acc[k][q] = 0.f;
+            if (f0 < n_feat) spmm_accumulate<VEC, U, NBLK>(col, val, B, ldb, f0, e0 + sub, e1, G, blk, acc);
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    float r = 0.f;
-                    for (int g = 0; g < G; ++g) r += red[(g * LPR + sl) * VEC + q];
-                    if (bias) r += bias[f0 + q];
-                    if (relu) r = r > 0.f ? r : 0.f;
-                    dst[q] = r;
+            for (int k = 0; k < NBLK; ++k) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) red[threadIdx.x * VEC + q] = acc[k][q];
+                __syncthreads();
+                if (sub == 0 && f0 < n_feat) {
+                    float *dst = C + lrow * ldc + f0 + k * blk;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float r = 0.f;
+                        for (int g = 0; g < G; ++g) r += red[(g * LPR + sl) * VEC + q];
+                        if (bias) r += bias[f0 + q];
+                        if (relu) r = r > 0.f ? r : 0.f;
+                        dst[q] = r;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 }
 
 template <int LPR, int VEC>
 static void launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
-                        int64_t n_rows, int n_feat, int64_t ldb, int64_t ldc, const float *bias, int relu,
+                        int64_t n_rows, int n_feat, int64_t ldb, int64_t ldc, const float *bias, int relu, int n_blocks,
                         hipStream_t st) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     const int64_t blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL((k_spmm_csr<LPR, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                       n_feat, ldb, ldc, bias, relu);
+    if (n_blocks == 2)
+        hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 2>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
+                           n_feat, ldb, ldc, bias, relu, n_feat);
+    else
+        hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 1>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
+                           n_feat, ldb, ldc, bias, relu, 0);
 }
 
 }  // namespace dcr
 
 using namespace dcr;
 
-extern "C" int dcr_spmm_csr_f32_dev(const int64_t *rowptr, const int32_t *col, const float *val, const float *B,
-                                    float *C, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
-                                    const float *bias, int relu, void *hip_stream) {
-    if (!rowptr || !B || !C || n_rows < 0 || n_feat <= 0 || ldb < n_feat || ldc < n_feat)
+static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
+                         int64_t n_rows, int64_t n_feat, int64_t n_blocks, int64_t ldb, int64_t ldc, const float *bias, int relu,
+                         void *hip_stream) {
+    if (!rowptr || !B || !C || n_rows < 0 || n_feat <= 0 || n_blocks < 1 || n_blocks > 2 || ldb < n_feat * n_blocks ||
+        ldc < n_feat * n_blocks)
         DCR_FAIL(DCR_EINVAL, "bad SpMM arguments");
     if (n_rows == 0) return DCR_OK;
-    if (n_feat > INT32_MAX) DCR_FAIL(DCR_EINVAL, "n_feat too large");
+    if (n_feat > INT32_MAX / 2) DCR_FAIL(DCR_EINVAL, "n_feat too large");
     hipStream_t st = (hipStream_t)hip_stream;
     const int F = (int)n_feat;
+    // (the template is chosen by the width of ONE block: a block of a two-block call is accumulated exactly like a call of its own)
     const bool v4 = (F % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)B & 15) == 0);
     const bool v2 = (F % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) && (((uintptr_t)B & 7) == 0);
-#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, st)
+#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, st)
     if (v4) {
         const int lanes = F / 4;
         if (lanes <= 4) GO(4, 4);
@@ -175,6 +202,18 @@ extern "C" int dcr_spmm_csr_f32_dev(const int64_t *rowptr, const int32_t *col, c
 #undef GO
     DCR_HIP(hipGetLastError());
     return DCR_OK;
+}
+
+extern "C" int dcr_spmm_csr_f32_dev(const int64_t *rowptr, const int32_t *col, const float *val, const float *B,
+                                    float *C, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
+                                    const float *bias, int relu, void *hip_stream) {
+    return spmm_dispatch(rowptr, col, val, B, C, n_rows, n_feat, 1, ldb, ldc, bias, relu, hip_stream);
+}
+
+extern "C" int dcr_spmm_csr_f32_pair_dev(const int64_t *rowptr, const int32_t *col, const float *val, const float *B,
+                                         float *C, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
+                                         const float *bias, int relu, void *hip_stream) {
+    return spmm_dispatch(rowptr, col, val, B, C, n_rows, n_feat, 2, ldb, ldc, bias, relu, hip_stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

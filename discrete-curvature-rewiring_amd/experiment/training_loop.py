@@ -122,9 +122,94 @@ class GraphedEpoch:
         return self.correct.item() / self.n_val
 
 
-def make_epoch(model, optimizer, data):
+class LaggedGraphedEpoch(GraphedEpoch):
+    """ONE captured HIP graph per epoch for models that offer ``forward_pair`` (models/gcn.py).
+
+    The reference's loop is train(e), evaluate(e), train(e+1), ... (training_loop.py:25-26), and evaluate(e) and the forward
+    of train(e+1) run on the same weights.  So the graph of step e+1 is: snapshot the weights, ``forward_pair`` (training
+    log-probabilities AND the evaluation log-probabilities of the weights as they stand, i.e. of epoch e), loss, backward,
+    optimiser step.  A replay therefore performs training step e+1 and delivers the validation accuracy of epoch e: the
+    first layer's GEMM and every aggregation are paid once for both (1.1 of the 5.3 ms of an epoch at the 1M-node
+    shape).  ``training_loop`` consumes the accuracies one step late: the checkpoint of epoch e is taken from the snapshot,
+    and a step that turns out to follow the stopping epoch is discarded with the rest when the best weights are restored,
+    so the returned model and every accuracy are what the plain loop gives.
+
+    ``step()`` = one replay; ``accuracy_before_step()`` = validation accuracy of the weights the last step started from;
+    ``snapshot()`` = those weights; ``accuracy_now()`` = a plain evaluation graph (used once, after the last step)."""
+
+    def __init__(self, model, optimizer, data):
+        super().__init__(model, optimizer, data)
+        self.graph = None
+        self.prev = None
+
+    @staticmethod
+    def supported(model, optimizer, data):
+        return (hasattr(model, 'forward_pair') and os.environ.get('DCR_LAGGED_EVAL', '1') != '0'
+                and GraphedEpoch.supported(model, optimizer, data))
+
+    def _fused_step(self):
+        for dst, src in zip(self.prev, self.model.state_dict().values()):
+            dst.copy_(src)
+        lp_train, lp_eval = self.model.forward_pair(self.data)
+        correct_prev = lp_eval.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
+        loss = F.nll_loss(lp_train.index_select(0, self.train_idx), self.y_train)
+        loss.backward()
+        self.optimizer.step()
+        return correct_prev
+
+    def step(self):
+        cur = torch.cuda.current_stream(self.data.x.device)
+        if self.graph is None:
+            self.prev = [v.detach().clone() for v in self.model.state_dict().values()]
+            self.model.train()
+            self.optimizer.zero_grad(set_to_none=True)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):  # one eager run of the fused step's own kernels before the capture
+                self.optimizer.zero_grad(set_to_none=True)
+                self._warm = self._fused_step()
+            cur.wait_stream(self.stream)
+            self.optimizer.zero_grad(set_to_none=True)
+            self.graph = torch.cuda.CUDAGraph()
+            self._pending_capture = True
+            return self._warm
+        if self._pending_capture:
+            self._pending_capture = False
+            self.model.train()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.correct_prev = self._fused_step()
+        self.graph.replay()
+        return self.correct_prev
+
+    def snapshot(self):
+        return {k: v.clone() for k, v in zip(self.model.state_dict().keys(), self.prev)}
+
+    def accuracy_now(self):
+        if self.eval_graph is None:
+            self.model.eval()
+            cur = torch.cuda.current_stream(self.data.x.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self._val_correct()
+            cur.wait_stream(self.stream)
+            self.eval_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.eval_graph, stream=self.stream):
+                self.correct = self._val_correct()
+            self.model.train()
+        self.eval_graph.replay()
+        return self.correct.item() / self.n_val
+
+    def __call__(self):
+        """For drivers that only want epochs done (bench.py): one training step + the evaluation that travels with it;
+        returns the validation accuracy of the weights the step started from."""
+        return self.step().item() / self.n_val
+
+
+def make_epoch(model, optimizer, data, lagged=False):
     """A callable that runs one epoch (training step + validation forward) and returns the validation accuracy:
-    graph replay where supported, the eager ``train`` / ``evaluate`` pair otherwise."""
+    graph replay where supported, the eager ``train`` / ``evaluate`` pair otherwise.  ``lagged=True`` (throughput
+    drivers): the one-graph epoch whose accuracy is that of the previous step's weights (``LaggedGraphedEpoch``)."""
+    if lagged and LaggedGraphedEpoch.supported(model, optimizer, data):
+        return LaggedGraphedEpoch(model, optimizer, data)
     if GraphedEpoch.supported(model, optimizer, data):
         return GraphedEpoch(model, optimizer, data)
 
@@ -138,15 +223,34 @@ def training_loop(model, optimizer, data, epochs, patience):
     """Train with early stopping on validation accuracy; returns the model holding the best weights
     (training_loop.py:10-37)."""
     best_acc, best_weights, since_best = 0, None, 0
-    epoch = make_epoch(model, optimizer, data)
-    for _ in range(epochs):
-        val_acc = epoch()
+
+    def account(val_acc, weights):
+        """training_loop.py:27-33 for one epoch; True: stop."""
+        nonlocal best_acc, best_weights, since_best
         if val_acc >= best_acc:  # ties advance the checkpoint, as in the reference
             best_acc, since_best = val_acc, 0
-            best_weights = copy.deepcopy(model.state_dict())
+            best_weights = weights()
         else:
             since_best += 1
-        if since_best >= patience:
+        return since_best >= patience
+
+    if epochs > 0 and LaggedGraphedEpoch.supported(model, optimizer, data):
+        # one graph per epoch; the accuracy of epoch e arrives with the replay of step e + 1 (see LaggedGraphedEpoch)
+        lag = LaggedGraphedEpoch(model, optimizer, data)
+        stopped = False
+        lag.step()                                           # training step of epoch 0 (its accuracy output: of the initial weights, unused)
+        for e in range(1, epochs):
+            correct = lag.step()                             # training step e, accuracy of epoch e - 1
+            if account(correct.item() / lag.n_val, lag.snapshot):
+                stopped = True                               # the reference stops after epoch e - 1: step e is discarded below
+                break
+        if not stopped:
+            account(lag.accuracy_now(), lambda: copy.deepcopy(model.state_dict()))
+        model.load_state_dict(best_weights)
+        return model
+    epoch = make_epoch(model, optimizer, data)
+    for _ in range(epochs):
+        if account(epoch(), lambda: copy.deepcopy(model.state_dict())):
             break
     model.load_state_dict(best_weights)
     return model

@@ -120,6 +120,25 @@ def spmm(rowptr, col, val, B, n_rows, bias=None, relu=False):
     return fn(rowptr, col, val, B, n_rows, bias, relu)
 
 
+def spmm_pair(rowptr, col, val, B2, n_rows, n_feat, bias=None):
+    """[Â·B0 + bias | Â·B1 + bias] for B2 = [B0 | B1] (two blocks of ``n_feat`` columns) in ONE sweep of the indices
+    (``dcr_spmm_csr_f32_pair_dev``): every block bit-identical to a ``spmm`` call of its own."""
+    if _AGG_BACKEND != 'hip':
+        return torch.cat([_spmm_torch(rowptr, col, val, B2[:, :n_feat], n_rows, bias),
+                          _spmm_torch(rowptr, col, val, B2[:, n_feat:], n_rows, bias)], 1)
+    if not B2.is_cuda:
+        raise RuntimeError('GCN aggregation runs on the MI355X HIP kernel (there is no CPU fallback)')
+    from dcr import _lib
+    B2 = B2.contiguous()
+    C = torch.empty((n_rows, 2 * n_feat), dtype=torch.float32, device=B2.device)
+    stream = torch.cuda.current_stream(B2.device).cuda_stream
+    _lib.check(_lib.lib().dcr_spmm_csr_f32_pair_dev(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), B2.data_ptr(),
+                                                    C.data_ptr(), n_rows, n_feat, 2 * n_feat, 2 * n_feat,
+                                                    bias.data_ptr() if bias is not None else None, 0,
+                                                    ctypes.c_void_p(stream)))
+    return C
+
+
 class _Aggregate(torch.autograd.Function):
     """out = Â·Z + b ; dZ = Âᵀ·dout ; db = Σ_rows dout."""
 
@@ -140,6 +159,26 @@ class _Aggregate(torch.autograd.Function):
 
 def aggregate(z, bias, csr):
     return _Aggregate.apply(z, bias, csr)
+
+
+class _AggregatePair(torch.autograd.Function):
+    """(Â·Z_train + b, Â·Z_eval + b) in one pass over the graph; only the training operand carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, z_train, z_eval, bias, csr):
+        ctx.csr = csr
+        ctx.has_bias = bias is not None
+        f = z_train.shape[1]
+        out = spmm_pair(csr.rowptr, csr.col, csr.val, torch.cat([z_train, z_eval], 1), csr.n_rows, f, bias=bias)
+        return out[:, :f].contiguous(), out[:, f:].contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_train, grad_eval):
+        csr = ctx.csr
+        grad_train = grad_train.contiguous()
+        gz = spmm(csr.rowptr_t, csr.col_t, csr.val_t, grad_train, csr.n_cols) if ctx.needs_input_grad[0] else None
+        gb = grad_train.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gz, None, gb, None
 
 
 def atb_hip(a, b):
@@ -355,6 +394,28 @@ class GCN(torch.nn.Module):
             if depth < last:
                 h = relu_dropout(h, self.act_fn, self.dropout)
         return torch.nn.functional.log_softmax(h, dim=1)
+
+    def forward_pair(self, data):
+        """(training-mode log-probabilities with their autograd graph, evaluation-mode log-probabilities) of the SAME
+        weights in one pass: what ``model.train(); model(data)`` and ``model.eval(); model(data)`` return, value for
+        value.  The two differ only in the dropout between the layers, so the first layer's output is computed once and
+        every later aggregation serves both operands in one sweep of the graph (``spmm_pair``).  The validation forward
+        of one epoch and the training forward of the next see the same weights (experiment/training_loop.py:25-26:
+        train, then evaluate, then train again), which is what ``LaggedGraphedEpoch`` builds on.  Call in training mode."""
+        last = len(self.layers) - 1
+        first = self.layers[0]
+        o_tr = first(data.x, data.edge_index, edge_weight=data.edge_attr)
+        o_ev = o_tr.detach()
+        for depth, conv in enumerate(list(self.layers)[1:], start=1):
+            h_tr = relu_dropout(o_tr, self.act_fn, self.dropout)
+            with torch.no_grad():
+                h_ev = self.act_fn(o_ev)                 # (dropout is the identity in evaluation mode)
+                z_ev = conv.lin(h_ev)
+            z_tr = conv.lin(h_tr)
+            csr = conv.norm_csr(data.edge_index, data.edge_attr, h_tr.shape[0])
+            o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, conv.bias, csr)
+        log_softmax = torch.nn.functional.log_softmax
+        return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)
 
 
 def dense_reference_logits(model, x, edge_index, num_nodes):

@@ -177,6 +177,16 @@ int dcr_spmm_csr_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, cons
                          const float *B_dev, float *C_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
                          const float *bias_dev, int relu, void *hip_stream);
 
+/* Two operands in one sweep of the indices: B = [B0 | B1] and C = [C0 | C1] hold two blocks of n_feat columns side by
+ * side (ldb, ldc >= 2 * n_feat); C0 = Â·B0 + bias, C1 = Â·B1 + bias, every block accumulated with the operations and in
+ * the order of a dcr_spmm_csr_f32_dev call of its own (bit-identical to two calls).  The training forward of one epoch and
+ * the validation forward of the previous one see the same weights, so their aggregations (models/gcn.py:36, called from
+ * experiment/training_loop.py:50 and :67) share one pass over the graph: the gathers are bound by the number of row
+ * requests, and a 128-byte request costs what a 64-byte one does. */
+int dcr_spmm_csr_f32_pair_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const float *B_dev,
+                              float *C_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc, const float *bias_dev,
+                              int relu, void *hip_stream);
+
 /* ---- GCN weight gradient on the matrix cores (device pointers, caller's stream)
  * C[M x N] = A^T * B with A [K x M] and B [K x N] row-major fp32 (lda/ldb/ldc in
  * elements), K = number of nodes: the backward of GCNConv's bias-free Linear,

@@ -149,3 +149,83 @@ def test_training_loop_reproduces_the_reference_run_on_the_gpu(graphed, monkeypa
         fx.check(case, model, data, losses, accs, tol=1e-7, wtol=1e-4 if graphed else 1e-7, watol=2e-5 if graphed else 1e-9)
         assert (not losses) == graphed  # the graphed epoch does not go through train() at all
         assert tl.GraphedEpoch.supported(model, torch.optim.Adam(model.parameters(), capturable=True), data) == graphed
+
+
+def _gcn_case(dropout, seed=3):
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from models.gcn import GCN
+    dev = torch.device('cuda')
+    ei_np, n = synthetic.powerlaw_graph(1500, 3, seed=5)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(n, 96, device=dev, generator=g)
+    y = torch.randint(0, 5, (n,), device=dev, generator=g)
+    r = torch.rand(n, device=dev, generator=g)
+    data = Data(x=x, edge_index=torch.from_numpy(ei_np).to(dev), y=y, num_nodes=n, train_mask=r < 0.3,
+                val_mask=(r >= 0.3) & (r < 0.6))
+    torch.manual_seed(seed)
+    model = GCN(Dataset(data, 5), hidden=[32], dropout=dropout).to(dev)
+    opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                            {'params': model.reg_params, 'weight_decay': 5e-3}], lr=0.02, capturable=True)
+    return model, opt, data
+
+
+def test_pair_aggregation_and_forward_pair_are_bit_identical_to_separate_passes():
+    """dcr_spmm_csr_f32_pair_dev: every block as a call of its own; GCN.forward_pair: what train-mode and eval-mode forwards
+    return (dropout 0, so that the two are comparable value for value)."""
+    from models.gcn import gcn_norm_csr, spmm, spmm_pair
+    model, _, data = _gcn_case(0.0)
+    csr = gcn_norm_csr(data.edge_index, None, data.num_nodes)
+    for f in (5, 16, 32, 6):
+        g = torch.Generator(device='cuda').manual_seed(f)
+        b2 = torch.randn(data.num_nodes, 2 * f, device='cuda', generator=g)
+        bias = torch.randn(f, device='cuda', generator=g)
+        both = spmm_pair(csr.rowptr, csr.col, csr.val, b2, csr.n_rows, f, bias=bias)
+        assert torch.equal(both[:, :f], spmm(csr.rowptr, csr.col, csr.val, b2[:, :f].contiguous(), csr.n_rows, bias=bias))
+        assert torch.equal(both[:, f:], spmm(csr.rowptr, csr.col, csr.val, b2[:, f:].contiguous(), csr.n_rows, bias=bias))
+    model.train()
+    lp_train, lp_eval = model.forward_pair(data)
+    assert torch.equal(lp_train, model(data))
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(lp_eval, model(data))
+    model.train()
+    lp_train, _ = model.forward_pair(data)
+    lp_train.sum().backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    model(data).sum().backward()
+    for a, p in zip(got, model.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+@pytest.mark.parametrize('epochs,patience', [(40, 4), (9, 100), (1, 5)])
+def test_one_graph_per_epoch_training_loop_equals_the_plain_loop(epochs, patience, monkeypatch):
+    """training_loop through LaggedGraphedEpoch (accuracies consumed one step late, a step past the stopping epoch
+    discarded) returns the weights and visits the accuracies of the plain train / evaluate loop
+    (experiment/training_loop.py:22-37)."""
+    import copy
+    import experiment.training_loop as tl
+    m1, o1, data = _gcn_case(0.0)
+    best, best_w, streak, accs = 0, None, 0, []
+    for _ in range(epochs):
+        tl.train(m1, o1, data)
+        acc = tl.evaluate(m1, data, test=False)['val_acc']
+        accs.append(acc)
+        if acc >= best:
+            best, streak, best_w = acc, 0, copy.deepcopy(m1.state_dict())
+        else:
+            streak += 1
+        if streak >= patience:
+            break
+    m2, o2, _ = _gcn_case(0.0)
+    assert tl.LaggedGraphedEpoch.supported(m2, o2, data)
+    seen = []
+    orig = tl.LaggedGraphedEpoch.step
+    monkeypatch.setattr(tl.LaggedGraphedEpoch, 'step', lambda self: seen.append(1) or orig(self))
+    out = tl.training_loop(m2, o2, data, epochs, patience)
+    assert out is m2
+    assert len(seen) in (len(accs), len(accs) + 1)     # at most the one discarded step more
+    for (k1, v1), (k2, v2) in zip(best_w.items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    assert tl.evaluate(m2, data, test=False)['val_acc'] == best
