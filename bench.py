@@ -113,9 +113,8 @@ def gcn_bench(args, rank, world, local_rank, dist):
         if GraphedShardedEpoch.supported(sh, opt, xl):  # RCCL: the epoch replays as two HIP graphs, collectives inside
             epoch = GraphedShardedEpoch(sh, opt, xl, yl, tl, vl, n_train)
         else:
-            def epoch():
-                sh.train_step(opt, xl, yl, tl, n_train)
-                sh.eval_correct(xl, yl, vl)
+            def epoch():  # eager (gloo rehearsals): the same one-pass epoch, not captured
+                sh.train_eval_step(opt, xl, yl, tl, vl, n_train)
 
     for _ in range(max(args.gcn_warmup, 5)):  # (the graphed epoch captures at its fourth call)
         epoch()

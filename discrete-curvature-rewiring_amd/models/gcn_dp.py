@@ -18,7 +18,7 @@ divided by the global number of training nodes, so the summed gradients equal th
 import torch
 import torch.distributed as dist
 
-from models.gcn import GCN, aggregate, gcn_norm_csr, relu_dropout
+from models.gcn import GCN, aggregate, gcn_norm_csr, relu_dropout, spmm, spmm_pair
 
 
 def block_range(n, world, rank):
@@ -55,6 +55,51 @@ class _GatherRows(torch.autograd.Function):
             dist.all_reduce(g, group=group)
             mine = g[rank * per:(rank + 1) * per]
         return mine[:ctx.rows].contiguous(), None, None, None
+
+
+def _pad_rows(z, per):
+    if z.shape[0] == per:
+        return z
+    pad = torch.zeros((per, z.shape[1]), dtype=z.dtype, device=z.device)
+    pad[:z.shape[0]] = z
+    return pad
+
+
+class _GatherAggregatePair(torch.autograd.Function):
+    """(Â_p·Z_train + b, Â_p·Z_eval + b) from the ranks' row blocks of both operands with ONE all-gather and one sweep of
+    the local rows of Â (``spmm_pair``); only the training operand carries a gradient, so the backward reduce-scatter
+    moves its half only.  See ``GCN.forward_pair``."""
+
+    @staticmethod
+    def forward(ctx, z_train, z_eval, bias, csr, n_total, per, group):
+        world = dist.get_world_size(group)
+        f = z_train.shape[1]
+        ctx.csr, ctx.group, ctx.per, ctx.rows, ctx.has_bias = csr, group, per, z_train.shape[0], bias is not None
+        local = _pad_rows(torch.cat([z_train, z_eval], 1), per).contiguous()
+        full = torch.empty((world * per, 2 * f), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, local, group=group)
+        out = spmm_pair(csr.rowptr, csr.col, csr.val, full[:n_total].contiguous(), csr.n_rows, f, bias=bias)
+        return out[:, :f].contiguous(), out[:, f:].contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_train, grad_eval):
+        csr, group, per = ctx.csr, ctx.group, ctx.per
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        grad_train = grad_train.contiguous()
+        gz = None
+        if ctx.needs_input_grad[0]:
+            gfull = spmm(csr.rowptr_t, csr.col_t, csr.val_t, grad_train, csr.n_cols)
+            g = torch.zeros((world * per, gfull.shape[1]), dtype=gfull.dtype, device=gfull.device)
+            g[:gfull.shape[0]] = gfull
+            if dist.get_backend(group) == 'nccl':
+                mine = torch.empty((per, g.shape[1]), dtype=g.dtype, device=g.device)
+                dist.reduce_scatter_tensor(mine, g, group=group)
+            else:  # gloo (CPU tests) has no reduce_scatter
+                dist.all_reduce(g, group=group)
+                mine = g[rank * per:(rank + 1) * per]
+            gz = mine[:ctx.rows].contiguous()
+        gb = grad_train.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gz, None, gb, None, None, None, None
 
 
 class ShardedGCN(torch.nn.Module):
@@ -100,6 +145,26 @@ class ShardedGCN(torch.nn.Module):
             if i + 1 < len(layers):
                 h = relu_dropout(h, self.gcn.act_fn, self.gcn.dropout)
         return torch.nn.functional.log_softmax(h, dim=1)
+
+    def forward_pair(self, x_local):
+        """(training-mode, evaluation-mode) log-probabilities of this rank's nodes in one pass: one all-gather and one
+        sweep of the local rows of Â per layer for both (``GCN.forward_pair``, data-parallel).  Call in training mode."""
+        layers = list(self.gcn.layers)
+        first = layers[0]
+        if first.propagate_input_first and not x_local.requires_grad:
+            o_tr = first.lin(self.propagated_input_local(x_local), first.bias)
+        else:
+            z = _GatherRows.apply(first.lin(x_local), self.n, self.per, self.group)
+            o_tr = aggregate(z, first.bias, self.csr)
+        o_ev = o_tr.detach()
+        for layer in layers[1:]:
+            h_tr = relu_dropout(o_tr, self.gcn.act_fn, self.gcn.dropout)
+            with torch.no_grad():
+                z_ev = layer.lin(self.gcn.act_fn(o_ev))
+            z_tr = layer.lin(h_tr)
+            o_tr, o_ev = _GatherAggregatePair.apply(z_tr, z_ev, layer.bias, self.csr, self.n, self.per, self.group)
+        log_softmax = torch.nn.functional.log_softmax
+        return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)
 
     def propagated_input_local(self, x_local):
         """Rows of Â·X owned by this rank, computed once per (x_local, graph): all-gather X, one local SpMM."""
@@ -174,6 +239,27 @@ class ShardedGCN(torch.nn.Module):
         optimizer.step()
         return loss.detach()
 
+    def train_eval_step(self, optimizer, x_local, y_local, train_mask_local, val_mask_local, n_train_global):
+        """One training step and, from the same pass, {correct, count} of the validation split for the weights the step
+        STARTED from (the evaluation of the previous epoch: ``LaggedGraphedEpoch`` in experiment/training_loop.py)."""
+        self.train()
+        self.zero_grads()
+        lp_train, lp_eval = self.forward_pair(x_local)
+        idx, y_sel, count = self._selection(train_mask_local, y_local)
+        if count:
+            loss = torch.nn.functional.nll_loss(lp_train.index_select(0, idx), y_sel, reduction='sum')
+        else:
+            loss = lp_train.sum() * 0.0
+        (loss / n_train_global).backward()
+        self.allreduce_grads()
+        optimizer.step()
+        with torch.no_grad():
+            vidx, vy, vcount = self._selection(val_mask_local, y_local)
+            correct = (lp_eval.index_select(0, vidx).argmax(1) == vy).sum() if vcount else lp_eval.new_zeros((), dtype=torch.long)
+            stats = torch.stack([correct.double(), torch.full((), float(vcount), dtype=torch.float64, device=lp_eval.device)])
+            dist.all_reduce(stats, group=self.group)
+        return stats
+
     @torch.no_grad()
     def eval_stats(self, x_local, y_local, mask_local):
         """{correct, count} over all ranks as a 2-element float64 device tensor (no host synchronisation)."""
@@ -200,7 +286,10 @@ class GraphedShardedEpoch:
 
     WARMUP = 3
 
-    def __init__(self, sharded, optimizer, x_local, y_local, train_mask_local, val_mask_local, n_train_global):
+    def __init__(self, sharded, optimizer, x_local, y_local, train_mask_local, val_mask_local, n_train_global, lagged=True):
+        # lagged: ONE graph per epoch (train_eval_step: the accuracy delivered is that of the weights the step started from)
+        self.lagged = lagged
+        self.val_mask = val_mask_local
         self.sh, self.opt = sharded, optimizer
         self.args = (x_local, y_local, train_mask_local, n_train_global)
         self.val = (x_local, y_local, val_mask_local)
@@ -219,6 +308,8 @@ class GraphedShardedEpoch:
 
     def _train(self):
         x, y, m, n_train = self.args
+        if self.lagged:
+            return self.sh.train_eval_step(self.opt, x, y, m, self.val_mask, n_train)
         return self.sh.train_step(self.opt, x, y, m, n_train)
 
     def __call__(self):
@@ -227,17 +318,21 @@ class GraphedShardedEpoch:
         if self.calls <= self.WARMUP:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
-                self._train()
-                stats = self.sh.eval_stats(*self.val)
+                out = self._train()
+                stats = out if self.lagged else self.sh.eval_stats(*self.val)
             cur.wait_stream(self.stream)
             return (stats[0] / stats[1].clamp(min=1)).item()
         if self.train_graph is None:
             self.train_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.train_graph, stream=self.stream):
-                self.loss = self._train()
-            self.eval_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.eval_graph, stream=self.stream):
-                self.stats = self.sh.eval_stats(*self.val)
+                out = self._train()
+            if self.lagged:
+                self.stats = out
+            else:
+                self.eval_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.eval_graph, stream=self.stream):
+                    self.stats = self.sh.eval_stats(*self.val)
         self.train_graph.replay()
-        self.eval_graph.replay()
+        if not self.lagged:
+            self.eval_graph.replay()
         return (self.stats[0] / self.stats[1].clamp(min=1)).item()

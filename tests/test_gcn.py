@@ -198,6 +198,61 @@ def _dp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _dp_pair_worker(rank, world, port, ret):
+    """train_eval_step (one pass for the training step and the evaluation of the weights it starts from) against the
+    single-process model doing evaluate-then-train."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from models import gcn
+    from models.gcn import GCN
+    from models.gcn_dp import ShardedGCN
+    gcn.set_aggregate_backend('torch')
+    data, ds = _toy(n=61, seed=4)
+    torch.manual_seed(7)
+    base = GCN(ds, hidden=[8], dropout=0.0)
+    ref = GCN(ds, hidden=[8], dropout=0.0)
+    ref.load_state_dict(base.state_dict())
+    sh = ShardedGCN(base, data.edge_index, data.num_nodes)
+    xl, yl = sh.shard(data.x), sh.shard(data.y)
+    tl, vl = sh.shard(data.train_mask), sh.shard(data.val_mask)
+    n_train = int(data.train_mask.sum())
+    opt = torch.optim.SGD(base.parameters(), lr=0.1)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    errs = []
+    for _ in range(3):
+        ref.eval()
+        with torch.no_grad():
+            lp = ref(data)
+        acc_ref = (lp[data.val_mask].argmax(1) == data.y[data.val_mask]).float().mean().item()   # of the weights as they stand
+        ref.train()
+        ropt.zero_grad()
+        torch.nn.functional.nll_loss(ref(data)[data.train_mask], data.y[data.train_mask]).backward()
+        ropt.step()
+        stats = sh.train_eval_step(opt, xl, yl, tl, vl, n_train)
+        acc = (stats[0] / stats[1]).item()
+        err_w = max((a - b).abs().max().item() for a, b in zip(base.parameters(), ref.parameters()))
+        errs.append((abs(acc - acc_ref), err_w))
+    sh.train()
+    lp_tr, lp_ev = sh.forward_pair(xl)
+    sh.eval()
+    with torch.no_grad():
+        e_ev = (lp_ev - sh(xl)).abs().max().item()
+    ret[rank] = (max(e[0] for e in errs), max(e[1] for e in errs), e_ev)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_data_parallel_one_pass_epoch_gloo(world):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_pair_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank, (dacc, err_w, e_ev) in ret.items():
+        assert dacc < 1e-6 and err_w < TOL and e_ev < TOL, (rank, dacc, err_w, e_ev)
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_data_parallel_ranks_gloo(world):
     """world 2 and 3 (61 nodes: blocks of 31 + 30 and of 21 + 21 + 19)"""
