@@ -292,6 +292,7 @@ def main():
     ap.add_argument('--gcn-nodes', type=int, default=1000000)
     ap.add_argument('--gcn-epochs', type=int, default=20)
     ap.add_argument('--gcn-warmup', type=int, default=3)
+    ap.add_argument('--gcn-timeout', type=float, default=420.0)
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -408,14 +409,7 @@ def main():
                 'note': 'BASELINE.json configs[2]: S100k, full Balanced Forman pass + SDRF, 500 iterations in one run'}
         run5 = None
     run = G = None  # release the SDRF graph before the GCN leg
-    # the side legs must not cost the headline line: a failure is recorded in their place
-    gcn = None
-    if not args.no_gcn:
-        try:
-            gcn = gcn_bench(args, rank, world, local_rank, dist)
-        except Exception as ex:  # noqa: BLE001
-            gcn = {'error': f'{type(ex).__name__}: {ex}'[:400]}
-
+    out = None
     if rank == 0:
         pass_ms = pass_ms_total / max(pass_count, 1)
         alg_bytes = 0.5 * (bytes0 + bytes1)            # one-sided: what a pass has to read (include/dcr.h)
@@ -488,6 +482,27 @@ def main():
             out['incremental_mode'] = inc
         if cfg2 is not None:
             out['config2_500_iterations'] = cfg2
+    # The side legs must not cost the headline line: a failure is recorded in their place, and a leg that does not come
+    # back (a collective waiting for a rank that died) is cut off by a timer on every rank: rank 0 prints the line it has,
+    # all ranks leave.  (The multi-GPU GCN leg has only ever run on one MI355X in the build environment.)
+    import threading
+
+    def cut_off():
+        if rank == 0 and out is not None:
+            out['gcn'] = {'error': f'GCN leg did not finish within {args.gcn_timeout} s'}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    timer = threading.Timer(args.gcn_timeout, cut_off)
+    timer.daemon = True
+    gcn = None
+    if not args.no_gcn:
+        timer.start()
+        try:
+            gcn = gcn_bench(args, rank, world, local_rank, dist)
+        except Exception as ex:  # noqa: BLE001
+            gcn = {'error': f'{type(ex).__name__}: {ex}'[:400]}
+        timer.cancel()
+    if rank == 0:
         if gcn is not None:
             out['gcn'] = gcn
             if world == 1:
