@@ -902,8 +902,89 @@ int dcr_candidate_at(dcr_graph *g, int64_t index, int32_t *out_i, int32_t *out_j
     return DCR_OK;
 }
 
+// The tail of an iteration in two halves, so that the NEXT iteration's curvature pass can be enqueued behind it without a
+// host round trip in between (dcr_sdrf_tail_at_pass_argmin): enqueue (add, dirty flags, stale arg-max, conditional remove)
+// and finish (read the result block after some later synchronisation).
+struct TailCall {
+    int32_t add_k, add_l;
+    int do_remove;
+    double bound;
+    bool adding, have_amax;
+    int edit_add, edit_rem;
+};
+
+static int tail_prepare(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound, TailCall *tc) {
+    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
+    if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
+    tc->adding = add_k >= 0 || add_k == -2;  // -2: the pair k_pick_candidate left in the result block
+    if (add_k >= 0) {
+        if (add_l < 0 || add_k >= g->n || add_l >= g->n || add_k == add_l) DCR_FAIL(DCR_EINVAL, "bad edge to add");
+        if (add_k > add_l) {
+            int32_t t = add_k;
+            add_k = add_l;
+            add_l = t;
+        }
+    }
+    tc->add_k = add_k;
+    tc->add_l = add_l;
+    tc->do_remove = do_remove;
+    tc->bound = removal_bound;
+    DCR_HIP(hipSetDevice(g->device));
+    g->am_valid = false;
+    tc->have_amax = g->amax_valid;  // computed on this graph before the add: nothing to exclude
+    g->amax_valid = false;
+    // edit numbers for the incremental pass's flags (edge_dirty): the add, then the removal
+    tc->edit_add = g->pending_edits;
+    tc->edit_rem = g->pending_edits + (tc->adding ? 1 : 0);
+    g->pending_edits += (tc->adding ? 1 : 0) + (do_remove ? 1 : 0);
+    return DCR_OK;
+}
+
+static int tail_enqueue(dcr_graph *g, const TailCall &tc, bool first_attempt) {
+    launch_add_edge(g, tc.add_k, tc.add_l);
+    launch_mark_dirty(g, tc.add_k, tc.add_l, tc.edit_add);  // after the append: the new neighbours are flagged too
+    if (tc.do_remove) {
+        if (!(tc.have_amax && first_attempt))
+            DCR_TRY(launch_argext(g, 1, tc.adding ? tc.add_k : -1, tc.adding ? tc.add_l : -1));
+        launch_remove_if_above(g, tc.bound, tc.edit_rem);
+    }
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+// after a synchronisation that brought the result block over: host-side bookkeeping and outputs
+static void tail_finish(dcr_graph *g, const TailCall &tc, int32_t out_removed[2], double *out_max_val, bool max_val_known) {
+    if (tc.adding && g->hres->add_status == 0) {
+        g->n_edges++;
+        g->max_deg_bound++;
+    }
+    int32_t ru = -1, rv = -1;
+    if (tc.do_remove) {
+        ru = g->hres->removed_u;
+        rv = g->hres->removed_v;
+        if (ru >= 0) g->n_edges--;
+        if (out_max_val) *out_max_val = (max_val_known && g->hres->ext_slot >= 0) ? g->hres->ext_val : 0.0;
+    }
+    if (out_removed) {
+        out_removed[0] = ru;
+        out_removed[1] = rv;
+    }
+}
+
 static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
-                          int32_t out_removed[2], double *out_max_val);
+                          int32_t out_removed[2], double *out_max_val) {
+    TailCall tc;
+    DCR_TRY(tail_prepare(g, add_k, add_l, do_remove, removal_bound, &tc));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        DCR_TRY(tail_enqueue(g, tc, attempt == 0));
+        DCR_TRY(sync_result(g));
+        if (g->hres->add_status != 1) break;
+        if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
+        DCR_TRY(relayout(g));
+    }
+    tail_finish(g, tc, out_removed, out_max_val, true);
+    return DCR_OK;
+}
 
 int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int32_t out_added[2],
                      int32_t out_removed[2], double *out_max_val) {
@@ -924,53 +1005,36 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
     return sdrf_tail_impl(g, add_k, add_l, do_remove, removal_bound, out_removed, out_max_val);
 }
 
-static int sdrf_tail_impl(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, double removal_bound,
-                          int32_t out_removed[2], double *out_max_val) {
+// Tail of iteration i and the head of iteration i + 1 in one call with ONE host synchronisation: add the drawn
+// candidate, conditional removal (sdrf_no_cuda.py:51,56-66), then the curvature pass of the next iteration and its first
+// minimum (:24,:27).  The pass is enqueued right behind the edit; the result block carries the tail's outcome and the
+// arg-min over together.  (A row overflow of the add — rare: rows carry slack — is seen only then: the rows are laid out
+// again, the tail replayed and the pass redone.)
+int dcr_sdrf_tail_at_pass_argmin(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int curv_type,
+                                 int incremental, int32_t out_added[2], int32_t out_removed[2], int32_t *out_u, int32_t *out_v,
+                                 double *out_val) {
     if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
-    if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
-    const bool adding = add_k >= 0 || add_k == -2;  // -2: the pair k_pick_candidate left in the result block
-    if (add_k >= 0) {
-        if (add_l < 0 || add_k >= g->n || add_l >= g->n || add_k == add_l) DCR_FAIL(DCR_EINVAL, "bad edge to add");
-        if (add_k > add_l) {
-            int32_t t = add_k;
-            add_k = add_l;
-            add_l = t;
-        }
-    }
+    if (cand_index < 0 || cand_index >= g->imp_n) DCR_FAIL(DCR_EINVAL, "candidate index out of range");
     DCR_HIP(hipSetDevice(g->device));
-    g->am_valid = false;
-    const bool have_amax = g->amax_valid;  // computed on this graph before the add: nothing to exclude
-    g->amax_valid = false;
-    // edit numbers for the incremental pass's flags (edge_dirty): the add, then the removal
-    const int edit_add = g->pending_edits, edit_rem = g->pending_edits + (adding ? 1 : 0);
-    g->pending_edits += (adding ? 1 : 0) + (do_remove ? 1 : 0);
+    hipLaunchKernelGGL(k_pick_candidate, dim3(1), dim3(1), 0, g->stream, g->imp_ci, g->imp_cj, cand_index, g->dres);
+    TailCall tc;
+    DCR_TRY(tail_prepare(g, -2, -2, do_remove, removal_bound, &tc));
     for (int attempt = 0; attempt < 2; ++attempt) {
-        launch_add_edge(g, add_k, add_l);
-        launch_mark_dirty(g, add_k, add_l, edit_add);  // after the append: the new neighbours are flagged too
-        if (do_remove) {
-            if (!(have_amax && attempt == 0)) DCR_TRY(launch_argext(g, 1, adding ? add_k : -1, adding ? add_l : -1));
-            launch_remove_if_above(g, removal_bound, edit_rem);
+        DCR_TRY(tail_enqueue(g, tc, attempt == 0));
+        if (attempt == 0) g->max_deg_bound++;  // the pass below sizes its launches by this upper bound: count the add in
+        const int rc = dcr_curvature_pass_argmin(g, curv_type, incremental, out_u, out_v, out_val);  // synchronises
+        if (attempt == 0) g->max_deg_bound--;  // (tail_finish counts it once the add is known to have happened)
+        if (g->hres->add_status != 1) {
+            DCR_TRY(rc);
+            break;
         }
-        DCR_HIP(hipGetLastError());
-        DCR_TRY(sync_result(g));
-        if (g->hres->add_status != 1) break;
         if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
-        DCR_TRY(relayout(g));
+        DCR_TRY(relayout(g));  // nothing was edited (the removal is skipped when the add overflows): lay out, replay
     }
-    if (adding && g->hres->add_status == 0) {
-        g->n_edges++;
-        g->max_deg_bound++;
-    }
-    int32_t ru = -1, rv = -1;
-    if (do_remove) {
-        ru = g->hres->removed_u;
-        rv = g->hres->removed_v;
-        if (ru >= 0) g->n_edges--;
-        if (out_max_val) *out_max_val = g->hres->ext_slot >= 0 ? g->hres->ext_val : 0.0;
-    }
-    if (out_removed) {
-        out_removed[0] = ru;
-        out_removed[1] = rv;
+    tail_finish(g, tc, out_removed, nullptr, false);
+    if (out_added) {
+        out_added[0] = g->hres->cand_i;
+        out_added[1] = g->hres->cand_j;
     }
     return DCR_OK;
 }

@@ -227,6 +227,18 @@ class DcrGraph:
         rem = None if removed[0] < 0 else (removed[0], removed[1])
         return (added[0], added[1]), rem, mx.value
 
+    def sdrf_tail_at_pass_argmin(self, cand_index, do_remove, removal_bound, curv_type='bfc', incremental=False):
+        """``sdrf_tail_at`` and the next iteration's ``curvature_pass_argmin`` with one host synchronisation; returns
+        (added pair, removed pair or None, (u, v, value) of the next first minimum)."""
+        added = (ctypes.c_int32 * 2)(-1, -1)
+        removed = (ctypes.c_int32 * 2)(-1, -1)
+        u, v, val = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        check(lib().dcr_sdrf_tail_at_pass_argmin(self._h, int(cand_index), int(bool(do_remove)), float(removal_bound),
+                                                 curv_code(curv_type), int(bool(incremental)), added, removed,
+                                                 ctypes.byref(u), ctypes.byref(v), ctypes.byref(val)))
+        rem = None if removed[0] < 0 else (removed[0], removed[1])
+        return (added[0], added[1]), rem, (u.value, v.value, val.value)
+
     # ---- measurement hooks ------------------------------------------------------------
     def profile_reset(self):
         check(lib().dcr_profile_reset(self._h))

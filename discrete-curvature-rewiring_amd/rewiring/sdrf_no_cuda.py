@@ -120,16 +120,24 @@ class SdrfRun:
         self.tau = tau
         self.trace = trace
         self.G = DcrGraph.from_data(data, device=device)
+        self._next_argmin = None  # (x, y) of the pass already run for the coming iteration (see step)
 
-    def step(self):
+    def step(self, more=True):
+        """One iteration.  ``more``: another iteration will follow (the default; ``sdrf_no_cuda`` passes False for the last
+        one): the coming iteration's curvature pass and first minimum are then enqueued right behind this iteration's edit
+        and share its host synchronisation (``dcr_sdrf_tail_at_pass_argmin``): two host round trips per iteration, not three."""
         G, curv_type, tau, trace = self.G, self.curv_type, self.tau, self.trace
         want_trace = trace is not None
         can_add = True
         # Full curvature pass, then the edge with the lowest curvature (first minimum in G.edges order).
-        try:
-            x, y, _ = G.curvature_pass_argmin(curv_type, incremental=self.incremental)
-        except KeyError:
-            raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
+        if self._next_argmin is not None:
+            x, y = self._next_argmin
+            self._next_argmin = None
+        else:
+            try:
+                x, y, _ = G.curvature_pass_argmin(curv_type, incremental=self.incremental)
+            except KeyError:
+                raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
         rec = {'argmin': [x, y]} if want_trace else None
 
         k = l = idx = None
@@ -163,7 +171,12 @@ class SdrfRun:
 
         # add candidate idx = (k, l), looked up on the device; then the stale arg-max (excluding the new edge) is
         # removed if above the bound
-        if n_cand:
+        if n_cand and more:
+            # (an edge was added, so the loop goes on whatever the removal step does: the next pass can follow at once)
+            (k, l), removed, nxt = G.sdrf_tail_at_pass_argmin(idx, self.remove_edges, self.removal_bound, curv_type,
+                                                             incremental=self.incremental)
+            self._next_argmin = nxt[:2]
+        elif n_cand:
             (k, l), removed, _ = G.sdrf_tail_at(idx, self.remove_edges, self.removal_bound)
         else:
             removed, _ = G.sdrf_tail(None, self.remove_edges, self.removal_bound)
@@ -192,7 +205,7 @@ def sdrf_no_cuda(data, curv_type, loops, remove_edges, removal_bound, tau, trace
     """
     run = SdrfRun(data, curv_type, remove_edges, removal_bound, tau, trace=trace, device=device,
                   incremental=incremental)
-    for _ in range(loops):
-        if not run.step():
+    for i in range(loops):
+        if not run.step(more=i + 1 < loops):
             break
     return run.result()

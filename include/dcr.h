@@ -128,6 +128,12 @@ int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double rem
  * Forman passes only); -1 before the first pass.  All three produce the same bits. */
 int dcr_pass_engine(dcr_graph *g, int *out);
 
+/* dcr_sdrf_tail_at followed by dcr_curvature_pass_argmin of the NEXT iteration (sdrf_no_cuda.py:51,56-66 then :24,:27) with
+ * one host synchronisation instead of two: the pass is enqueued right behind the edit.  Same results as the two calls. */
+int dcr_sdrf_tail_at_pass_argmin(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int curv_type,
+                                 int incremental, int32_t out_added[2], int32_t out_removed[2], int32_t *out_u, int32_t *out_v,
+                                 double *out_val);
+
 /* Timing hooks for bench.py: accumulated device time (HIP events on the
  * handle's stream) of the curvature-pass kernels since the last reset. */
 int dcr_profile_reset(dcr_graph *g);

@@ -739,3 +739,28 @@ def test_stale_buffer_stays_edge_keyed_after_removal(dcr, oracle):
         for want_max, pick in ((True, int(np.argmax(vals))), (False, int(np.argmin(vals)))):
             u, v, val = G.argext(want_max)
             assert (u, v, val) == (int(ru[pick]), int(rv[pick]), float(vals[pick]))
+
+
+@pytest.mark.parametrize('incremental', [False, True])
+def test_fused_tail_and_next_pass_including_row_overflow(dcr, oracle, incremental):
+    """dcr_sdrf_tail_at_pass_argmin (tail of iteration i + pass and first minimum of iteration i + 1, one host sync)
+    against the oracle's loop, on a run long enough to exhaust the slack of the rows it keeps adding to: a row overflow
+    of the add is only seen after the pass has run, and the call has to lay out again, replay the tail and redo the pass."""
+    from dcr import synthetic
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import SdrfRun
+    import torch
+    ei, n = synthetic.powerlaw_graph(250, 3, seed=8)
+    loops = 140                                     # min slack is 8 slots per row: the hubs' rows overflow several times
+    np.random.seed(3)
+    want = oracle.sdrf(ei, n, 'bfc', loops, True, 0.6, 30.0, nthreads=4)
+    np.random.seed(3)
+    run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.6, 30.0, incremental=incremental)
+    fused = 0
+    for i in range(loops):
+        before = run._next_argmin
+        if not run.step(more=i + 1 < loops):
+            break
+        fused += run._next_argmin is not None
+    assert fused >= loops - 5                       # nearly every iteration took the one-sync path
+    assert np.array_equal(run.result().edge_index.numpy(), want)
