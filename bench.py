@@ -292,7 +292,7 @@ def main():
     ap.add_argument('--gcn-nodes', type=int, default=1000000)
     ap.add_argument('--gcn-epochs', type=int, default=20)
     ap.add_argument('--gcn-warmup', type=int, default=3)
-    ap.add_argument('--gcn-timeout', type=float, default=420.0)
+    ap.add_argument('--gcn-timeout', type=float, default=300.0)
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
