@@ -64,6 +64,7 @@ def choice_index(p):
 
 
 _cdf_scratch = np.empty(0, dtype=np.float64)
+_exp_scratch = np.empty(0, dtype=np.float64)
 
 
 def draw_index(improvements, tau):
@@ -72,16 +73,22 @@ def draw_index(improvements, tau):
     is part of the bit-exact contract); the division and the sequential cumsum run fused in the library's host helper
     ``dcr_host_cdf_from_exp`` with numpy's operations in numpy's order; validation, the one uniform and the search follow
     ``RandomState.choice``.  Pinned against numpy in tests/test_host_cpu.py."""
-    global _cdf_scratch
+    global _cdf_scratch, _exp_scratch
     import ctypes
     from dcr import _lib
-    exp_a = np.exp(np.asarray(improvements, dtype=np.float64) * tau)
+    a = np.asarray(improvements, dtype=np.float64)
+    n = a.shape[0]
+    if _exp_scratch.shape[0] < n:
+        _exp_scratch = np.empty(n + n // 4 + 64, dtype=np.float64)
+        _cdf_scratch = np.empty(n + n // 4 + 64, dtype=np.float64)
+    # the same numpy operations as utils/softmax.py:9 (multiply, exp, pairwise sum), written into scratch that is kept
+    # between iterations: two fresh 1.4 MB temporaries per draw cost more in page faults than the arithmetic
+    exp_a = _exp_scratch[:n]
+    np.multiply(a, tau, out=exp_a)
+    np.exp(exp_a, out=exp_a)
     s = exp_a.sum()
     if not np.isfinite(s) or s == 0.0:
         return choice_index(exp_a / s)  # overflow / all-zero: numpy's own NaN pattern and error (utils/softmax.py:9-10)
-    n = exp_a.shape[0]
-    if _cdf_scratch.shape[0] < n:
-        _cdf_scratch = np.empty(n + n // 4 + 64, dtype=np.float64)
     cdf = _cdf_scratch
     total = ctypes.c_double()
     _lib.check(_lib.lib().dcr_host_cdf_from_exp(exp_a.ctypes.data_as(_lib._f64p), n, float(s),
