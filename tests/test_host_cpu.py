@@ -200,3 +200,42 @@ def test_vectorised_cdf_is_numpy_cumsum():
     np.random.seed(3)
     from rewiring.sdrf_no_cuda import draw_index
     assert draw_index(a, 163.0) == want
+
+
+def test_ordered_graph_follows_networkx():
+    """dcr/ordered_graph.py is the host-side graph of the dense SDRF loop (rewiring/sdrf_cuda_bfc.py:31-33,44-54,69,85,93
+    use an nx.Graph / nx.DiGraph there): same neighbour / successor / predecessor order as networkx under random edits,
+    DiGraph.to_undirected() order, and the edge order of PyG's from_networkx (relabel, then to_directed().edges)."""
+    import networkx as nx
+    from dcr.ordered_graph import OrderedDiGraph, digraph_from_edge_index
+    rng = np.random.Generator(np.random.PCG64(12))
+    for trial in range(30):
+        n = int(rng.integers(3, 25))
+        m = int(rng.integers(0, 80))
+        ei = rng.integers(0, n, size=(2, m))
+        ei = ei[:, ei[0] != ei[1]]
+        D = nx.DiGraph()
+        D.add_nodes_from(range(n))
+        D.add_edges_from(zip(ei[0].tolist(), ei[1].tolist()))
+        O = digraph_from_edge_index(ei, n)
+        assert isinstance(O, OrderedDiGraph)
+        U, OU = D.to_undirected(), O.to_undirected()
+        for _ in range(40):  # the same random edits on all four
+            a, b = (int(t) for t in rng.integers(0, n, size=2))
+            if a == b:
+                continue
+            if rng.random() < 0.6:
+                D.add_edge(a, b); O.add_edge(a, b); U.add_edge(a, b); OU.add_edge(a, b)
+            else:
+                if D.has_edge(a, b):
+                    D.remove_edge(a, b); O.remove_edge(a, b)
+                if U.has_edge(a, b):
+                    U.remove_edge(a, b); OU.remove_edge(a, b)
+            assert D.has_edge(a, b) == O.has_edge(a, b) and U.has_edge(a, b) == OU.has_edge(a, b)
+        for v in range(n):
+            assert list(D.successors(v)) == O.successors(v) and list(D.predecessors(v)) == O.predecessors(v)
+            assert list(U.neighbors(v)) == OU.neighbors(v)
+        assert [list(e) for e in D.edges] == O.to_edge_index().T.tolist()
+        H = nx.convert_node_labels_to_integers(U).to_directed()      # what from_networkx lists for an undirected graph
+        assert [list(e) for e in H.edges] == OU.to_edge_index().T.tolist()
+        assert OU.number_of_edges() == U.number_of_edges()
