@@ -813,7 +813,15 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));  // first minimum in G.edges order, same host sync
     DCR_TRY(sync_result(g));
     if (g->last_engine == 0) {
-        for (int c = 0; c < 3; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
+        for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
+        if (g->hres->h2_status == 2 && g->hres->misc[0] == 0 && h2_grow_pools(g)) {
+            // the pools of its triangle step were too small (dense neighbourhoods): run it again with what it asked for
+            DCR_TRY(launch_curvature_pass(g, curv_type, false));
+            if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
+            if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));
+            DCR_TRY(sync_result(g));
+            for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
+        }
         if (g->hres->h2_status != 0 && g->hres->misc[0] == 0) {
             // a table of the two-hop pass filled up (keys of a split node hashed unevenly) or a unit list overflowed:
             // nothing it wrote is kept, the node-centric kernels redo the whole pass

@@ -1,7 +1,6 @@
-// Two-hop curvature pass of libdcr_hip.so: an ALTERNATIVE implementation of a full Balanced Forman pass (DCR_PASS=h2).
-// Same bits as the node-centric kernels, 9x fewer adjacency entries streamed, but slower on MI355X as built (3.0 ms against
-// 1.98 ms on the bench graph, DESIGN.md §4.1b has the counters): the map of a node grows with its 2-HOP neighbourhood, so
-// LDS admits 8 waves per CU where the node-centric kernels run 24, and every visit pays an LDS atomic.
+// Two-hop curvature pass of libdcr_hip.so: full Balanced Forman passes from row u of A·A instead of per-edge
+// neighbourhood streaming (round 3: rebuilt around Bloom bitmaps; the round-2 hash-map version of this file was slower
+// than the node-centric kernels and is gone).
 //
 // Replaces compute_curvature_graph(G, 'bfc') at rewiring/sdrf_no_cuda.py:24, i.e. E calls of bfc_naive.bfc_edge
 // (curvature/bfc_naive.py:7-40), with the same integers and the same float64 closing expression as the other two
@@ -13,37 +12,33 @@
 //     c(w) = |N(w) ∩ N(u)|  -  1  -  |N(w) ∩ N(u) ∩ N(v)|
 //
 // (v itself is a common neighbour of w and u; the last term are the triangle partners of {u,v} adjacent to w).  The first
-// term M_u(w) does not depend on v: it is row u of A·A.  So instead of streaming, per edge, the rows of all of DY against
-// N(u) (1.08 G adjacency entries per pass on the 100k-node bench graph), every node u
-//   A. builds M_u once as a hash map in LDS by streaming the rows of its neighbours (Σ_u Σ_{k∈N(u)} d_k = Σ d² entries:
-//      0.117 G on that graph), members of N(u) flagged;
-//   B. streams the same rows once more: for neighbour v and w in row v, a flagged w is a triangle (T, bfc_naive.py:25),
-//      w = u gives the slot of the reverse entry, anything else contributes M_u(w) - 1.  96 % of the 2-hop entries have
-//      M_u(w) = 1 and contribute nothing;
-//   C. only for edges with T > 0 AND some positive count: the triangle partners' rows are streamed against a small
-//      per-edge table of the positive candidates to subtract the third term (5 % of the edges).
+// term M_u(w) does not depend on v: it is row u of A·A, the number of times w is met when the rows of the neighbours of
+// u are read once.  The node-centric kernels find it by intersecting N(w) with N(u) for every (edge, w): 1.05 G adjacency
+// entries per pass on the 100k-node bench graph; here every node reads its neighbours' rows: Σ d² = 0.117 G entries.
+//
+// 97.6 % of the 2-hop keys of a node occur once (c = 0: nothing to count) and only 5 % of the entries belong to keys
+// that repeat, so exact state is kept for those only:
+//   A. first sweep of the neighbours' rows: test-and-set one bit per entry in a Bloom bitmap B1 (LDS, ~16 bits per
+//      entry); an entry that finds its bit set is a repeat (or, rarely, a collision) and sets the bit of a second,
+//      smaller bitmap B2.  No table, no queue, one LDS atomic per entry;
+//   B. second sweep: an entry whose B2 bit is set — every occurrence of every repeated key, first ones included, plus a
+//      few collisions — goes to an exact table EX of (key → rows that hold it); the members of N(u) are seeded into
+//      B1, B2 and EX beforehand, flagged, so a hit on one of them is a triangle (bfc_naive.py:25);
+//   C. with EX complete, c(w) for the occurrence of w in row i is |rows(w) \ {i} \ rows adjacent to row i|.
+// Nodes of at most 64 neighbours (97 % of the bench graph's nodes, 85 % of its entries) are taken by one wave each:
+// rows(w) is a 64-bit mask, the rows adjacent to row i (the triangle partners of edge {u, v_i}) another, the B-sweep
+// leaves a short list of candidate occurrences and step C is one pass over that list — no third sweep, no edge-set
+// probes.  Larger nodes are taken by a workgroup with a counting table (key → occurrences) and a third sweep for the
+// per-row statistics; the triangle term is subtracted per edge with triangles AND positive counts by probing an edge
+// hash set in device memory; hubs whose repeated keys exceed the table are split by key hash into partitions (units of
+// their own, results met by integer atomics).  A node whose tables fill up (dense neighbourhoods: sizes are typical,
+// not worst case) is put on a retry list and redone by the largest class with worst-case partitions; only if that fails
+// too does the whole pass fall back to the node-centric kernels.
 // Each node writes, per adjacency slot u->v, {|sq| on v's side, max count, T, reverse slot}; a final kernel joins the two
 // records of an edge and evaluates the float64 closing expression in the reference's order (bfc_naive.py:31-40).
-//
-// The map.  96 % of the 2-hop entries occur once, and what is rare per lane (a second occurrence, a collision) happens in
-// nearly every 64-lane instruction, so the common case must be branch-free and the rest must not run at 1/64 occupancy:
-//   * a direct-mapped FRONT table takes the first key that hashes to a slot with ONE compare-and-swap (phase A) and
-//     answers "seen exactly once, not a neighbour" with ONE read (phase B);
-//   * everything else — later occurrences, keys whose front slot is taken by another key, the flagged members of N(u) —
-//     lives in an OVERFLOW table (4-slot buckets, 15-bit counters, as in dcr_bfc_nc.hip); M_u(w) = its counter, plus
-//     one if w also holds its front slot;
-//   * lanes that need the overflow table do not walk it on the spot: they queue (key, row) in LDS and the wave works the
-//     queue off 64 items at a time.
-// (First cut, bucket table only, every lane walking it in line: 720 M vector instructions per pass, as many as the
-// node-centric kernels execute for nine times the entries.)
-//
-// Nodes are grouped by K = deg + 1 + Σ neighbour degrees (an upper bound of the keys of M_u): up to 1,280 keys a wave
-// owns a node and private tables (2,048 front slots); up to 5,120 (10,240) a workgroup of 4 (8) waves shares tables of
-// 8,192 (16,384) front slots; beyond that the KEYS of a node are split by a second hash into P partitions, each a unit
-// of its own (every unit streams all rows but keeps only its share; results meet in the record through integer
-// atomics), which also spreads a hub over P workgroups.  Units are laid out heaviest first.  Bounds: HBM / L2 row
-// streaming (2 x 4 B x Σ d² per pass) and LDS atomics; no MFMA (integer set counting).
+// Bounds: HBM / L2 row streaming (2-3 x 4 B x Σ d² per pass) and LDS atomics; no MFMA (integer set counting).
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -52,27 +47,25 @@
 namespace dcr {
 
 constexpr unsigned H2_EMPTY = 0xFFFFFFFFu;
-constexpr int H2_MAXDEG = 8190;  // flagged neighbours live in every partition's table; 15-bit counters
-constexpr int H2_CLASSES = 3;
-constexpr int H2_WB = 8;         // weight buckets per class (units are laid out heaviest bucket first)
+constexpr unsigned H2_NBR = 0x80000000u;  // on a key of the small classes' EX: member of N(u) (node ids stay below 2^30)
+constexpr int H2_MAXDEG = 4094;           // flagged neighbours live in every partition's table (5,500 keys in the largest class)
+constexpr int H2_CLASSES = 5;             // 0-2: one wave per node (<= 64 neighbours), 3-4: one workgroup per unit
+constexpr int H2_WB = 4;                  // weight buckets per class (units are laid out heaviest bucket first)
+constexpr int H2_SMALL_DEG = 64;
 #ifndef H2_Q
-#define H2_Q 2                   // 16-byte pieces per lane in flight in the streaming loops
+#define H2_Q 2                            // 16-byte pieces per lane in flight in the streaming loops
 #endif
+constexpr int H2_QCAP = 128;              // queued exact-path items per wave (worked off when fewer than 64 slots are left)
+__host__ __device__ constexpr int h2_wpb(int c) { return c == 2 ? 2 : 4; }  // waves (= nodes in flight) per workgroup of the wave classes
 
-__host__ __device__ constexpr int h2_capd(int c) { return c == 0 ? 2048 : c == 1 ? 8192 : 16384; }  // front slots
-__host__ __device__ constexpr int h2_cap(int c) { return h2_capd(c) / 2; }                            // overflow slots
-__host__ __device__ constexpr int h2_maxkeys(int c) { return c == 0 ? 1280 : c == 1 ? 5120 : 10240; }
-#ifndef H2_W1
-#define H2_W1 4
-#endif
-#ifndef H2_W2
-#define H2_W2 8
-#endif
-__host__ __device__ constexpr int h2_waves(int c) { return c == 0 ? 1 : c == 1 ? H2_W1 : H2_W2; }
-__host__ __device__ constexpr int h2_ecap(int c) { return c == 0 ? 128 : 256; }
-constexpr int H2_WPB0 = 2;  // waves (= nodes in flight) per workgroup of the wave class
-constexpr unsigned H2_FLAG = 0x80000000u;  // on a front entry: the key also has an overflow entry (node ids stay below 2^30)
-constexpr int H2_QCAP = 192;               // queued overflow items per wave (worked off when fewer than 64 slots are left)
+// per class: log2 of the bits of B1; largest weight W = Σ neighbour degrees (the entries of one sweep)
+__host__ __device__ constexpr int h2_l1(int c) { return c == 0 ? 14 : c == 1 ? 15 : c == 2 ? 16 : c == 3 ? 16 : 17; }
+__host__ __device__ constexpr int h2_maxw(int c) { return c == 0 ? 1024 : c == 1 ? 2048 : c == 2 ? 4096 : c == 3 ? 8192 : INT_MAX; }
+__host__ __device__ constexpr int h2_exs(int c) { return c == 0 ? 128 : c == 1 ? 256 : c == 2 ? 512 : c == 3 ? 4096 : 8192; }
+__host__ __device__ constexpr int h2_clcap(int c) { return c == 0 ? 192 : c == 1 ? 384 : 768; }
+__host__ __device__ constexpr int h2_waves(int c) { return c == 3 ? 4 : 16; }
+__host__ __device__ constexpr int h2_keycap(int c) { return c == 3 ? 2800 : 5500; }  // keys a block table takes (4-slot buckets)
+constexpr int H2_WALK = 32;                // longest probe sequence of the exact tables
 
 __device__ inline void h2_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -85,108 +78,46 @@ __device__ inline void h2_sync() {
     else __syncthreads();
 }
 
-// ---- the table: open addressing over 4-slot buckets (one 16-byte LDS read settles almost every access) -------------
-template <int CAP>
-__device__ inline unsigned h2_bucket(unsigned key) {
-    constexpr int BITS = __builtin_ctz(CAP / 4);
-    unsigned prod;  // Fibonacci hashing of the low 24 bits with the full-rate 24-bit multiply (see dcr_bfc_nc.hip)
+// ---- hashing: Fibonacci hashing of the low 24 bits with the full-rate 24-bit multiply (see dcr_bfc_nc.hip) ----------
+__device__ inline unsigned h2_mul24(unsigned key) {
+    unsigned prod;
     asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(prod) : "v"(key));
-    return (prod >> (24 - BITS)) & ((1u << BITS) - 1);
+    return prod;
 }
-template <int CAPD>
-__device__ inline unsigned h2_dslot(unsigned key) {  // front slot: another 24-bit multiplier than the bucket hash
-    constexpr int BITS = __builtin_ctz(CAPD);
+__device__ inline unsigned h2_mul24b(unsigned key) {  // an independent multiplier for the exact tables
     unsigned prod;
     asm("v_mul_u32_u24 %0, 0x85ebcb, %1" : "=v"(prod) : "v"(key));
-    return (prod >> (24 - BITS)) & ((1u << BITS) - 1);
+    return prod;
 }
-// which partition of a split node a key belongs to: a hash independent of the bucket hash
+template <int L1>
+__device__ inline unsigned h2_bit(unsigned key) {
+    return (h2_mul24(key) >> (24 - L1)) & ((1u << L1) - 1u);
+}
+// which partition of a split node a key belongs to: a hash independent of the others (NOT a multiplier whose leading digits
+// equal those of h2_mul24b: the keys of one partition then share the leading bits of their bucket index and fill 1 / nparts
+// of the table)
 __device__ inline int h2_part(unsigned key, int nparts) {
-    return (int)((((key * 0x85EBCA6Bu) >> 16) * (unsigned)nparts) >> 16);
-}
-__device__ inline int h2_match(const uint4 e, unsigned w) {
-    return e.x == w ? 0 : e.y == w ? 1 : e.z == w ? 2 : e.w == w ? 3 : -1;
+    return (int)((((key * 0xC2B2AE35u) >> 16) * (unsigned)nparts) >> 16);
 }
 
-// slot of w, continuing from its (already read) home bucket; -1: absent
-template <int CAP>
-__device__ inline int h2_find_from(const unsigned *key, unsigned b, uint4 e, unsigned w) {
-    const uint4 *tb = reinterpret_cast<const uint4 *>(key);
-    for (int walk = 0; walk < CAP / 4; ++walk) {
-        const int pos = h2_match(e, w);
-        if (pos >= 0) return (int)(b * 4) + pos;
-        if (e.w == H2_EMPTY) return -1;  // slots of a bucket fill in order: a free last slot means the key never spilled
-        b = (b + 1) & (CAP / 4 - 1);
-        e = tb[b];
+// ---- the bitmaps ------------------------------------------------------------------------------------------------------
+// B1: one bit per 2-hop entry (seen); B2 (a quarter of the bits, indexed by the same hash): seen again
+__device__ inline void h2_mark(unsigned *b1, unsigned *b2, unsigned b) {  // sweep A: one returning LDS atomic per entry
+    const unsigned m = 1u << (b & 31u);
+    const unsigned old = atomicOr(&b1[b >> 5], m);
+    if (old & m) {
+        const unsigned c = b >> 2;
+        atomicOr(&b2[c >> 5], 1u << (c & 31u));
     }
-    return -1;
 }
-template <int CAP>
-__device__ inline int h2_find(const unsigned *key, unsigned w) {
-    const unsigned b = h2_bucket<CAP>(w);
-    return h2_find_from<CAP>(key, b, reinterpret_cast<const uint4 *>(key)[b], w);
+__device__ inline void h2_seed(unsigned *b1, unsigned *b2, unsigned b) {  // a member of N(u): every occurrence is exact
+    atomicOr(&b1[b >> 5], 1u << (b & 31u));
+    const unsigned c = b >> 2;
+    atomicOr(&b2[c >> 5], 1u << (c & 31u));
 }
-
-// slot of w, inserting it if absent; -1: the table is full (reported by the caller, never loops forever).
-// A lane claims the first free slot it saw; slots never empty again, so filled slots always form a prefix of a bucket and a
-// key is never stored twice (a racing lane with the same key meets it on its way up).
-template <int CAP>
-__device__ inline int h2_insert_from(unsigned *key, unsigned b, uint4 e, unsigned w) {
-    const uint4 *tb = reinterpret_cast<const uint4 *>(key);
-    for (int walk = 0; walk < CAP / 4; ++walk) {
-        const int pos = h2_match(e, w);
-        if (pos >= 0) return (int)(b * 4) + pos;
-        int ep = e.x == H2_EMPTY ? 0 : e.y == H2_EMPTY ? 1 : e.z == H2_EMPTY ? 2 : e.w == H2_EMPTY ? 3 : 4;
-        for (; ep < 4; ++ep) {
-            const unsigned old = atomicCAS(&key[b * 4 + ep], H2_EMPTY, w);
-            if (old == H2_EMPTY || old == w) return (int)(b * 4) + ep;
-        }
-        b = (b + 1) & (CAP / 4 - 1);
-        e = tb[b];
-    }
-    return -1;
-}
-template <int CAP>
-__device__ inline int h2_insert(unsigned *key, unsigned w) {
-    const unsigned b = h2_bucket<CAP>(w);
-    return h2_insert_from<CAP>(key, b, reinterpret_cast<const uint4 *>(key)[b], w);
-}
-
-// per-slot state, two 16-bit halves per word: bit 15 = member of N(u), bits 0-14 = occurrences in the neighbours' rows
-__device__ inline void h2_cnt_flag(unsigned *cnt, int s) { atomicOr(&cnt[s >> 1], 0x8000u << ((s & 1) * 16)); }
-__device__ inline void h2_cnt_add(unsigned *cnt, int s) { atomicAdd(&cnt[s >> 1], 1u << ((s & 1) * 16)); }
-__device__ inline unsigned h2_cnt_get(const unsigned *cnt, int s) { return (cnt[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu; }
-
-template <int ECAP>
-struct H2Scratch {
-    int2 desc[64];   // {start, length} of the rows of the current batch
-    int poff[66];    // exclusive prefix of their piece counts; poff[64] = total
-    int rowT[64], rowPos[64], rowMx[64], rowRev[64];  // phase B accumulators per row of the batch
-    unsigned ekey[ECAP];  // step C: candidate ids and counts ...
-    unsigned eval[ECAP];  // ... triangle partners and corrections
-    unsigned qw[H2_QCAP];       // queued overflow work: key ...
-    unsigned char qr[H2_QCAP];  // ... and row of the batch
-};
-
-// the three LDS arrays of a unit
-struct H2Tab {
-    unsigned *front;  // [CAPD] direct-mapped: key, | H2_FLAG once the key has an overflow entry
-    unsigned *key;    // [CAP]  overflow keys, 4-slot buckets
-    unsigned *cnt;    // [CAP / 2] their state, 16 bits each
-};
-
-// M_u(w) and whether w is a member of N(u); {0, false} for a key this unit does not hold
-template <int CAPD, int CAP>
-__device__ inline int h2_query(const H2Tab t, unsigned w, bool &nbr) {
-    nbr = false;
-    const unsigned e = t.front[h2_dslot<CAPD>(w)];
-    if (e == w) return 1;
-    if (e == H2_EMPTY) return 0;  // every key that was ever touched found its front slot taken, or took it
-    const int s = h2_find<CAP>(t.key, w);
-    if (s < 0) return 0;
-    const unsigned c16 = h2_cnt_get(t.cnt, s);
-    nbr = (c16 & 0x8000u) != 0u;
-    return (int)(c16 & 0x7FFFu) + ((e & ~H2_FLAG) == w ? 1 : 0);
+__device__ inline bool h2_again(const unsigned *b2, unsigned b) {
+    const unsigned c = b >> 2;
+    return (b2[c >> 5] >> (c & 31u)) & 1u;
 }
 
 __device__ inline unsigned h2_piece_mask(int a, int lo, int hi) {
@@ -212,15 +143,386 @@ __device__ inline int h2_piece_row(const int *poff, int poff_lane, int j, int j_
     return r;
 }
 
-template <int ECAP>
-__device__ inline unsigned h2_ehash(unsigned key) {
-    constexpr int BITS = __builtin_ctz(ECAP);
-    return (key * 0x9E3779B1u) >> (32 - BITS);
+// The rows of a batch (descriptors and piece prefix sums in LDS) as one flat list of aligned 16-byte pieces shared evenly
+// by the 64 lanes.  body(piece, valid-entry mask, row, slot of the piece's first entry) is called by ALL lanes, converged
+// (lanes without a piece pass mask 0, row -1).
+template <typename Body>
+__device__ inline void h2_for_pieces(const int32_t *col, const int2 *desc, const int *poff, int poff_lane, int P, Body body) {
+    const int lane = threadIdx.x & 63;
+    for (int j0 = 0; j0 < P; j0 += 64 * H2_Q) {
+        int4 w[H2_Q];
+        int rr[H2_Q], aa[H2_Q];
+        unsigned vm[H2_Q];
+#pragma unroll
+        for (int q = 0; q < H2_Q; ++q) {
+            const int j = j0 + 64 * q + lane;
+            rr[q] = -1;
+            aa[q] = 0;
+            vm[q] = 0u;
+            w[q] = make_int4(0, 0, 0, 0);
+            const int jf = j0 + 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+            if (jf >= P) continue;  // uniform
+            const int r = h2_piece_row(poff, poff_lane, j < P ? j : jl, jf, jl);
+            if (j < P) {
+                const int2 d = desc[r];
+                const int a = (d.x & ~3) + 4 * (j - poff[r]);
+                w[q] = load_piece(col, a);
+                rr[q] = r;
+                aa[q] = a;
+                vm[q] = h2_piece_mask(a, d.x, d.x + d.y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < H2_Q; ++q) {
+            if (j0 + 64 * q >= P) continue;  // uniform
+            body(w[q], vm[q], rr[q], aa[q]);
+        }
+    }
+}
+
+// piece counts of the rows held by the lanes -> exclusive prefix in `excl`, total returned
+__device__ inline int h2_prefix(int np, int &excl) {
+    const int lane = threadIdx.x & 63;
+    int incl = np;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    excl = incl - np;
+    return __shfl(incl, 63);
+}
+
+// ---- the retry list: nodes whose tables filled up in their class -------------------------------------------------------
+// partitions of a node in the largest class: `safe` sizes them for the worst case (every key repeats: W / 2 keys, a
+// quarter of slack for the partition hash), else for what power-law graphs need (W / 4)
+__host__ __device__ inline int h2_parts_for(int d, int64_t W, bool safe) {
+    const int64_t room = h2_keycap(4) - d;  // the flagged neighbours live in every partition's table
+    if (room <= 0) return 65536;
+    const int64_t keys = safe ? W / 2 + W / 8 + 64 : W / 3 + 64;
+    int64_t p = (keys + room - 1) / room;
+    // ... and B1 wants 8 (16) bits per entry of the partition, or its collisions fill B2 and the table with keys that occur once
+    const int64_t per = safe ? (1 << h2_l1(4)) / 16 : (1 << h2_l1(4)) / 8;
+    if (p < (W + per - 1) / per) p = (W + per - 1) / per;
+    if (p < 1) p = 1;
+    if (p > 65535) p = 65536;
+    return (int)p;
+}
+struct H2Retry {
+    int2 *units;
+    int64_t cap;
+    int32_t *weight;  // bit 31: the node is on the list already (several partitions of a split node may fail)
+    DevResult *res;
+};
+__device__ inline void h2_retry_push(const H2Retry rt, int u, int d, int cls) {  // one lane calls this
+    atomicAdd(&rt.res->h2_failed[cls], 1);
+    const unsigned old = atomicOr(reinterpret_cast<unsigned *>(&rt.weight[u]), 0x80000000u);
+    if (old & 0x80000000u) return;
+    const int nparts = h2_parts_for(d, (int64_t)old, true);
+    const int first = atomicAdd(&rt.res->h2_retry, nparts);
+    if (nparts > 65535 || first < 0 || (int64_t)first + nparts > rt.cap) {
+        rt.res->h2_status = 1;  // not even the retry list takes it: the pass is redone by the node-centric kernels
+        return;
+    }
+    for (int j = 0; j < nparts; ++j) rt.units[first + j] = make_int2(u, (nparts << 16) | j);
+}
+
+// =====================================================================================================================
+// wave classes: a node of at most 64 neighbours, by one wave
+// =====================================================================================================================
+template <int L1, int EXS, int CLCAP>
+struct __attribute__((aligned(16))) H2Small {
+    unsigned b1[(1 << L1) / 32];
+    unsigned b2[(1 << (L1 - 2)) / 32];
+    unsigned exkey[EXS];           // candidate key, or a member of N(u) | H2_NBR
+    unsigned exlo[EXS], exhi[EXS];  // candidate: the rows that hold it (64-bit mask); member of N(u): its position in row u
+    unsigned adjlo[64], adjhi[64];  // per row i: the rows adjacent to it = triangle partners of edge {u, v_i}
+    int2 desc[64];
+    int poff[66];
+    int pos[64], mx[64], rev[64];
+    unsigned qk[H2_QCAP];
+    unsigned short cls[CLCAP];     // candidate occurrences: EX slot ...
+    unsigned char qr[H2_QCAP];
+    unsigned char clr[CLCAP];      // ... and row
+};
+
+template <int EXS>
+__device__ inline unsigned h2s_home(unsigned key) {
+    constexpr int BITS = __builtin_ctz(EXS);
+    return (h2_mul24b(key) >> (24 - BITS)) & (unsigned)(EXS - 1);
+}
+// slot of w (a plain id), inserting it if absent; -1: table full
+template <int EXS>
+__device__ inline int h2s_find_or_insert(unsigned *exkey, unsigned w) {
+    unsigned s = h2s_home<EXS>(w);
+    for (int walk = 0; walk < EXS; ++walk) {
+        const unsigned e = exkey[s];
+        if ((e & ~H2_NBR) == w && e != H2_EMPTY) return (int)s;
+        if (e == H2_EMPTY) {
+            const unsigned old = atomicCAS(&exkey[s], H2_EMPTY, w);
+            if (old == H2_EMPTY || (old & ~H2_NBR) == w) return (int)s;
+        }
+        s = (s + 1) & (unsigned)(EXS - 1);
+    }
+    return -1;
+}
+template <int EXS>
+__device__ inline int h2s_insert_nbr(unsigned *exkey, unsigned k) {  // the members of N(u) are distinct
+    unsigned s = h2s_home<EXS>(k);
+    for (int walk = 0; walk < EXS; ++walk) {
+        if (atomicCAS(&exkey[s], H2_EMPTY, k | H2_NBR) == H2_EMPTY) return (int)s;
+        s = (s + 1) & (unsigned)(EXS - 1);
+    }
+    return -1;
+}
+
+template <int L1, int EXS, int CLCAP>
+__device__ inline void h2s_node(const View &g, int u, int2 ru, H2Small<L1, EXS, CLCAP> *s, uint4 *rec, const H2Retry rt) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    {   // clear: bitmaps and row masks to zero, keys to "free"
+        uint4 *z = reinterpret_cast<uint4 *>(s->b1);
+        constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;  // b1 and b2 are adjacent
+        for (int i = lane; i < NZ; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *k4 = reinterpret_cast<uint4 *>(s->exkey);
+        for (int i = lane; i < EXS / 4; i += 64) k4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
+        uint4 *m4 = reinterpret_cast<uint4 *>(s->exlo);  // exlo and exhi are adjacent
+        for (int i = lane; i < 2 * EXS / 4; i += 64) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+        s->adjlo[lane] = 0u;
+        s->adjhi[lane] = 0u;
+        s->pos[lane] = 0;
+        s->mx[lane] = 0;
+        s->rev[lane] = -1;
+    }
+    h2_wave_sync();
+    // the members of N(u): seeded into both bitmaps and the exact table (flagged, with their position in row u)
+    int k = -1;
+    int2 rk = make_int2(0, 0);
+    bool full = false;
+    if (lane < ru.y) {
+        k = g.col[ru.x + lane];
+        if (k >= 0 && k < g.n && k != u) {
+            rk = g.rowinfo[k];
+            if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
+            const int slot = h2s_insert_nbr<EXS>(s->exkey, (unsigned)k);
+            if (slot < 0) full = true;
+            else s->exlo[slot] = (unsigned)lane;
+            h2_seed(s->b1, s->b2, h2_bit<L1>((unsigned)k));
+        } else {
+            k = -1;
+        }
+    }
+    const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
+    int poff_lane;
+    const int P = h2_prefix(np, poff_lane);
+    s->desc[lane] = rk;
+    s->poff[lane] = poff_lane;
+    if (lane == 0) s->poff[64] = P;
+    h2_wave_sync();
+    // sweep A
+    h2_for_pieces(g.col, s->desc, s->poff, poff_lane, P, [&](const int4 w, unsigned vm, int, int) {
+        const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (((vm >> jj) & 1u) && kk[jj] != (unsigned)u) h2_mark(s->b1, s->b2, h2_bit<L1>(kk[jj]));
+    });
+    h2_wave_sync();
+    // sweep B: entries whose B2 bit is set are queued and settled against the exact table 64 at a time
+    int qn = 0, cln = 0;  // uniform
+    auto drain = [&]() {
+        h2_wave_sync();
+        for (int base = 0; base < qn; base += 64) {
+            const int i = base + lane;
+            bool cand = false;
+            int slot = -1, row = 0;
+            if (i < qn) {
+                const unsigned w = s->qk[i];
+                row = s->qr[i];
+                slot = h2s_find_or_insert<EXS>(s->exkey, w);
+                if (slot < 0) {
+                    full = true;
+                } else if (s->exkey[slot] & H2_NBR) {  // a member of N(u) in row `row`: rows `row` and exlo[slot] are adjacent
+                    const unsigned x = s->exlo[slot];
+                    atomicOr(x < 32u ? &s->adjlo[row] : &s->adjhi[row], 1u << (x & 31u));
+                } else {
+                    atomicOr(row < 32 ? &s->exlo[slot] : &s->exhi[slot], 1u << (row & 31));
+                    cand = true;
+                }
+            }
+            const unsigned long long m = __ballot(cand);
+            if (cand) {
+                const int idx = cln + __popcll(m & below);
+                if (idx < CLCAP) {
+                    s->cls[idx] = (unsigned short)slot;
+                    s->clr[idx] = (unsigned char)row;
+                } else {
+                    full = true;
+                }
+            }
+            cln += __popcll(m);
+        }
+        h2_wave_sync();
+        qn = 0;
+    };
+    h2_for_pieces(g.col, s->desc, s->poff, poff_lane, P, [&](const int4 w, unsigned vm, int r, int a) {
+        const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
+        unsigned f = 0u;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (!((vm >> jj) & 1u)) continue;
+            if (kk[jj] == (unsigned)u) s->rev[r] = a + jj;  // where u sits in row r: the slot of the reverse entry
+            else if (h2_again(s->b2, h2_bit<L1>(kk[jj]))) f |= 1u << jj;
+        }
+        if (__ballot(f != 0u) == 0ull) return;  // uniform
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const bool p = (f >> jj) & 1u;
+            const unsigned long long m = __ballot(p);
+            if (m == 0ull) continue;  // uniform
+            if (qn > H2_QCAP - 64) drain();
+            if (p) {
+                const int idx = qn + __popcll(m & below);
+                s->qk[idx] = kk[jj];
+                s->qr[idx] = (unsigned char)r;
+            }
+            qn += __popcll(m);
+        }
+    });
+    if (qn > 0) drain();
+    h2_wave_sync();
+    if (__ballot(full) != 0ull) {  // a table or the list filled up: nothing is published, the node is redone elsewhere
+        if (lane == 0) h2_retry_push(rt, u, ru.y, EXS == 128 ? 0 : EXS == 256 ? 1 : 2);
+        h2_wave_sync();
+        return;
+    }
+    // step C: c(w) for the occurrence of w in row i = the rows that hold w, less row i, less the rows adjacent to row i
+    const int cl_n = cln < CLCAP ? cln : CLCAP;
+    for (int e = lane; e < cl_n; e += 64) {
+        const int slot = s->cls[e], row = s->clr[e];
+        const int c = __popc(s->exlo[slot] & ~s->adjlo[row]) + __popc(s->exhi[slot] & ~s->adjhi[row]) - 1;
+        if (c > 0) {
+            atomicAdd(&s->pos[row], 1);
+            atomicMax(&s->mx[row], c);
+        }
+    }
+    h2_wave_sync();
+    if (k >= 0) {
+        const int rev = s->rev[lane];
+        if (rev < 0 || rev >= g.cap_total) {
+            row_ok(g, make_int2(-1, rev), 33, u, k);  // adjacency not symmetric: report, never publish
+        } else {
+            const int T = __popc(s->adjlo[lane]) + __popc(s->adjhi[lane]);
+            rec[(int64_t)ru.x + lane] = make_uint4((unsigned)s->pos[lane], (unsigned)s->mx[lane], (unsigned)T, (unsigned)rev);
+        }
+    }
+    h2_wave_sync();  // the arrays are rewritten by the next node
+}
+
+// units are taken grid-stride from a list laid out heaviest first: every wave gets a similar mix
+template <int L1, int EXS, int CLCAP, int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_h2_small(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+                                                       uint4 *rec, H2Retry rt) {
+    __shared__ H2Small<L1, EXS, CLCAP> sm[WPB];
+    const int wid = threadIdx.x >> 6;
+    const int total = *count;
+    if (total < 0 || total > unit_cap) {
+        row_ok(g, make_int2(-1, total), 34, 0, 0);
+        return;
+    }
+    for (int64_t it = (int64_t)blockIdx.x * WPB + wid; it < total; it += (int64_t)gridDim.x * WPB) {
+        const int u = units[it].x;
+        if (u < 0 || u >= g.n) {
+            row_ok(g, make_int2(-1, u), 35, (int)it, total);
+            continue;
+        }
+        const int2 ru = g.rowinfo[u];
+        if (!row_ok(g, ru, 36, u, (int)it) || ru.y <= 0 || ru.y > H2_SMALL_DEG) continue;
+        h2s_node<L1, EXS, CLCAP>(g, u, ru, &sm[wid], rec, rt);
+    }
+}
+
+// =====================================================================================================================
+// block classes: a unit (node, key partition) by a workgroup; counting table, third sweep, edge-set probes
+// =====================================================================================================================
+// ---- the table: open addressing over 4-slot buckets (one 16-byte LDS read settles almost every access) -------------
+template <int CAP>
+__device__ inline unsigned h2_bucket(unsigned key) {
+    constexpr int BITS = __builtin_ctz(CAP / 4);
+    return (h2_mul24b(key) >> (24 - BITS)) & ((1u << BITS) - 1);
+}
+__device__ inline int h2_match(const uint4 e, unsigned w) {
+    return e.x == w ? 0 : e.y == w ? 1 : e.z == w ? 2 : e.w == w ? 3 : -1;
+}
+// slot of w; -1: absent
+template <int CAP>
+__device__ inline int h2_find(const unsigned *key, unsigned w) {
+    const uint4 *tb = reinterpret_cast<const uint4 *>(key);
+    unsigned b = h2_bucket<CAP>(w);
+    for (int walk = 0; walk < H2_WALK; ++walk) {  // (insertion never walks further than this)
+        const uint4 e = tb[b];
+        const int pos = h2_match(e, w);
+        if (pos >= 0) return (int)(b * 4) + pos;
+        if (e.w == H2_EMPTY) return -1;  // slots of a bucket fill in order: a free last slot means the key never spilled
+        b = (b + 1) & (CAP / 4 - 1);
+    }
+    return -1;
+}
+// slot of w, inserting it if absent; -1: the table is full (reported by the caller, never loops forever).
+// A lane claims the first free slot it saw; slots never empty again, so filled slots always form a prefix of a bucket and a
+// key is never stored twice (a racing lane with the same key meets it on its way up).
+template <int CAP>
+__device__ inline int h2_insert(unsigned *key, unsigned w) {
+    const uint4 *tb = reinterpret_cast<const uint4 *>(key);
+    unsigned b = h2_bucket<CAP>(w);
+    for (int walk = 0; walk < H2_WALK; ++walk) {  // (a longer walk: too full, treated as full)
+        const uint4 e = tb[b];
+        const int pos = h2_match(e, w);
+        if (pos >= 0) return (int)(b * 4) + pos;
+        int ep = e.x == H2_EMPTY ? 0 : e.y == H2_EMPTY ? 1 : e.z == H2_EMPTY ? 2 : e.w == H2_EMPTY ? 3 : 4;
+        for (; ep < 4; ++ep) {
+            const unsigned old = atomicCAS(&key[b * 4 + ep], H2_EMPTY, w);
+            if (old == H2_EMPTY || old == w) return (int)(b * 4) + ep;
+        }
+        b = (b + 1) & (CAP / 4 - 1);
+    }
+    return -1;
+}
+// per-slot state, two 16-bit halves per word: bit 15 = member of N(u), bits 0-14 = occurrences in the neighbours' rows
+__device__ inline void h2_cnt_flag(unsigned *cnt, int s) { atomicOr(&cnt[s >> 1], 0x8000u << ((s & 1) * 16)); }
+__device__ inline void h2_cnt_add(unsigned *cnt, int s) { atomicAdd(&cnt[s >> 1], 1u << ((s & 1) * 16)); }
+__device__ inline unsigned h2_cnt_get(const unsigned *cnt, int s) { return (cnt[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu; }
+
+struct H2Scratch {
+    int2 desc[64];   // {start, length} of the rows of the current batch
+    int poff[66];    // exclusive prefix of their piece counts; poff[64] = total
+    int rowT[64], rowPos[64], rowMx[64], rowRev[64];  // third-sweep accumulators per row of the batch
+    unsigned qw[H2_QCAP];       // queued exact-path work: key ...
+    unsigned char qr[H2_QCAP];  // ... and row of the batch
+};
+
+// the LDS arrays of a unit
+struct H2Tab {
+    unsigned *b1, *b2;
+    unsigned *key;  // [EXS] 4-slot buckets
+    unsigned *cnt;  // [EXS / 2] their state, 16 bits each
+    int *full;      // set when the table fills up
+};
+
+// M_u(w) and whether w is a member of N(u); {1, false} for a key this unit keeps no exact state for
+template <int L1, int EXS>
+__device__ inline int h2_query(const H2Tab t, unsigned w, bool &nbr) {
+    nbr = false;
+    if (!h2_again(t.b2, h2_bit<L1>(w))) return 1;
+    const int s = h2_find<EXS>(t.key, w);
+    if (s < 0) return 1;
+    const unsigned c16 = h2_cnt_get(t.cnt, s);
+    nbr = (c16 & 0x8000u) != 0u;
+    return (int)(c16 & 0x7FFFu);
 }
 
 // ---- the edge set: every undirected edge as one 64-bit key in an open-addressing table in device memory -------------------
-// Rebuilt by every pass (one CAS per edge).  Step C asks it "is w adjacent to t?" a few times per edge with triangles,
-// where the first cut streamed the whole (hub) row of every triangle partner: 2.3 ms of a 4.7 ms pass on the bench graph.
+// Rebuilt by every pass (one CAS per edge).  The triangle step asks it "is w adjacent to t?" a few times per edge with
+// triangles.
 constexpr unsigned long long H2_ESET_EMPTY = ~0ull;
 __device__ inline unsigned long long h2_edge_key(int a, int b) {
     return a < b ? ((unsigned long long)(unsigned)a << 32) | (unsigned)b : ((unsigned long long)(unsigned)b << 32) | (unsigned)a;
@@ -231,7 +533,12 @@ __device__ inline unsigned long long h2_eset_slot(unsigned long long key, int bi
 struct H2EdgeSet {
     unsigned long long *tab;
     int bits;
+    unsigned *bloom;  // one bit per edge in a bitmap small enough for an XCD's L2: most probes end there
+    int bloom_bits;
 };
+__device__ inline unsigned h2_bloom_bit(unsigned long long key, int bits) {
+    return (unsigned)((key * 0xD6E8FEB86659FD93ull) >> (64 - bits));
+}
 __device__ inline bool h2_eset_has(const H2EdgeSet es, int a, int b) {
     const unsigned long long key = h2_edge_key(a, b), mask = (1ull << es.bits) - 1ull;
     unsigned long long h = h2_eset_slot(key, es.bits);
@@ -253,6 +560,8 @@ __global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int
     const int v = g.col[s];
     if (v <= u || v >= g.n) return;
     const unsigned long long key = h2_edge_key(u, v), mask = (1ull << es.bits) - 1ull;
+    const unsigned bb = h2_bloom_bit(key, es.bloom_bits);
+    atomicOr(&es.bloom[bb >> 5], 1u << (bb & 31u));
     unsigned long long h = h2_eset_slot(key, es.bits);
     for (unsigned long long walk = 0; walk <= mask; ++walk) {
         const unsigned long long old = atomicCAS(&es.tab[h], H2_ESET_EMPTY, key);
@@ -262,100 +571,164 @@ __global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int
     *status = 1;
 }
 
-// ---- step C: one edge {u,v} with triangles and positive counts, by one wave ------------------------------------------
-// Returns {|{w : c(w) > 0}|, max c(w)} over the w of row v that live in this unit's table, c(w) = M_u(w) - 1 - |N(w) ∩ Tset|.
-// One sweep of row v lists the candidates (w outside N(u) with M_u(w) >= 2) and the triangle partners (flagged w); every
-// (candidate, partner) pair is then one probe of the edge set.  Lists longer than LCAP are taken LCAP at a time.
-template <int CAPD, int CAP, int ECAP>
-__device__ inline int2 h2_edge_with_triangles(const View &g, const H2EdgeSet es, int u, int2 rv, const H2Tab t,
-                                              H2Scratch<ECAP> *sc, int32_t *status) {
-    constexpr int LCAP = ECAP / 2;  // candidates: ekey[0..LCAP) ids, ekey[LCAP..) counts; partners: eval[0..LCAP); corrections: eval[LCAP..)
-    const int lane = threadIdx.x & 63;
-    const int32_t *rowv = g.col + rv.x;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int pos = 0, mx = 0;
-    int ncand_total = 0, npart_total = 0;
-    for (int cbase = 0, first = 1; first || cbase < ncand_total; cbase += LCAP, first = 0) {
-        for (int pbase = 0, pfirst = 1; pfirst || pbase < npart_total; pbase += LCAP, pfirst = 0) {
-            // sweep row v: candidates number cbase.. and partners number pbase.. go to the lists
-            int nc = 0, np = 0;  // running totals (uniform)
-            for (int base = 0; base < rv.y; base += 64) {
-                const int i = base + lane;
-                const int w = i < rv.y ? rowv[i] : -1;
-                bool isC = false, isT = false;
-                int M = 0;
-                if (w >= 0 && w != u) {
-                    M = h2_query<CAPD, CAP>(t, (unsigned)w, isT);
-                    isC = !isT && M >= 2;
-                }
-                const unsigned long long mC = __ballot(isC), mT = __ballot(isT);
-                const int ic = nc + __popcll(mC & below) - cbase, it = np + __popcll(mT & below) - pbase;
-                if (isC && ic >= 0 && ic < LCAP) {
-                    sc->ekey[ic] = (unsigned)w;
-                    sc->ekey[LCAP + ic] = (unsigned)(M - 1);
-                    if (pbase == 0) sc->eval[LCAP + ic] = 0u;  // corrections accumulate over the partner rounds
-                }
-                if (isT && it >= 0 && it < LCAP) sc->eval[it] = (unsigned)w;
-                nc += __popcll(mC);
-                np += __popcll(mT);
-            }
-            ncand_total = nc;
-            npart_total = np;
-            h2_wave_sync();
-            const int ncl = nc - cbase < LCAP ? nc - cbase : LCAP, npl = np - pbase < LCAP ? np - pbase : LCAP;
-            const int pairs = (ncl > 0 && npl > 0) ? ncl * npl : 0;
-            for (int p = lane; p < pairs; p += 64) {
-                const int ci = p / npl, tj = p - ci * npl;
-                if (h2_eset_has(es, (int)sc->ekey[ci], (int)sc->eval[tj])) atomicAdd(&sc->eval[LCAP + ci], 1u);
-            }
-            h2_wave_sync();
-        }
-        const int ncl = ncand_total - cbase < LCAP ? ncand_total - cbase : LCAP;
-        for (int ci = lane; ci < ncl; ci += 64) {
-            const int c = (int)sc->ekey[LCAP + ci] - (int)sc->eval[LCAP + ci];
-            if (c > 0) {
-                ++pos;
-                mx = c > mx ? c : mx;
-            }
-        }
-        h2_wave_sync();
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        pos += __shfl_xor(pos, off);
-        const int o = __shfl_xor(mx, off);
-        mx = o > mx ? o : mx;
-    }
-    (void)status;
-    return make_int2(pos, mx);
+// ---- triangle step ------------------------------------------------------------------------------------------------------
+// An edge {u,v} with triangles AND candidates (w in row v, outside N(u), M_u(w) >= 2): c(w) = M_u(w) - 1 - |N(w) ∩ Tset|,
+// Tset = N(u) ∩ N(v).  Every (candidate, partner) pair is one probe of the edge set, and nearly all the pairs (98 % on the
+// bench graph: 13.5 M) belong to a few thousand hub-to-hub edges with hundreds of candidates and partners each, up to
+// 57 k pairs for one edge.  Probed on the spot by the wave that owns the row, they were 1.2 ms of a 2.6 ms pass (one
+// dependent device-memory read per lane and round, the heavy rows of one hub in the same workgroup).  So the units only
+// LIST the work — per such edge a task {record slot, candidates (w, M - 1), partners} in device-memory pools — and one
+// dense kernel over all candidates of all tasks (k_h2_triangles) probes and publishes, spread over the whole chip.
+struct H2Tasks {
+    uint4 *task;   // {record slot, first partner, partners, node | 0x80000000 when listed by the retry launch}
+    int4 *cand;    // {w, M_u(w) - 1, task, unused}
+    int32_t *part;
+    int64_t task_cap, cand_cap, part_cap;
+    DevResult *res;
+    const int32_t *weight;  // bit 31: the node went to the retry list (what its first attempt listed is void)
+    unsigned retry_flag;    // 0x80000000 in the retry launch
+};
+// Pool space is handed out in chunks per wave (a reservation per edge on three shared counters cost more than the whole
+// step: same-address atomics serialise); what a wave leaves of a candidate chunk is marked void.  All members are uniform.
+constexpr int H2_CHUNK_C = 256, H2_CHUNK_P = 128, H2_CHUNK_T = 16;
+struct H2Alloc {
+    int c_cur = 0, c_end = 0, p_cur = 0, p_end = 0, t_cur = 0, t_end = 0;
+};
+__device__ inline int h2_pool_grab(int32_t *counter, int n) {  // all lanes call this
+    int v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(counter, n);
+    return __shfl(v, 0);
+}
+__device__ inline void h2_void_candidates(const H2Tasks tk, int from, int to) {
+    for (int64_t i = (int64_t)from + (threadIdx.x & 63); i < to && i < tk.cand_cap; i += 64) tk.cand[i] = make_int4(0, 0, -1, 0);
 }
 
-// ---- phases A and B: the rows of the neighbours of u, in batches of 64 rows per wave --------------------------------
-// the queued overflow work of one wave (see the file comment): n is uniform and lives in a register
-template <int CAPD, int CAP, int ECAP, int PHASE>
-__device__ inline void h2_drain(const H2Tab t, H2Scratch<ECAP> *sc, int &n, int32_t *status) {
+// nt tasks, nc candidates and np partners, each contiguous (all lanes call this; false: the pools are too small)
+__device__ inline bool h2_pool_reserve(const H2Tasks tk, H2Alloc &al, int nt, int nc, int np, int &t0, int &c0, int &p0) {
+    if (al.t_end - al.t_cur < nt) {
+        const int n = nt > H2_CHUNK_T ? nt : H2_CHUNK_T;
+        al.t_cur = h2_pool_grab(&tk.res->h2_ntask, n);
+        al.t_end = al.t_cur + n;
+    }
+    if (al.c_end - al.c_cur < nc) {
+        h2_void_candidates(tk, al.c_cur, al.c_end);
+        const int n = nc > H2_CHUNK_C ? nc : H2_CHUNK_C;
+        al.c_cur = h2_pool_grab(&tk.res->h2_ncand, n);
+        al.c_end = al.c_cur + n;
+    }
+    if (al.p_end - al.p_cur < np) {
+        const int n = np > H2_CHUNK_P ? np : H2_CHUNK_P;
+        al.p_cur = h2_pool_grab(&tk.res->h2_npart, n);
+        al.p_end = al.p_cur + n;
+    }
+    t0 = al.t_cur;
+    c0 = al.c_cur;
+    p0 = al.p_cur;
+    al.t_cur += nt;
+    al.c_cur += nc;
+    al.p_cur += np;
+    if (t0 < 0 || (int64_t)t0 + nt > tk.task_cap || c0 < 0 || (int64_t)c0 + nc > tk.cand_cap || p0 < 0 || (int64_t)p0 + np > tk.part_cap) {
+        // the pools are too small (or the 31-bit counters wrapped): the counters keep counting, the host grows the pools
+        // to what they say and runs the pass again
+        if ((threadIdx.x & 63) == 0) {
+            if (c0 < 0 || p0 < 0 || t0 < 0) tk.res->h2_status = 1;
+            else atomicCAS(&tk.res->h2_status, 0, 2);  // (a table failure elsewhere, 1, stays)
+        }
+        return false;
+    }
+    return true;
+}
+
+// one wave lists the edge to row v (record slot `slot`): ncand candidates and npart partners, as counted by the third sweep
+template <int L1, int EXS>
+__device__ inline void h2_emit_task(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 rv, int64_t slot, int ncand,
+                                    int npart, const H2Tab t) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int ti, c0, p0;
+    if (!h2_pool_reserve(tk, al, 1, ncand, npart, ti, c0, p0)) return;
+    if (lane == 0) tk.task[ti] = make_uint4((unsigned)slot, (unsigned)p0, (unsigned)npart, (unsigned)u | tk.retry_flag);
+    const int32_t *rowv = g.col + rv.x;
+    int nc = 0, np = 0;  // running totals (uniform)
+    for (int base = 0; base < rv.y; base += 64) {
+        const int i = base + lane;
+        const int w = i < rv.y ? rowv[i] : -1;
+        bool isC = false, isT = false;
+        int M = 0;
+        if (w >= 0 && w != u) {
+            M = h2_query<L1, EXS>(t, (unsigned)w, isT);
+            isC = !isT && M >= 2;
+        }
+        const unsigned long long mC = __ballot(isC), mT = __ballot(isT);
+        const int ic = nc + __popcll(mC & below), it = np + __popcll(mT & below);
+        if (isC && ic < ncand) tk.cand[c0 + ic] = make_int4(w, M - 1, ti, 0);
+        if (isT && it < npart) tk.part[p0 + it] = w;
+        nc += __popcll(mC);
+        np += __popcll(mT);
+    }
+    if (lane == 0 && (nc != ncand || np != npart)) row_ok(g, make_int2(-1, nc), 43, ncand, np);  // cannot happen
+}
+
+// The same for up to 64 edges at once, a LANE per edge (rows of at most H2_SHORT_ROW entries: most of a hub's rows; a
+// wave per edge is ~4 us of dependent latency for a handful of entries).  `mine`: this lane has an edge to list.
+constexpr int H2_SHORT_ROW = 32;
+template <int L1, int EXS>
+__device__ inline void h2_emit_short(const View &g, const H2Tasks tk, H2Alloc &al, int u, bool mine, int2 rv, int64_t slot,
+                                     int ncand, int npart, const H2Tab t) {
+    int ec, ep, et;
+    const int C = h2_prefix(mine ? ncand : 0, ec), Pn = h2_prefix(mine ? npart : 0, ep), Tn = h2_prefix(mine ? 1 : 0, et);
+    int t0, c0, p0;
+    if (!h2_pool_reserve(tk, al, Tn, C, Pn, t0, c0, p0)) return;
+    if (!mine) return;
+    const int ti = t0 + et;
+    int ci = c0 + ec, pi = p0 + ep;
+    const int cend = ci + ncand, pend = pi + npart;
+    tk.task[ti] = make_uint4((unsigned)slot, (unsigned)pi, (unsigned)npart, (unsigned)u | tk.retry_flag);
+    for (int q0 = 0; q0 < rv.y; q0 += 8) {  // (eight loads in flight: a lane walks its row alone)
+        int ww[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ww[q] = q0 + q < rv.y ? g.col[rv.x + q0 + q] : -1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int w = ww[q];
+            if (w < 0 || w == u) continue;
+            bool isT;
+            const int M = h2_query<L1, EXS>(t, (unsigned)w, isT);
+            if (isT) {
+                if (pi < pend) tk.part[pi] = w;
+                ++pi;
+            } else if (M >= 2) {
+                if (ci < cend) tk.cand[ci] = make_int4(w, M - 1, ti, 0);
+                ++ci;
+            }
+        }
+    }
+    if (ci != cend || pi != pend) row_ok(g, make_int2(-1, ci - cend), 43, ncand, pi - pend);  // cannot happen
+}
+
+// ---- the three sweeps: the rows of the neighbours of u, in batches of 64 rows per wave -----------------------------------
+// the queued exact-path work of one wave: n is uniform and lives in a register
+template <int L1, int EXS, int PHASE>
+__device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n) {
     const int lane = threadIdx.x & 63;
     h2_wave_sync();
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         if (i >= n) continue;
         const unsigned w = sc->qw[i];
-        const unsigned ds = h2_dslot<CAPD>(w);
-        const unsigned e = t.front[ds];
-        const bool in_front = (e & ~H2_FLAG) == w;
-        if (PHASE == 0) {
-            if (in_front && !(e & H2_FLAG)) atomicOr(&t.front[ds], H2_FLAG);  // a second occurrence of the slot's own key
-            const int s = h2_insert<CAP>(t.key, w);
-            if (s < 0) *status = 1;
+        if (PHASE == 1) {
+            const int s = h2_insert<EXS>(t.key, w);
+            if (s < 0) *t.full = 1;
             else h2_cnt_add(t.cnt, s);
         } else {
-            const int s = h2_find<CAP>(t.key, w);
+            const int s = h2_find<EXS>(t.key, w);
             if (s >= 0) {
                 const int r = sc->qr[i];
                 const unsigned c16 = h2_cnt_get(t.cnt, s);
                 if (c16 & 0x8000u) {
                     atomicAdd(&sc->rowT[r], 1);
                 } else {
-                    const int c = (int)(c16 & 0x7FFFu) + (in_front ? 1 : 0) - 1;
+                    const int c = (int)(c16 & 0x7FFFu) - 1;
                     if (c > 0) {
                         atomicAdd(&sc->rowPos[r], 1);
                         atomicMax(&sc->rowMx[r], c);
@@ -370,13 +743,14 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch<ECAP> *sc, int &n, int3
 
 // Wave `wid` of NW takes the rows i = wid, wid + NW, ... of row u (strided: a hub's heaviest rows, adjacent at the
 // front of its row, spread over the waves); lane l of the batch starting at `base` stands for row base + l * NW + wid.
-template <int CAPD, int CAP, int NW, int ECAP, bool PARTS, int PHASE>
-__device__ inline void h2_stream(const View &g, const H2EdgeSet es, int u, int2 ru, int part, int nparts, const H2Tab t,
-                                 H2Scratch<ECAP> *sc, uint4 *rec, int32_t *status) {
+// PHASE 0: bitmaps; 1: occurrences of the repeated keys; 2: per-row statistics, triangle step, records.
+template <int L1, int EXS, int NW, bool PARTS, int PHASE>
+__device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
+                                 const H2Tab t, H2Scratch *sc, uint4 *rec) {
     const int lane = threadIdx.x & 63;
-    const int wid = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
+    const int wid = (int)(threadIdx.x >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
-    int qn = 0;  // queued overflow items (uniform)
+    int qn = 0;  // queued items (uniform)
     for (int base = 0; base < ru.y; base += 64 * NW) {
         const int i = base + lane * NW + wid;
         int k = -1;
@@ -391,106 +765,80 @@ __device__ inline void h2_stream(const View &g, const H2EdgeSet es, int u, int2 
             }
         }
         const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
-        int incl = np;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int tt = __shfl_up(incl, off);
-            if (lane >= off) incl += tt;
-        }
-        const int P = __shfl(incl, 63);
+        int poff_lane;
+        const int P = h2_prefix(np, poff_lane);
         if (P == 0) continue;  // uniform: no row in this wave's share of the batch
-        const int poff_lane = incl - np;
         sc->desc[lane] = rk;
         sc->poff[lane] = poff_lane;
         if (lane == 0) sc->poff[64] = P;
-        if (PHASE == 1) {
+        if (PHASE == 2) {
             sc->rowT[lane] = 0;
             sc->rowPos[lane] = 0;
             sc->rowMx[lane] = 0;
             sc->rowRev[lane] = -1;
         }
         h2_wave_sync();
-        for (int j0 = 0; j0 < P; j0 += 64 * H2_Q) {
-            int4 w[H2_Q];
-            int rr[H2_Q], aa[H2_Q];
+        h2_for_pieces(g.col, sc->desc, sc->poff, poff_lane, P, [&](const int4 w, unsigned vm, int r, int a) {
+            const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
+            unsigned f = 0u;
 #pragma unroll
-            for (int q = 0; q < H2_Q; ++q) {
-                const int j = j0 + 64 * q + lane;
-                rr[q] = -1;
-                aa[q] = 0;
-                w[q] = make_int4(0, 0, 0, 0);
-                const int jf = j0 + 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
-                if (jf >= P) continue;  // uniform
-                const int r = h2_piece_row(sc->poff, poff_lane, j < P ? j : jl, jf, jl);
-                if (j < P) {
-                    const int2 d = sc->desc[r];
-                    const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
-                    w[q] = load_piece(g.col, a);
-                    rr[q] = r;
-                    aa[q] = a;
+            for (int jj = 0; jj < 4; ++jj) {
+                if (!((vm >> jj) & 1u)) continue;
+                if (kk[jj] == (unsigned)u) {
+                    if (PHASE == 2) sc->rowRev[r] = a + jj;
+                    continue;
                 }
+                // (third sweep: no partition test — a key of another partition is simply not in the table, and the flagged
+                //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole)
+                if (PARTS && PHASE != 2 && h2_part(kk[jj], nparts) != part) continue;
+                const unsigned b = h2_bit<L1>(kk[jj]);
+                if (PHASE == 0) h2_mark(t.b1, t.b2, b);
+                else if (h2_again(t.b2, b)) f |= 1u << jj;
             }
+            if (PHASE == 0) return;
+            if (__ballot(f != 0u) == 0ull) return;  // uniform
 #pragma unroll
-            for (int q = 0; q < H2_Q; ++q) {
-                if (j0 + 64 * q >= P) continue;  // uniform
-                unsigned vm = 0u;
-                if (rr[q] >= 0) {
-                    const int2 d = sc->desc[rr[q]];
-                    vm = h2_piece_mask(aa[q], d.x, d.x + d.y);
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool p = (f >> jj) & 1u;
+                const unsigned long long m = __ballot(p);
+                if (m == 0ull) continue;  // uniform
+                if (qn > H2_QCAP - 64) h2_drain<L1, EXS, PHASE>(t, sc, qn);
+                if (p) {
+                    const int idx = qn + __popcll(m & below);
+                    sc->qw[idx] = kk[jj];
+                    if (PHASE == 2) sc->qr[idx] = (unsigned char)r;
                 }
-                const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
-                bool slow[4];
-                // the common case, branch-free: one compare-and-swap (A) or one read (B) on the front table per entry
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const bool in = (vm >> jj) & 1u;
-                    bool take = in && kk[jj] != (unsigned)u && kk[jj] < (unsigned)g.n;
-                    if (PHASE == 0 && PARTS) take = take && h2_part(kk[jj], nparts) == part;
-                    if (PHASE == 1 && in && kk[jj] == (unsigned)u) sc->rowRev[rr[q]] = aa[q] + jj;
-                    slow[jj] = false;
-                    if (take) {
-                        unsigned *fs = &t.front[h2_dslot<CAPD>(kk[jj])];
-                        if (PHASE == 0) {
-                            slow[jj] = atomicCAS(fs, H2_EMPTY, kk[jj]) != H2_EMPTY;
-                        } else {
-                            const unsigned e = *fs;
-                            slow[jj] = e != kk[jj] && e != H2_EMPTY;
-                        }
-                    }
-                }
-                // whatever needs the overflow table is queued
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const unsigned long long m = __ballot(slow[jj]);
-                    if (m == 0) continue;  // uniform
-                    if (qn > H2_QCAP - 64) h2_drain<CAPD, CAP, ECAP, PHASE>(t, sc, qn, status);
-                    if (slow[jj]) {
-                        const int idx = qn + __popcll(m & below);
-                        sc->qw[idx] = kk[jj];
-                        if (PHASE == 1) sc->qr[idx] = (unsigned char)rr[q];
-                    }
-                    qn += __popcll(m);
-                }
+                qn += __popcll(m);
             }
-        }
-        if (PHASE == 1) h2_drain<CAPD, CAP, ECAP, PHASE>(t, sc, qn, status);  // the row totals are read next
-        h2_wave_sync();
-        if (PHASE == 1) {
+        });
+        if (PHASE == 2) {
+            h2_drain<L1, EXS, PHASE>(t, sc, qn);  // the row totals are read next
             int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
             const int rev = sc->rowRev[lane];
-            // triangles AND positive counts: the counts of this edge still include the triangle partners (step C)
-            unsigned long long todo = __ballot(k >= 0 && T > 0 && pos > 0);
+            // triangles AND positive counts: the counts of this edge still include the triangle partners.  The edge is
+            // listed for k_h2_triangles, which publishes its counts; here it contributes none
+            const bool listed = k >= 0 && T > 0 && pos > 0 && rev >= 0 && rev < g.cap_total;
+            const bool shortrow = listed && rk.y <= H2_SHORT_ROW;
+            unsigned long long todo = __ballot(listed && !shortrow);
 #ifdef H2_NO_STEPC  // timing-only build (results wrong)
             todo = 0;
+#else
+            if (__ballot(shortrow) != 0ull) {
+                h2_emit_short<L1, EXS>(g, tk, al, u, shortrow, rk, (int64_t)ru.x + i, pos, T, t);
+                if (shortrow) {
+                    pos = 0;
+                    mx = 0;
+                }
+            }
 #endif
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const int2 rv = make_int2(__shfl(rk.x, l), __shfl(rk.y, l));
-                const int2 pm = h2_edge_with_triangles<CAPD, CAP, ECAP>(g, es, u, rv, t, sc, status);
+                h2_emit_task<L1, EXS>(g, tk, al, u, rv, (int64_t)ru.x + __shfl(i, l), __shfl(pos, l), __shfl(T, l), t);
                 if (lane == l) {
-                    pos = pm.x;
-                    mx = pm.y;
+                    pos = 0;
+                    mx = 0;
                 }
             }
             if (k >= 0) {
@@ -509,88 +857,66 @@ __device__ inline void h2_stream(const View &g, const H2EdgeSet es, int u, int2 
                     }
                 }
             }
-            h2_wave_sync();
         }
+        h2_wave_sync();  // the scratch is rewritten by the next batch
     }
-    if (qn > 0) h2_drain<CAPD, CAP, ECAP, PHASE>(t, sc, qn, status);  // (after the loop: a wave's last batches may be empty)
+    if (qn > 0) h2_drain<L1, EXS, PHASE>(t, sc, qn);  // (after the loop: a wave's last batches may be empty)
 }
 
-// one unit: node u, key partition `part` of `nparts`, by NW waves sharing the tables `t`
-template <int CAPD, int CAP, int NW, int ECAP, bool PARTS>
-__device__ inline void h2_node(const View &g, const H2EdgeSet es, int u, int2 ru, int part, int nparts, const H2Tab t,
-                               H2Scratch<ECAP> *sc, uint4 *rec, int32_t *status) {
-    const int tid = NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+// one unit: node u, key partition `part` of `nparts`, by NW waves sharing the tables `t`; false: the table filled up
+template <int L1, int EXS, int NW, bool PARTS>
+__device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
+                               const H2Tab t, H2Scratch *sc, uint4 *rec) {
+    const int tid = (int)threadIdx.x;
     constexpr int NT = 64 * NW;
-    uint4 *f4 = reinterpret_cast<uint4 *>(t.front);
-    uint4 *k4 = reinterpret_cast<uint4 *>(t.key);
-    uint4 *c4 = reinterpret_cast<uint4 *>(t.cnt);
-    for (int i = tid; i < CAPD / 4; i += NT) f4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
-    for (int i = tid; i < CAP / 4; i += NT) k4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
-    for (int i = tid; i < CAP / 8; i += NT) c4[i] = make_uint4(0u, 0u, 0u, 0u);
-    h2_sync<NW>();
-    for (int i = tid; i < ru.y; i += NT) {  // the members of N(u): flagged overflow entries (in every partition's tables)
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(t.b1);  // b1 and b2 are adjacent
+        constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;
+        for (int i = tid; i < NZ; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *k4 = reinterpret_cast<uint4 *>(t.key);
+        for (int i = tid; i < EXS / 4; i += NT) k4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
+        uint4 *c4 = reinterpret_cast<uint4 *>(t.cnt);
+        for (int i = tid; i < EXS / 8; i += NT) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) *t.full = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < ru.y; i += NT) {  // the members of N(u): flagged table entries (in every partition's tables)
         const int k = g.col[ru.x + i];
         if (k >= 0 && k < g.n && k != u) {
-            const int s = h2_insert<CAP>(t.key, (unsigned)k);
-            if (s < 0) *status = 1;
+            const int s = h2_insert<EXS>(t.key, (unsigned)k);
+            if (s < 0) *t.full = 1;
             else h2_cnt_flag(t.cnt, s);
-            atomicCAS(&t.front[h2_dslot<CAPD>((unsigned)k)], H2_EMPTY, (unsigned)k | H2_FLAG);  // (taken: k stays overflow-only)
+            h2_seed(t.b1, t.b2, h2_bit<L1>((unsigned)k));
         }
     }
-    h2_sync<NW>();
-#ifndef H2_NO_PHASEA
-    h2_stream<CAPD, CAP, NW, ECAP, PARTS, 0>(g, es, u, ru, part, nparts, t, sc, rec, status);
-#endif
-    h2_sync<NW>();
-#ifndef H2_NO_PHASEB
-    h2_stream<CAPD, CAP, NW, ECAP, PARTS, 1>(g, es, u, ru, part, nparts, t, sc, rec, status);
-#endif
-    h2_sync<NW>();  // the tables are rewritten by the next unit
+    __syncthreads();
+    h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec);
+    __syncthreads();
+    h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec);
+    __syncthreads();
+    const bool ok = *t.full == 0;  // uniform
+    if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec);
+    __syncthreads();  // the tables are rewritten by the next unit
+    return ok;
 }
 
-// ---- kernels -----------------------------------------------------------------------------------------------------------
-// wave class: a wave owns a unit and its private table; units are taken grid-stride (heaviest first in the list)
-template <int CAPD, int CAP, int ECAP>
-__global__ void __launch_bounds__(64 * H2_WPB0) k_h2_wave(View g, H2EdgeSet es, const int2 *units, const int32_t *count, int64_t unit_cap,
-                                                          uint4 *rec, int32_t *status) {
-    __shared__ __attribute__((aligned(16))) unsigned front_all[H2_WPB0][CAPD];
-    __shared__ __attribute__((aligned(16))) unsigned key_all[H2_WPB0][CAP];
-    __shared__ __attribute__((aligned(16))) unsigned cnt_all[H2_WPB0][CAP / 2];
-    __shared__ H2Scratch<ECAP> sc_all[H2_WPB0];
-    const int wid = threadIdx.x >> 6;
-    const int total = *count;
-    if (total < 0 || total > unit_cap) {
-        row_ok(g, make_int2(-1, total), 34, 0, 0);
-        return;
-    }
-    for (int64_t it = (int64_t)blockIdx.x * H2_WPB0 + wid; it < total; it += (int64_t)gridDim.x * H2_WPB0) {
-        const int2 un = units[it];
-        const int u = un.x;
-        if (u < 0 || u >= g.n) {
-            row_ok(g, make_int2(-1, u), 35, (int)it, total);
-            continue;
-        }
-        const int2 ru = g.rowinfo[u];
-        if (!row_ok(g, ru, 36, u, (int)it) || ru.y <= 0 || ru.y > H2_MAXDEG) continue;
-        h2_node<CAPD, CAP, 1, ECAP, false>(g, es, u, ru, 0, 1, H2Tab{front_all[wid], key_all[wid], cnt_all[wid]}, &sc_all[wid],
-                                           rec, status);
-    }
-}
-
-// block classes: a workgroup of W waves shares one table per unit
-template <int CAPD, int CAP, int W, int ECAP, bool PARTS>
-__global__ void __launch_bounds__(64 * W) k_h2_block(View g, H2EdgeSet es, const int2 *units, const int32_t *count, int64_t unit_cap,
-                                                      uint4 *rec, int32_t *status) {
-    __shared__ __attribute__((aligned(16))) unsigned front[CAPD];
-    __shared__ __attribute__((aligned(16))) unsigned key[CAP];
-    __shared__ __attribute__((aligned(16))) unsigned cnt[CAP / 2];
-    __shared__ H2Scratch<ECAP> sc_all[W];
+// RETRY: the units come from the retry list (whose tables must not fill up again: the pass falls back then)
+template <int L1, int EXS, int NW, bool PARTS>
+__global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const int2 *units, const int32_t *count, int64_t unit_cap,
+                                                       uint4 *rec, H2Retry rt, int is_retry) {
+    __shared__ __attribute__((aligned(16))) unsigned bits[(1 << L1) / 32 + (1 << (L1 - 2)) / 32];
+    __shared__ __attribute__((aligned(16))) unsigned key[EXS];
+    __shared__ __attribute__((aligned(16))) unsigned cnt[EXS / 2];
+    __shared__ H2Scratch sc_all[NW];
+    __shared__ int full;
     const int wid = threadIdx.x >> 6;
     const int total = *count;
     if (total < 0 || total > unit_cap) {  // uniform
         row_ok(g, make_int2(-1, total), 37, 0, 0);
         return;
     }
+    const H2Tab t{bits, bits + (1 << L1) / 32, key, cnt, &full};
+    H2Alloc al;
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {  // every value steering the barriers is uniform
         const int2 un = units[it];
         const int u = un.x;
@@ -602,7 +928,76 @@ __global__ void __launch_bounds__(64 * W) k_h2_block(View g, H2EdgeSet es, const
             ok = row_ok(g, ru, 38, u, (int)it) && ru.y > 0 && ru.y <= H2_MAXDEG;
         }
         if (!ok) continue;
-        h2_node<CAPD, CAP, W, ECAP, PARTS>(g, es, u, ru, part, nparts, H2Tab{front, key, cnt}, &sc_all[wid], rec, status);
+        if (!h2_node<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, &sc_all[wid], rec)) {
+            if (threadIdx.x == 0) {  // every partition of the node is redone (the retry starts from zeroed records)
+                if (is_retry) {
+                    rt.res->h2_status = 1;
+                    atomicAdd(&rt.res->h2_failed[5], 1);
+                } else {
+                    h2_retry_push(rt, u, ru.y, PARTS ? 4 : 3);
+                }
+            }
+        }
+    }
+    h2_void_candidates(tk, al.c_cur, al.c_end);
+}
+
+// the listed (candidate, partner) pairs: a thread per candidate probes the edge set for each partner of its edge (eight
+// probes in flight) and adds its corrected count to the record of the edge; the candidates of an edge are adjacent, so a
+// wave whose lanes share one record reduces first
+__global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status) {
+    if (*status != 0) return;
+    const int total = tk.res->h2_ncand;
+    if (total <= 0 || total > tk.cand_cap) return;  // (beyond the pool: the pass is run again with larger pools)
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll; base < total; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + lane;
+        int c = 0;
+        unsigned slot = 0xFFFFFFFFu;
+        if (i < total) {
+            const int4 cd = tk.cand[i];
+            const uint4 ts = cd.z >= 0 ? tk.task[cd.z] : make_uint4(0u, 0u, 0u, 0x80000000u);  // (void: the tail of a wave's chunk)
+            // (a split node some partition of which failed is redone as a whole: what its other partitions listed is void)
+            const bool stale = !(ts.w & 0x80000000u) && ((unsigned)tk.weight[ts.w & 0x7FFFFFFFu] & 0x80000000u);
+            slot = (stale || cd.z < 0) ? 0xFFFFFFFFu : ts.x;
+            c = cd.z < 0 ? 0 : cd.y;
+            const int32_t *pt = tk.part + ts.y;
+            const int np = (stale || cd.z < 0) ? 0 : (int)ts.z;
+            for (int j = 0; j < np; j += 8) {
+                int tt[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tt[q] = j + q < np ? pt[j + q] : -1;
+                unsigned bw[8], bb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    bb[q] = h2_bloom_bit(h2_edge_key(cd.x, tt[q] < 0 ? cd.x : tt[q]), es.bloom_bits);
+                    bw[q] = es.bloom[bb[q] >> 5];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)  // (few pairs are adjacent, and few others pass the bitmap)
+                    if (tt[q] >= 0 && ((bw[q] >> (bb[q] & 31u)) & 1u) && h2_eset_has(es, cd.x, tt[q])) c -= 1;
+            }
+        }
+        // the candidates of an edge are adjacent: one pair of atomics per run of equal record slots (segmented scan)
+        const unsigned prev = (unsigned)__shfl_up((int)slot, 1);
+        const bool head = lane == 0 || prev != slot;
+        const unsigned long long heads = __ballot(head);
+        const int seg = __popcll(heads & ((2ull << lane) - 1ull));
+        int n = c > 0 ? 1 : 0, mx = c > 0 ? c : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int s2 = __shfl_up(seg, off), n2 = __shfl_up(n, off), m2 = __shfl_up(mx, off);
+            if (lane >= off && s2 == seg) {
+                n += n2;
+                mx = m2 > mx ? m2 : mx;
+            }
+        }
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        if (tail && n > 0 && slot != 0xFFFFFFFFu) {
+            unsigned *r4 = reinterpret_cast<unsigned *>(rec + slot);
+            atomicAdd(&r4[0], (unsigned)n);
+            atomicMax(&r4[1], (unsigned)mx);
+        }
     }
 }
 
@@ -642,22 +1037,19 @@ constexpr int H2_NB = H2_CLASSES * H2_WB;
 constexpr int H2_PLAN_THREADS = 1024;
 
 __device__ inline void h2_classify(int d, int S, int &cls, int &wb, int &nparts) {
-    const int64_t K = (int64_t)d + 1 + S;
     nparts = 1;
-    if (K <= h2_maxkeys(0)) {
-        cls = 0;
-        wb = (int)(K * H2_WB / (h2_maxkeys(0) + 1));
-    } else if (K <= h2_maxkeys(1)) {
-        cls = 1;
-        wb = (int)((K - h2_maxkeys(0)) * H2_WB / (h2_maxkeys(1) - h2_maxkeys(0) + 1));
+    int lo = 0;
+    if (d <= H2_SMALL_DEG && S <= h2_maxw(2)) {
+        cls = S <= h2_maxw(0) ? 0 : S <= h2_maxw(1) ? 1 : 2;
+        lo = cls == 0 ? 0 : h2_maxw(cls - 1);
+        wb = (int)((int64_t)(S - lo) * H2_WB / (h2_maxw(cls) - lo + 1));
+    } else if (S <= h2_maxw(3) && d + S / 4 <= h2_keycap(3)) {
+        cls = 3;
+        wb = S < 2048 ? 0 : S < 4096 ? 1 : S < 6144 ? 2 : 3;
     } else {
-        cls = 2;
-        if (K > h2_maxkeys(2)) {  // split the keys: deg + 1 flagged neighbours in every part, a quarter of slack for the hash
-            const int64_t room = h2_maxkeys(2) - d - 1;
-            nparts = (int)(((int64_t)S * 5 / 4 + room - 1) / room);
-            if (nparts > 65535) nparts = 65535;  // (cannot fit then: the table reports it and the pass falls back)
-        }
-        wb = S < 16384 ? 0 : S < 32768 ? 1 : S < 65536 ? 2 : S < 131072 ? 3 : S < 262144 ? 4 : S < 524288 ? 5 : S < 1048576 ? 6 : 7;
+        cls = 4;
+        nparts = h2_parts_for(d, S, false);
+        wb = S < 16384 ? 0 : S < 32768 ? 1 : S < 65536 ? 2 : 3;
     }
     if (wb > H2_WB - 1) wb = H2_WB - 1;
     if (wb < 0) wb = 0;
@@ -721,8 +1113,10 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
     __syncthreads();
     if (bkt >= 0) {
         const int64_t first = (int64_t)blk_base[bkt] + my_off;
-        if (first >= 0 && first + nunits <= L.cap[cls]) {
+        if (nparts <= 65535 && first >= 0 && first + nunits <= L.cap[cls]) {
             for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int2(u, (nparts << 16) | j);
+        } else if (nparts > 65535) {
+            res->h2_status = 1;
         }  // (else: reported through h2_count / h2_status above)
     }
 }
@@ -736,17 +1130,33 @@ __global__ void k_h2_clear(DevResult *res) {
     if (threadIdx.x < H2_CLASSES) res->h2_count[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         res->h2_status = 0;
+        res->h2_retry = 0;
+        res->h2_ntask = 0;
+        res->h2_ncand = 0;
+        res->h2_npart = 0;
+        for (int c = 0; c < 6; ++c) res->h2_failed[c] = 0;
         res->flag_too_big = 0;
     }
 }
 
+// the records of the nodes on the retry list start from zero again (a split node's partitions add into them)
+__global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int2 *units, const int32_t *count, int64_t unit_cap, uint4 *rec) {
+    const int total = *count;
+    if (total <= 0 || total > unit_cap) return;
+    for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const int2 un = units[it];
+        if ((un.y & 0xFFFF) != 0 || un.x < 0 || un.x >= g.n) continue;
+        const int2 ru = g.rowinfo[un.x];
+        if (!row_ok(g, ru, 42, un.x, (int)it)) continue;
+        for (int i = threadIdx.x; i < ru.y; i += 256) rec[(int64_t)ru.x + i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // ---- join the two records of every edge and evaluate the closing expression ------------------------------------------
-__global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv) {
+__global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv, const int32_t *status) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= g.cap_total) return;
-#ifdef H2_NO_PHASEB  // timing-only build: there are no records to join
-    return;
-#endif
+    if (*status != 0) return;  // some records are missing: the whole pass is redone by the node-centric kernels
     const int u = g.slot_row[s];
     if (u < 0 || u >= g.n) return;
     const int2 ru = g.rowinfo[u];
@@ -774,6 +1184,16 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
+// the pools of the triangle step were too small for the last pass: remember what it asked for (the counters kept counting)
+bool h2_grow_pools(dcr_graph *g) {
+    const int64_t t = g->hres->h2_ntask, c = g->hres->h2_ncand, p = g->hres->h2_npart;
+    if (t < 0 || c < 0 || p < 0) return false;  // the 31-bit counters wrapped: not a case for this engine
+    g->h2_want[0] = t + t / 4 + 4096;
+    g->h2_want[1] = c + c / 4 + 65536;
+    g->h2_want[2] = p + p / 4 + 65536;
+    return true;
+}
+
 bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental) {
     return g->pass_impl == 3 && curv_type == DCR_CURV_BFC && !incremental && g->max_deg_bound <= H2_MAXDEG && g->cap_total < (int64_t)1 << 31;
 }
@@ -781,30 +1201,61 @@ bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental) {
 static int ensure_h2(dcr_graph *g) {
     DCR_TRY(dev_regrow(&g->h2_weight, &g->h2_weight_cap, g->n + 64));
     DCR_TRY(dev_regrow(&g->h2_rec, &g->h2_rec_cap, g->cap_total + 64));
-    // edge set: at most cap_total / 2 undirected edges, load <= 1/4
+    // edge set: at most cap_total / 2 undirected edges, load <= 1/2
     int bits = 10;
-    while ((1ll << bits) < 2 * g->cap_total) ++bits;
+    while ((1ll << bits) < g->cap_total) ++bits;
     if (g->h2_eset_bits != bits || !g->h2_eset) {
         if (g->h2_eset) (void)hipFree(g->h2_eset);
         g->h2_eset = nullptr;
         DCR_TRY(dev_alloc(&g->h2_eset, (int64_t)1 << bits));
         g->h2_eset_bits = bits;
     }
-    const int64_t need[H2_CLASSES] = {g->n + 64, g->n + 64, g->n + g->cap_total / 4 + 64};
+    int bbits = 16;
+    while ((1ll << bbits) < 4 * g->cap_total) ++bbits;
+    if (g->h2_bloom_bits != bbits || !g->h2_bloom) {
+        if (g->h2_bloom) (void)hipFree(g->h2_bloom);
+        g->h2_bloom = nullptr;
+        DCR_TRY(dev_alloc(&g->h2_bloom, ((int64_t)1 << bbits) / 32));
+        g->h2_bloom_bits = bbits;
+    }
+    const int64_t need[H2_CLASSES] = {g->n + 64, g->n + 64, g->n + 64, g->n + 64, g->n + g->cap_total / 4 + 64};
     for (int c = 0; c < H2_CLASSES; ++c) DCR_TRY(dev_regrow(&g->h2_units[c], &g->h2_units_cap[c], need[c]));
+    DCR_TRY(dev_regrow(&g->h2_retry, &g->h2_retry_cap, g->n + g->cap_total / 4 + 64));
+    // triangle step pools: tasks are edges (with the partitions of split nodes: a few times that), candidates and partners
+    // adjacency entries of theirs
+    // (sized for power-law graphs; a pass that needs more says how much — h2_grow_pools — and is run again)
+    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, std::max<int64_t>(g->cap_total / 2 + 4096, g->h2_want[0])));
+    DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[1])));
+    DCR_TRY(dev_regrow(&g->h2_part, &g->h2_part_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[2])));
     return DCR_OK;
 }
 
-static unsigned h2_grid(const dcr_graph *g, int c, int64_t per_block) {
-    // one unit per workgroup slot when the count of the previous pass is known (the graph changes by an edge or two per
-    // SDRF iteration), else a grid-stride launch over a few rounds of workgroups; any grid is correct
-    const int64_t units = g->h2_last_count[c] >= 0 ? (int64_t)g->h2_last_count[c] + g->h2_last_count[c] / 32 + 8
-                                                   : (int64_t)g->num_cu * 32 * per_block;
-    int64_t grid = (units + per_block - 1) / per_block;
+template <int C>
+static void launch_h2_small(dcr_graph *g, const View &vw, const H2Retry &rt, hipStream_t st) {
+    constexpr int H2_WPB = h2_wpb(C);
+    constexpr int LDS = H2_WPB * (int)sizeof(H2Small<h2_l1(C), h2_exs(C), h2_clcap(C)>);
+    int per_cu = (160 * 1024) / LDS;
+    if (per_cu > 32 / H2_WPB) per_cu = 32 / H2_WPB;
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)g->num_cu * per_cu;
     static const int64_t cap = getenv("DCR_H2_GRID") ? atoll(getenv("DCR_H2_GRID")) : 0;  // tuning aid: workgroups per CU
-    if (cap > 0 && grid > cap * g->num_cu) grid = cap * g->num_cu;
+    if (cap > 0) grid = cap * g->num_cu;
+    const int64_t units = g->h2_last_count[C] >= 0 ? (int64_t)g->h2_last_count[C] + g->h2_last_count[C] / 32 + 8 : g->n;
+    if (grid > (units + H2_WPB - 1) / H2_WPB) grid = (units + H2_WPB - 1) / H2_WPB;  // small graphs: no idle workgroups
     if (grid < 1) grid = 1;
-    return (unsigned)grid;
+    hipLaunchKernelGGL((k_h2_small<h2_l1(C), h2_exs(C), h2_clcap(C), H2_WPB>), dim3((unsigned)grid), dim3(64 * H2_WPB), 0, st, vw,
+                       g->h2_units[C], &g->dres->h2_count[C], g->h2_units_cap[C], g->h2_rec, rt);
+}
+
+template <int C, bool PARTS>
+static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, const H2Retry &rt, const int2 *units,
+                            const int32_t *count, int64_t cap, int64_t units_hint, int is_retry, hipStream_t st) {
+    int64_t grid = units_hint;
+    const int64_t most = (int64_t)g->num_cu * (C == 3 ? 3 : 1);
+    if (grid > most) grid = most;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((k_h2_block<h2_l1(C), h2_exs(C), h2_waves(C), PARTS>), dim3((unsigned)grid), dim3(64 * h2_waves(C)), 0,
+                       st, vw, tk, units, count, cap, g->h2_rec, rt, is_retry);
 }
 
 int launch_curvature_pass_h2(dcr_graph *g) {
@@ -822,9 +1273,24 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         L.cap[c] = g->h2_units_cap[c];
     }
     int32_t *status = &g->dres->h2_status;
+    const H2Retry rt{g->h2_retry, g->h2_retry_cap, g->h2_weight, g->dres};
+    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, g->h2_task_cap, g->h2_cand_cap, g->h2_part_cap, g->dres, g->h2_weight, 0u};
     hipLaunchKernelGGL(k_h2_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
-    DCR_HIP(hipMemsetAsync(g->h2_weight, 0, sizeof(int32_t) * (size_t)(g->n > 0 ? g->n : 1), g->stream));
+    static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
     const int64_t sblocks = (g->cap_total + 255) / 256;
+    const H2EdgeSet es{g->h2_eset, g->h2_eset_bits, g->h2_bloom, g->h2_bloom_bits};
+    // the edge set (triangle step of the block classes) depends on the graph only: rebuilt on a stream of its own
+    // while weights and plan are computed
+    hipStream_t sa = serial ? g->stream : g->aux;
+    if (!serial) {
+        DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
+        DCR_HIP(hipStreamWaitEvent(sa, g->ev_fork, 0));
+    }
+    DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, sa));
+    DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), sa));
+    if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, sa, vw, es, status);
+    if (!serial) DCR_HIP(hipEventRecord(g->ev_aux, sa));
+    DCR_HIP(hipMemsetAsync(g->h2_weight, 0, sizeof(int32_t) * (size_t)(g->n > 0 ? g->n : 1), g->stream));
     if (sblocks > 0) hipLaunchKernelGGL(k_h2_weight, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_weight);
     const int64_t pblocks = (g->n + H2_PLAN_THREADS - 1) / H2_PLAN_THREADS;
     if (pblocks > 0) {
@@ -833,37 +1299,50 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         hipLaunchKernelGGL(k_h2_plan<1>, dim3((unsigned)pblocks), dim3(H2_PLAN_THREADS), 0, g->stream, vw, g->h2_weight, L,
                            g->dres);
     }
-    const H2EdgeSet es{g->h2_eset, g->h2_eset_bits};
-    DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, g->stream));
-    if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, es, status);
     // records of split nodes are accumulated with atomics: start from zero
-    DCR_HIP(hipMemsetAsync(g->h2_rec, 0, sizeof(uint4) * (size_t)(g->cap_total > 0 ? g->cap_total : 1), g->stream));
-    static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
-    hipStream_t s1 = g->stream, s2 = g->stream;
+    hipLaunchKernelGGL(k_h2_retry_zero, dim3(64), dim3(256), 0, g->stream, vw, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4],
+                       g->h2_rec);
+    hipStream_t s0 = g->stream, s1 = g->stream, s2 = g->stream, s3 = g->stream;
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        for (int b = 0; b < 2; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
-        s1 = g->side[0];
-        s2 = g->side[1];
+        for (int b = 0; b < 4; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
+        s0 = g->side[0];
+        s1 = g->side[1];
+        s2 = g->side[3];
+        s3 = g->side[2];  // (the low-priority stream: the finest-grained kernel)
     }
-    // heaviest class first on the main stream; the classes are independent
-    hipLaunchKernelGGL((k_h2_block<h2_capd(2), h2_cap(2), h2_waves(2), h2_ecap(2), true>), dim3(h2_grid(g, 2, 1)),
-                       dim3(64 * h2_waves(2)), 0, g->stream, vw, es, g->h2_units[2], &g->dres->h2_count[2], g->h2_units_cap[2],
-                       g->h2_rec, status);
-    hipLaunchKernelGGL((k_h2_block<h2_capd(1), h2_cap(1), h2_waves(1), h2_ecap(1), false>), dim3(h2_grid(g, 1, 1)),
-                       dim3(64 * h2_waves(1)), 0, s1, vw, es, g->h2_units[1], &g->dres->h2_count[1], g->h2_units_cap[1],
-                       g->h2_rec, status);
-    hipLaunchKernelGGL((k_h2_wave<h2_capd(0), h2_cap(0), h2_ecap(0)>), dim3(h2_grid(g, 0, H2_WPB0)),
-                       dim3(64 * H2_WPB0), 0, s2, vw, es, g->h2_units[0], &g->dres->h2_count[0], g->h2_units_cap[0], g->h2_rec,
-                       status);
+    // the block classes first (the longest units), then the wave classes
+    const int64_t hint4 = g->h2_last_count[4] >= 0 ? (int64_t)g->h2_last_count[4] + 8 : g->num_cu;
+    const int64_t hint3 = g->h2_last_count[3] >= 0 ? (int64_t)g->h2_last_count[3] + 8 : 3 * (int64_t)g->num_cu;
+    launch_h2_block<4, true>(g, vw, tk, rt, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4], hint4, 0, g->stream);
+    launch_h2_block<3, false>(g, vw, tk, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, s2);
+    launch_h2_small<2>(g, vw, rt, s0);
+    launch_h2_small<1>(g, vw, rt, s1);
+    launch_h2_small<0>(g, vw, rt, s3);
     if (!serial) {
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 4; ++b) {
             DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
             DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[b], 0));
         }
     }
-    if (sblocks > 0) hipLaunchKernelGGL(k_h2_final, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv);
+    // nodes whose tables filled up in their class: zero their records, redo them with worst-case partitions
+    hipLaunchKernelGGL(k_h2_retry_zero, dim3(64), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
+                       g->h2_rec);
+    tk.retry_flag = 0x80000000u;
+    launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_aux, 0));  // the edge set is probed from here on only
+    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status);
+    if (sblocks > 0) hipLaunchKernelGGL(k_h2_final, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status);
     DCR_HIP(hipGetLastError());
+    static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;
+    if (debug) {
+        DevResult h;
+        DCR_HIP(hipStreamSynchronize(g->stream));
+        DCR_HIP(hipMemcpy(&h, g->dres, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[h2] units per class %d %d %d %d %d, retry units %d, status %d, failed per class %d %d %d %d %d retry %d\n",
+                h.h2_count[0], h.h2_count[1], h.h2_count[2], h.h2_count[3], h.h2_count[4], h.h2_retry, h.h2_status, h.h2_failed[0],
+                h.h2_failed[1], h.h2_failed[2], h.h2_failed[3], h.h2_failed[4], h.h2_failed[5]);
+    }
     return DCR_OK;
 }
 

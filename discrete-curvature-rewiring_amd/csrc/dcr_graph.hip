@@ -380,6 +380,8 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_HIP(hipEventCreate(&g->ev0));
     DCR_HIP(hipEventCreate(&g->ev1));
     DCR_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    DCR_HIP(hipEventCreateWithFlags(&g->ev_aux, hipEventDisableTiming));
+    DCR_HIP(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
     // side[2] carries the finest-grained kernel of a pass (the smallest degree class): lowest priority, so that the
     // kernels with long units get their workgroups resident first and the fine-grained one fills in and finishes last
     int prio_low = 0, prio_high = 0;
@@ -422,7 +424,8 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->imp_stats, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
                         g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
                         g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
-                        g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_rec, g->h2_eset};
+                        g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_units[3], g->h2_units[4], g->h2_retry, g->h2_task, g->h2_cand, g->h2_part, g->h2_bloom,
+                        g->h2_rec, g->h2_eset};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)
@@ -436,6 +439,8 @@ int dcr_graph_destroy(dcr_graph *g) {
         if (g->ev_join[b]) (void)hipEventDestroy(g->ev_join[b]);
     }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_aux) (void)hipEventDestroy(g->ev_aux);
+    if (g->aux) (void)hipStreamDestroy(g->aux);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);

@@ -68,7 +68,10 @@ struct DevResult {
     // two-hop pass (dcr_bfc_h2.hip): units per (class, weight bucket), placement cursors, units per class
     int32_t h2_bucket[24];
     int32_t h2_fill[24];
-    int32_t h2_count[3];
+    int32_t h2_count[5];
+    int32_t h2_failed[6];  // diagnostic: nodes whose tables filled up, per class (5: on the retry list itself)
+    int32_t h2_ntask, h2_ncand, h2_npart;  // triangle step: listed edges, candidates, partners
+    int32_t h2_retry;   // units on the retry list (nodes whose tables filled up in their class, redone by the largest class)
     int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels)
 };
 
@@ -137,14 +140,23 @@ struct dcr_graph {
 
     // two-hop pass (dcr_bfc_h2.hip)
     int32_t *h2_weight = nullptr;     // [n] sum of the neighbours' degrees
-    int2 *h2_units[3] = {nullptr, nullptr, nullptr};  // per class {node, partitions << 16 | partition}
-    int64_t h2_units_cap[3] = {0, 0, 0};
+    int2 *h2_units[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // per class {node, partitions << 16 | partition}
+    int64_t h2_units_cap[5] = {0, 0, 0, 0, 0};
+    uint4 *h2_task = nullptr;         // triangle step pools (dcr_bfc_h2.hip)
+    int4 *h2_cand = nullptr;
+    int32_t *h2_part = nullptr;
+    int64_t h2_task_cap = 0, h2_cand_cap = 0, h2_part_cap = 0;
+    int64_t h2_want[3] = {0, 0, 0};   // pool sizes a pass asked for (tasks, candidates, partners)
+    unsigned *h2_bloom = nullptr;     // one bit per edge (prefilter of the edge set)
+    int h2_bloom_bits = 0;
+    int2 *h2_retry = nullptr;         // units of nodes whose tables filled up in their class (redone by the largest class)
+    int64_t h2_retry_cap = 0;
     uint4 *h2_rec = nullptr;          // [cap_total] per directed slot {|sq| on the far side, max count, triangles, reverse slot}
     int64_t h2_rec_cap = 0;
     int64_t h2_weight_cap = 0;
     unsigned long long *h2_eset = nullptr;  // every undirected edge as one 64-bit key (open addressing), rebuilt per pass
     int h2_eset_bits = 0;
-    int32_t h2_last_count[3] = {-1, -1, -1};  // units per class of the previous pass (sizes the next grids)
+    int32_t h2_last_count[5] = {-1, -1, -1, -1, -1};  // units per class of the previous pass (sizes the next grids)
 
     // edges beyond every LDS table (dcr_bfc_giant.hip): records {slot, u, v, deg u, deg v}; position map over all ids
     int32_t *giant_list = nullptr;
@@ -190,6 +202,8 @@ struct dcr_graph {
     // side streams: the work bins of a curvature pass run concurrently
     hipStream_t side[dcr::NBINS - 1] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr;
+    hipStream_t aux = nullptr;   // two-hop pass: the edge set is rebuilt here while the plan runs
+    hipEvent_t ev_aux = nullptr;
     hipEvent_t ev_join[dcr::NBINS - 1] = {nullptr, nullptr, nullptr, nullptr};
     int num_cu = 0;
 
@@ -224,6 +238,7 @@ int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental);
 // dcr_bfc_h2.hip
 bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental);
 int launch_curvature_pass_h2(dcr_graph *g);
+bool h2_grow_pools(dcr_graph *g);
 
 template <typename T>
 int dev_alloc(T **p, int64_t count) {

@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libdcr_hip.so')
+# DCR_LIB: another build of the same library (A/B timing of kernel variants, tools/ab_pass.sh) without touching the default
+LIB_PATH = os.environ.get('DCR_LIB') or os.path.join(CSRC, 'libdcr_hip.so')
 
 _i32 = ctypes.c_int32
 _i64 = ctypes.c_int64
