@@ -119,6 +119,50 @@ __device__ inline bool h2_again(const unsigned *b2, unsigned b) {
     const unsigned c = b >> 2;
     return (b2[c >> 5] >> (c & 31u)) & 1u;
 }
+// The four entries of a piece at once, branch-free up to the rare second step: entry by entry, every returning atomic was
+// followed by a wait and a branch (20 round trips of LDS latency per sweep of a small node).  `valid`: 4-bit mask.
+template <int L1>
+__device__ inline void h2_mark4(unsigned *b1, unsigned *b2, const unsigned kk[4], unsigned valid) {
+    unsigned b[4], m[4], old[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        b[jj] = h2_bit<L1>(kk[jj]);
+        m[jj] = ((valid >> jj) & 1u) << (b[jj] & 31u);  // (no bit for an entry that does not count: the atomic changes nothing)
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) old[jj] = atomicOr(&b1[b[jj] >> 5], m[jj]);
+    unsigned any = 0u;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        old[jj] &= m[jj];
+        any |= old[jj];
+    }
+    if (any) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (old[jj]) {
+                const unsigned c = b[jj] >> 2;
+                atomicOr(&b2[c >> 5], 1u << (c & 31u));
+            }
+    }
+}
+// which of the four entries have their B2 bit set (four independent reads)
+template <int L1>
+__device__ inline unsigned h2_again4(const unsigned *b2, const unsigned kk[4], unsigned valid) {
+    unsigned c[4], wd[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        c[jj] = h2_bit<L1>(kk[jj]) >> 2;
+        wd[jj] = b2[c[jj] >> 5];
+    }
+    unsigned f = 0u;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) f |= ((wd[jj] >> (c[jj] & 31u)) & 1u) << jj;
+    return f & valid;
+}
+__device__ inline unsigned h2_eq4(const unsigned kk[4], unsigned u) {
+    return (kk[0] == u ? 1u : 0u) | (kk[1] == u ? 2u : 0u) | (kk[2] == u ? 4u : 0u) | (kk[3] == u ? 8u : 0u);
+}
 
 __device__ inline unsigned h2_piece_mask(int a, int lo, int hi) {
     const int s = lo - a, t = hi - a;
@@ -180,6 +224,71 @@ __device__ inline void h2_for_pieces(const int32_t *col, const int2 *desc, const
     }
 }
 
+// The same with the exact-path queue: flags(piece, mask, row, slot) -> which of the four entries go to the queue;
+// push(index, key, row) stores one; drain() works the queue off and resets qn.  The drain is called from ONE place per
+// iteration (inlined at every entry position it was 4 x H2_Q copies of the table walks per sweep, and the kernels
+// outgrew the instruction cache: 135-190 KB each).
+template <typename Flags, typename Push, typename Drain>
+__device__ inline void h2_for_pieces_queued(const int32_t *col, const int2 *desc, const int *poff, int poff_lane, int P, int &qn,
+                                            Flags flags, Push push, Drain drain) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int j0 = 0; j0 < P; j0 += 64 * H2_Q) {
+        int4 w[H2_Q];
+        int rr[H2_Q];
+        unsigned fl[H2_Q];
+        unsigned anyf = 0u;
+#pragma unroll
+        for (int q = 0; q < H2_Q; ++q) {
+            const int j = j0 + 64 * q + lane;
+            rr[q] = -1;
+            fl[q] = 0u;
+            w[q] = make_int4(0, 0, 0, 0);
+            const int jf = j0 + 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+            if (jf >= P) continue;  // uniform
+            const int r = h2_piece_row(poff, poff_lane, j < P ? j : jl, jf, jl);
+            int a = 0;
+            unsigned vm = 0u;
+            if (j < P) {
+                const int2 d = desc[r];
+                a = (d.x & ~3) + 4 * (j - poff[r]);
+                w[q] = load_piece(col, a);
+                rr[q] = r;
+                vm = h2_piece_mask(a, d.x, d.x + d.y);
+            }
+            fl[q] = flags(w[q], vm, rr[q], a);
+            anyf |= fl[q];
+        }
+        if (__ballot(anyf != 0u) == 0ull) continue;  // uniform
+#pragma unroll 1
+        while (true) {
+            bool stop = false;  // uniform: the queue is full, the rest waits for the drain
+#pragma unroll
+            for (int q = 0; q < H2_Q; ++q) {
+                const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const bool p = (fl[q] >> jj) & 1u;
+                    const unsigned long long m = __ballot(p);
+                    if (m == 0ull) continue;  // uniform
+                    if (stop || qn + __popcll(m) > H2_QCAP) {
+                        stop = true;
+                        continue;
+                    }
+                    if (p) {
+                        push(qn + __popcll(m & below), kk[jj], rr[q]);
+                        fl[q] &= ~(1u << jj);
+                    }
+                    qn += __popcll(m);
+                }
+            }
+            if (!stop) break;
+            drain();
+        }
+    }
+}
+
 // piece counts of the rows held by the lanes -> exclusive prefix in `excl`, total returned
 __device__ inline int h2_prefix(int np, int &excl) {
     const int lane = threadIdx.x & 63;
@@ -209,7 +318,7 @@ __host__ __device__ inline int h2_parts_for(int d, int64_t W, bool safe) {
     return (int)p;
 }
 struct H2Retry {
-    int2 *units;
+    int4 *units;
     int64_t cap;
     int32_t *weight;  // bit 31: the node is on the list already (several partitions of a split node may fail)
     DevResult *res;
@@ -224,9 +333,20 @@ __device__ inline void h2_retry_push(const H2Retry rt, int u, int d, int cls) { 
         rt.res->h2_status = 1;  // not even the retry list takes it: the pass is redone by the node-centric kernels
         return;
     }
-    for (int j = 0; j < nparts; ++j) rt.units[first + j] = make_int2(u, (nparts << 16) | j);
+    for (int j = 0; j < nparts; ++j) rt.units[first + j] = make_int4(u, (nparts << 16) | j, 0, 0);
 }
 
+#ifdef H2_PROF  // diagnostic build (tools/build_variant.sh prof -DH2_PROF): wave-cycles per section of the wave classes
+__device__ unsigned long long h2_prof[16];
+#define H2_STAMP(i)                                                      \
+    {                                                                    \
+        const long long now_ = (long long)__builtin_amdgcn_s_memtime();  \
+        if ((threadIdx.x & 63) == 0) s->prof[i] += (unsigned long long)(now_ - t_prof);              \
+        t_prof = now_;                                                   \
+    }
+#else
+#define H2_STAMP(i)
+#endif
 // =====================================================================================================================
 // wave classes: a node of at most 64 neighbours, by one wave
 // =====================================================================================================================
@@ -244,6 +364,9 @@ struct __attribute__((aligned(16))) H2Small {
     unsigned short cls[CLCAP];     // candidate occurrences: EX slot ...
     unsigned char qr[H2_QCAP];
     unsigned char clr[CLCAP];      // ... and row
+#ifdef H2_PROF
+    unsigned long long prof[8];    // per wave, flushed when the kernel ends
+#endif
 };
 
 template <int EXS>
@@ -255,6 +378,7 @@ __device__ inline unsigned h2s_home(unsigned key) {
 template <int EXS>
 __device__ inline int h2s_find_or_insert(unsigned *exkey, unsigned w) {
     unsigned s = h2s_home<EXS>(w);
+#pragma unroll 1
     for (int walk = 0; walk < EXS; ++walk) {
         const unsigned e = exkey[s];
         if ((e & ~H2_NBR) == w && e != H2_EMPTY) return (int)s;
@@ -269,6 +393,7 @@ __device__ inline int h2s_find_or_insert(unsigned *exkey, unsigned w) {
 template <int EXS>
 __device__ inline int h2s_insert_nbr(unsigned *exkey, unsigned k) {  // the members of N(u) are distinct
     unsigned s = h2s_home<EXS>(k);
+#pragma unroll 1
     for (int walk = 0; walk < EXS; ++walk) {
         if (atomicCAS(&exkey[s], H2_EMPTY, k | H2_NBR) == H2_EMPTY) return (int)s;
         s = (s + 1) & (unsigned)(EXS - 1);
@@ -276,10 +401,17 @@ __device__ inline int h2s_insert_nbr(unsigned *exkey, unsigned k) {  // the memb
     return -1;
 }
 
-template <int L1, int EXS, int CLCAP>
-__device__ inline void h2s_node(const View &g, int u, int2 ru, H2Small<L1, EXS, CLCAP> *s, uint4 *rec, const H2Retry rt) {
+// k, rk: the lane's member of N(u) and its row (loaded ahead by the caller); NP: 64-piece steps a node of this class can
+// have — all pieces of the node stay in registers and serve both sweeps; mid(): called once between the sweeps (the
+// caller's prefetch of the next node)
+template <int L1, int EXS, int CLCAP, int NP, typename Mid>
+__device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H2Small<L1, EXS, CLCAP> *s, uint4 *rec,
+                                const H2Retry rt, Mid mid) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef H2_PROF
+    long long t_prof = (long long)__builtin_amdgcn_s_memtime();
+#endif
     {   // clear: bitmaps and row masks to zero, keys to "free"
         uint4 *z = reinterpret_cast<uint4 *>(s->b1);
         constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;  // b1 and b2 are adjacent
@@ -295,22 +427,18 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, H2Small<L1, EXS, 
         s->rev[lane] = -1;
     }
     h2_wave_sync();
+    H2_STAMP(0)
     // the members of N(u): seeded into both bitmaps and the exact table (flagged, with their position in row u)
-    int k = -1;
-    int2 rk = make_int2(0, 0);
     bool full = false;
-    if (lane < ru.y) {
-        k = g.col[ru.x + lane];
-        if (k >= 0 && k < g.n && k != u) {
-            rk = g.rowinfo[k];
-            if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
-            const int slot = h2s_insert_nbr<EXS>(s->exkey, (unsigned)k);
-            if (slot < 0) full = true;
-            else s->exlo[slot] = (unsigned)lane;
-            h2_seed(s->b1, s->b2, h2_bit<L1>((unsigned)k));
-        } else {
-            k = -1;
-        }
+    if (lane >= ru.y || k < 0 || k >= g.n || k == u) {
+        k = -1;
+        rk = make_int2(0, 0);
+    } else {
+        if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
+        const int slot = h2s_insert_nbr<EXS>(s->exkey, (unsigned)k);
+        if (slot < 0) full = true;
+        else s->exlo[slot] = (unsigned)lane;
+        h2_seed(s->b1, s->b2, h2_bit<L1>((unsigned)k));
     }
     const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
     int poff_lane;
@@ -319,14 +447,38 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, H2Small<L1, EXS, 
     s->poff[lane] = poff_lane;
     if (lane == 0) s->poff[64] = P;
     h2_wave_sync();
-    // sweep A
-    h2_for_pieces(g.col, s->desc, s->poff, poff_lane, P, [&](const int4 w, unsigned vm, int, int) {
-        const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
+    H2_STAMP(1)
+    if (P > 64 * NP) full = true;  // (cannot happen: the class bounds the weight; such a node would be redone elsewhere)
+    // every piece of the node is requested at once and kept: meta = valid-entry mask | row << 4 | first slot of the piece << 12
+    int4 w[NP];
+    unsigned long long meta[NP];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-            if (((vm >> jj) & 1u) && kk[jj] != (unsigned)u) h2_mark(s->b1, s->b2, h2_bit<L1>(kk[jj]));
-    });
+    for (int q = 0; q < NP; ++q) {
+        const int j = 64 * q + lane;
+        w[q] = make_int4(0, 0, 0, 0);
+        meta[q] = 0ull;
+        const int jf = 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+        if (jf >= P) continue;  // uniform
+        const int r = h2_piece_row(s->poff, poff_lane, j < P ? j : jl, jf, jl);
+        if (j < P) {
+            const int2 d = s->desc[r];
+            const int a = (d.x & ~3) + 4 * (j - s->poff[r]);
+            w[q] = load_piece(g.col, a);
+            meta[q] = (unsigned long long)h2_piece_mask(a, d.x, d.x + d.y) | ((unsigned long long)r << 4) | ((unsigned long long)(unsigned)a << 12);
+        }
+    }
+    H2_STAMP(2)
+    // sweep A
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        if (64 * q >= P) continue;  // uniform
+        const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+        const unsigned vm = (unsigned)meta[q] & 0xFu;
+        h2_mark4<L1>(s->b1, s->b2, kk, vm & ~h2_eq4(kk, (unsigned)u));
+    }
+    mid();
     h2_wave_sync();
+    H2_STAMP(3)
     // sweep B: entries whose B2 bit is set are queued and settled against the exact table 64 at a time
     int qn = 0, cln = 0;  // uniform
     auto drain = [&]() {
@@ -364,32 +516,49 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, H2Small<L1, EXS, 
         h2_wave_sync();
         qn = 0;
     };
-    h2_for_pieces(g.col, s->desc, s->poff, poff_lane, P, [&](const int4 w, unsigned vm, int r, int a) {
-        const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
-        unsigned f = 0u;
+    unsigned fl[NP];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            if (!((vm >> jj) & 1u)) continue;
-            if (kk[jj] == (unsigned)u) s->rev[r] = a + jj;  // where u sits in row r: the slot of the reverse entry
-            else if (h2_again(s->b2, h2_bit<L1>(kk[jj]))) f |= 1u << jj;
-        }
-        if (__ballot(f != 0u) == 0ull) return;  // uniform
+    for (int q = 0; q < NP; ++q) {
+        fl[q] = 0u;
+        if (64 * q >= P) continue;  // uniform
+        const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+        const unsigned vm = (unsigned)meta[q] & 0xFu;
+        const unsigned isu = h2_eq4(kk, (unsigned)u) & vm;
+        if (isu) s->rev[(int)((meta[q] >> 4) & 0xFFull)] = (int)(meta[q] >> 12) + __ffs((int)isu) - 1;  // where u sits in that row
+        fl[q] = h2_again4<L1>(s->b2, kk, vm & ~isu);
+    }
+    // the flagged entries are queued; the drain has ONE call site (inlined per entry position the kernels outgrew the
+    // instruction cache)
+#pragma unroll 1
+    while (true) {
+        bool stop = false;  // uniform: the queue is full, the rest waits for the drain
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const bool p = (f >> jj) & 1u;
-            const unsigned long long m = __ballot(p);
-            if (m == 0ull) continue;  // uniform
-            if (qn > H2_QCAP - 64) drain();
-            if (p) {
-                const int idx = qn + __popcll(m & below);
-                s->qk[idx] = kk[jj];
-                s->qr[idx] = (unsigned char)r;
+        for (int q = 0; q < NP; ++q) {
+            if (64 * q >= P) continue;  // uniform
+            const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool p = (fl[q] >> jj) & 1u;
+                const unsigned long long m = __ballot(p);
+                if (m == 0ull) continue;  // uniform
+                if (stop || qn + __popcll(m) > H2_QCAP) {
+                    stop = true;
+                    continue;
+                }
+                if (p) {
+                    const int idx = qn + __popcll(m & below);
+                    s->qk[idx] = kk[jj];
+                    s->qr[idx] = (unsigned char)((meta[q] >> 4) & 0xFFull);
+                    fl[q] &= ~(1u << jj);
+                }
+                qn += __popcll(m);
             }
-            qn += __popcll(m);
         }
-    });
-    if (qn > 0) drain();
+        if (qn > 0) drain();
+        if (!stop) break;
+    }
     h2_wave_sync();
+    H2_STAMP(4)
     if (__ballot(full) != 0ull) {  // a table or the list filled up: nothing is published, the node is redone elsewhere
         if (lane == 0) h2_retry_push(rt, u, ru.y, EXS == 128 ? 0 : EXS == 256 ? 1 : 2);
         h2_wave_sync();
@@ -416,29 +585,60 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, H2Small<L1, EXS, 
         }
     }
     h2_wave_sync();  // the arrays are rewritten by the next node
+    H2_STAMP(5)
 }
 
-// units are taken grid-stride from a list laid out heaviest first: every wave gets a similar mix
-template <int L1, int EXS, int CLCAP, int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_h2_small(View g, const int2 *units, const int32_t *count, int64_t unit_cap,
+// Units are taken grid-stride from a list laid out heaviest first: every wave gets a similar mix.  A node is a chain of
+// dependent device-memory reads (unit -> row of u -> rows of its members -> their pieces) with little to do in between,
+// so the chain of the NEXT node is started while the current one is worked on: its unit two nodes ahead, its row at the
+// start of this node, the rows' descriptors between the sweeps.
+template <int L1, int EXS, int CLCAP, int WPB, int NP>
+__global__ void __launch_bounds__(64 * WPB, (L1 == 14 ? 5 : 1)) k_h2_small(View g, const int4 *units, const int32_t *count, int64_t unit_cap,
                                                        uint4 *rec, H2Retry rt) {
     __shared__ H2Small<L1, EXS, CLCAP> sm[WPB];
-    const int wid = threadIdx.x >> 6;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int total = *count;
     if (total < 0 || total > unit_cap) {
         row_ok(g, make_int2(-1, total), 34, 0, 0);
         return;
     }
-    for (int64_t it = (int64_t)blockIdx.x * WPB + wid; it < total; it += (int64_t)gridDim.x * WPB) {
-        const int u = units[it].x;
-        if (u < 0 || u >= g.n) {
-            row_ok(g, make_int2(-1, u), 35, (int)it, total);
-            continue;
+    const int64_t stride = (int64_t)gridDim.x * WPB;
+    int64_t it = (int64_t)blockIdx.x * WPB + wid;
+#ifdef H2_PROF
+    if (lane < 8) sm[wid].prof[lane] = 0ull;
+#endif
+    const int4 none = make_int4(-1, 0, 0, 0);
+    auto unit_ok = [&](const int4 un) {
+        return un.x >= 0 && un.x < g.n && un.w > 0 && un.w <= H2_SMALL_DEG && un.z >= 0 && (int64_t)un.z + un.w <= g.cap_total;
+    };
+    // prologue: this node's unit, row and row descriptors; the next node's unit and row
+    int4 un = it < total ? units[it] : none;
+    int4 un1 = it + stride < total ? units[it + stride] : none;
+    int k = (unit_ok(un) && lane < un.w) ? g.col[un.z + lane] : -1;
+    int2 rk = (k >= 0 && k < g.n) ? g.rowinfo[k] : make_int2(0, 0);
+    int k1 = (unit_ok(un1) && lane < un1.w) ? g.col[un1.z + lane] : -1;
+    for (; it < total; it += stride) {
+        const int4 un2 = it + 2 * stride < total ? units[it + 2 * stride] : none;  // two nodes ahead
+        int2 rk1 = make_int2(0, 0);
+        if (unit_ok(un)) {
+            // (the plan read the row of u in this same pass: {start, degree} travel with the unit)
+            h2s_node<L1, EXS, CLCAP, NP>(g, un.x, make_int2(un.z, un.w), k, rk, &sm[wid], rec, rt, [&]() {
+                rk1 = (k1 >= 0 && k1 < g.n) ? g.rowinfo[k1] : make_int2(0, 0);
+            });
+        } else {
+            if (un.x != -1 || it < total) row_ok(g, make_int2(-1, un.x), 35, (int)it, total);
+            rk1 = (k1 >= 0 && k1 < g.n) ? g.rowinfo[k1] : make_int2(0, 0);
         }
-        const int2 ru = g.rowinfo[u];
-        if (!row_ok(g, ru, 36, u, (int)it) || ru.y <= 0 || ru.y > H2_SMALL_DEG) continue;
-        h2s_node<L1, EXS, CLCAP>(g, u, ru, &sm[wid], rec, rt);
+        un = un1;
+        k = k1;
+        rk = rk1;
+        un1 = un2;
+        k1 = (unit_ok(un1) && lane < un1.w) ? g.col[un1.z + lane] : -1;
     }
+#ifdef H2_PROF
+    h2_wave_sync();
+    if (lane < 8) atomicAdd(&h2_prof[lane], sm[wid].prof[lane]);
+#endif
 }
 
 // =====================================================================================================================
@@ -458,6 +658,7 @@ template <int CAP>
 __device__ inline int h2_find(const unsigned *key, unsigned w) {
     const uint4 *tb = reinterpret_cast<const uint4 *>(key);
     unsigned b = h2_bucket<CAP>(w);
+#pragma unroll 1
     for (int walk = 0; walk < H2_WALK; ++walk) {  // (insertion never walks further than this)
         const uint4 e = tb[b];
         const int pos = h2_match(e, w);
@@ -474,6 +675,7 @@ template <int CAP>
 __device__ inline int h2_insert(unsigned *key, unsigned w) {
     const uint4 *tb = reinterpret_cast<const uint4 *>(key);
     unsigned b = h2_bucket<CAP>(w);
+#pragma unroll 1
     for (int walk = 0; walk < H2_WALK; ++walk) {  // (a longer walk: too full, treated as full)
         const uint4 e = tb[b];
         const int pos = h2_match(e, w);
@@ -542,6 +744,7 @@ __device__ inline unsigned h2_bloom_bit(unsigned long long key, int bits) {
 __device__ inline bool h2_eset_has(const H2EdgeSet es, int a, int b) {
     const unsigned long long key = h2_edge_key(a, b), mask = (1ull << es.bits) - 1ull;
     unsigned long long h = h2_eset_slot(key, es.bits);
+#pragma unroll 1
     for (unsigned long long walk = 0; walk <= mask; ++walk) {
         const unsigned long long k = es.tab[h];
         if (k == key) return true;
@@ -563,6 +766,7 @@ __global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int
     const unsigned bb = h2_bloom_bit(key, es.bloom_bits);
     atomicOr(&es.bloom[bb >> 5], 1u << (bb & 31u));
     unsigned long long h = h2_eset_slot(key, es.bits);
+#pragma unroll 1
     for (unsigned long long walk = 0; walk <= mask; ++walk) {
         const unsigned long long old = atomicCAS(&es.tab[h], H2_ESET_EMPTY, key);
         if (old == H2_ESET_EMPTY || old == key) return;
@@ -580,7 +784,8 @@ __global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int
 // LIST the work — per such edge a task {record slot, candidates (w, M - 1), partners} in device-memory pools — and one
 // dense kernel over all candidates of all tasks (k_h2_triangles) probes and publishes, spread over the whole chip.
 struct H2Tasks {
-    uint4 *task;   // {record slot, first partner, partners, node | 0x80000000 when listed by the retry launch}
+    uint4 *task;   // two per edge: {record slot, first partner, partners, node | 0x80000000 when listed by the retry launch},
+                   // {first candidate, candidates, -, -}
     int4 *cand;    // {w, M_u(w) - 1, task, unused}
     int32_t *part;
     int64_t task_cap, cand_cap, part_cap;
@@ -602,10 +807,17 @@ __device__ inline int h2_pool_grab(int32_t *counter, int n) {  // all lanes call
 __device__ inline void h2_void_candidates(const H2Tasks tk, int from, int to) {
     for (int64_t i = (int64_t)from + (threadIdx.x & 63); i < to && i < tk.cand_cap; i += 64) tk.cand[i] = make_int4(0, 0, -1, 0);
 }
+__device__ inline void h2_void_tasks(const H2Tasks tk, int from, int to) {
+    for (int64_t i = (int64_t)from + (threadIdx.x & 63); i < to && i < tk.task_cap; i += 64) {
+        tk.task[2 * i] = make_uint4(0u, 0u, 0u, 0u);
+        tk.task[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
 
 // nt tasks, nc candidates and np partners, each contiguous (all lanes call this; false: the pools are too small)
 __device__ inline bool h2_pool_reserve(const H2Tasks tk, H2Alloc &al, int nt, int nc, int np, int &t0, int &c0, int &p0) {
     if (al.t_end - al.t_cur < nt) {
+        h2_void_tasks(tk, al.t_cur, al.t_end);
         const int n = nt > H2_CHUNK_T ? nt : H2_CHUNK_T;
         al.t_cur = h2_pool_grab(&tk.res->h2_ntask, n);
         al.t_end = al.t_cur + n;
@@ -647,7 +859,10 @@ __device__ inline void h2_emit_task(const View &g, const H2Tasks tk, H2Alloc &al
     const unsigned long long below = (1ull << lane) - 1ull;
     int ti, c0, p0;
     if (!h2_pool_reserve(tk, al, 1, ncand, npart, ti, c0, p0)) return;
-    if (lane == 0) tk.task[ti] = make_uint4((unsigned)slot, (unsigned)p0, (unsigned)npart, (unsigned)u | tk.retry_flag);
+    if (lane == 0) {
+        tk.task[2 * ti] = make_uint4((unsigned)slot, (unsigned)p0, (unsigned)npart, (unsigned)u | tk.retry_flag);
+        tk.task[2 * ti + 1] = make_uint4((unsigned)c0, (unsigned)ncand, 0u, 0u);
+    }
     const int32_t *rowv = g.col + rv.x;
     int nc = 0, np = 0;  // running totals (uniform)
     for (int base = 0; base < rv.y; base += 64) {
@@ -683,7 +898,8 @@ __device__ inline void h2_emit_short(const View &g, const H2Tasks tk, H2Alloc &a
     const int ti = t0 + et;
     int ci = c0 + ec, pi = p0 + ep;
     const int cend = ci + ncand, pend = pi + npart;
-    tk.task[ti] = make_uint4((unsigned)slot, (unsigned)pi, (unsigned)npart, (unsigned)u | tk.retry_flag);
+    tk.task[2 * ti] = make_uint4((unsigned)slot, (unsigned)pi, (unsigned)npart, (unsigned)u | tk.retry_flag);
+    tk.task[2 * ti + 1] = make_uint4((unsigned)ci, (unsigned)ncand, 0u, 0u);
     for (int q0 = 0; q0 < rv.y; q0 += 8) {  // (eight loads in flight: a lane walks its row alone)
         int ww[8];
 #pragma unroll
@@ -778,39 +994,30 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
             sc->rowRev[lane] = -1;
         }
         h2_wave_sync();
-        h2_for_pieces(g.col, sc->desc, sc->poff, poff_lane, P, [&](const int4 w, unsigned vm, int r, int a) {
+        auto flags = [&](const int4 w, unsigned vm, int r, int a) -> unsigned {
             const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
-            unsigned f = 0u;
+            const unsigned isu = h2_eq4(kk, (unsigned)u) & vm;
+            if (PHASE == 2 && isu) sc->rowRev[r] = a + __ffs((int)isu) - 1;
+            unsigned valid = vm & ~isu;
+            // (third sweep: no partition test — a key of another partition is simply not in the table, and the flagged
+            //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole)
+            if (PARTS && PHASE != 2) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (!((vm >> jj) & 1u)) continue;
-                if (kk[jj] == (unsigned)u) {
-                    if (PHASE == 2) sc->rowRev[r] = a + jj;
-                    continue;
-                }
-                // (third sweep: no partition test — a key of another partition is simply not in the table, and the flagged
-                //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole)
-                if (PARTS && PHASE != 2 && h2_part(kk[jj], nparts) != part) continue;
-                const unsigned b = h2_bit<L1>(kk[jj]);
-                if (PHASE == 0) h2_mark(t.b1, t.b2, b);
-                else if (h2_again(t.b2, b)) f |= 1u << jj;
+                for (int jj = 0; jj < 4; ++jj)
+                    if (h2_part(kk[jj], nparts) != part) valid &= ~(1u << jj);
             }
-            if (PHASE == 0) return;
-            if (__ballot(f != 0u) == 0ull) return;  // uniform
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const bool p = (f >> jj) & 1u;
-                const unsigned long long m = __ballot(p);
-                if (m == 0ull) continue;  // uniform
-                if (qn > H2_QCAP - 64) h2_drain<L1, EXS, PHASE>(t, sc, qn);
-                if (p) {
-                    const int idx = qn + __popcll(m & below);
-                    sc->qw[idx] = kk[jj];
-                    if (PHASE == 2) sc->qr[idx] = (unsigned char)r;
-                }
-                qn += __popcll(m);
+            if (PHASE == 0) {
+                h2_mark4<L1>(t.b1, t.b2, kk, valid);
+                return 0u;
             }
-        });
+            return h2_again4<L1>(t.b2, kk, valid);
+        };
+        h2_for_pieces_queued(g.col, sc->desc, sc->poff, poff_lane, P, qn, flags,
+                             [&](int idx, unsigned key, int r) {
+                                 sc->qw[idx] = key;
+                                 if (PHASE == 2) sc->qr[idx] = (unsigned char)r;
+                             },
+                             [&]() { h2_drain<L1, EXS, PHASE>(t, sc, qn); });
         if (PHASE == 2) {
             h2_drain<L1, EXS, PHASE>(t, sc, qn);  // the row totals are read next
             int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
@@ -902,7 +1109,7 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
 
 // RETRY: the units come from the retry list (whose tables must not fill up again: the pass falls back then)
 template <int L1, int EXS, int NW, bool PARTS>
-__global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const int2 *units, const int32_t *count, int64_t unit_cap,
+__global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const int4 *units, const int32_t *count, int64_t unit_cap,
                                                        uint4 *rec, H2Retry rt, int is_retry) {
     __shared__ __attribute__((aligned(16))) unsigned bits[(1 << L1) / 32 + (1 << (L1 - 2)) / 32];
     __shared__ __attribute__((aligned(16))) unsigned key[EXS];
@@ -918,7 +1125,7 @@ __global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const 
     const H2Tab t{bits, bits + (1 << L1) / 32, key, cnt, &full};
     H2Alloc al;
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {  // every value steering the barriers is uniform
-        const int2 un = units[it];
+        const int4 un = units[it];
         const int u = un.x;
         const int nparts = PARTS ? (int)((unsigned)un.y >> 16) : 1, part = PARTS ? (un.y & 0xFFFF) : 0;
         bool ok = u >= 0 && u < g.n && nparts >= 1 && part < nparts;
@@ -940,11 +1147,45 @@ __global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const 
         }
     }
     h2_void_candidates(tk, al.c_cur, al.c_end);
+    h2_void_tasks(tk, al.t_cur, al.t_end);
 }
 
-// the listed (candidate, partner) pairs: a thread per candidate probes the edge set for each partner of its edge (eight
-// probes in flight) and adds its corrected count to the record of the edge; the candidates of an edge are adjacent, so a
-// wave whose lanes share one record reduces first
+// how many of the partners pt[0..np) are adjacent to w: one probe of the edge set per pair, eight in flight, most of
+// them settled by the edge bitmap
+__device__ inline int h2_probe_partners(const H2EdgeSet es, int w, const int32_t *pt, int np) {
+    int found = 0;
+    for (int j = 0; j < np; j += 8) {
+        int tt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tt[q] = j + q < np ? pt[j + q] : -1;
+        unsigned long long key[8], k0[8], h[8];
+        unsigned bw[8], bb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            key[q] = h2_edge_key(w, tt[q] < 0 ? w : tt[q]);
+            bb[q] = h2_bloom_bit(key[q], es.bloom_bits);
+            bw[q] = es.bloom[bb[q] >> 5];
+        }
+        // few pairs pass the bitmap; those that do read their home slot of the edge set together, not one after the other
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool maybe = tt[q] >= 0 && ((bw[q] >> (bb[q] & 31u)) & 1u);
+            h[q] = h2_eset_slot(key[q], es.bits);
+            k0[q] = maybe ? es.tab[h[q]] : H2_ESET_EMPTY;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bool hit = k0[q] == key[q];
+            if (!hit && k0[q] != H2_ESET_EMPTY) hit = h2_eset_has(es, w, tt[q]);  // (rare: the home slot is someone else's)
+            found += hit ? 1 : 0;
+        }
+    }
+    return found;
+}
+
+// the listed (candidate, partner) pairs: a thread per candidate probes the edge set for each partner of its edge
+// and adds its corrected count to the record of the edge; the candidates of an edge are adjacent, so lanes that share a
+// record reduce first
 __global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status) {
     if (*status != 0) return;
     const int total = tk.res->h2_ncand;
@@ -956,26 +1197,12 @@ __global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, 
         unsigned slot = 0xFFFFFFFFu;
         if (i < total) {
             const int4 cd = tk.cand[i];
-            const uint4 ts = cd.z >= 0 ? tk.task[cd.z] : make_uint4(0u, 0u, 0u, 0x80000000u);  // (void: the tail of a wave's chunk)
+            const uint4 ts = cd.z >= 0 ? tk.task[2 * (int64_t)cd.z] : make_uint4(0u, 0u, 0u, 0x80000000u);  // (void: the tail of a wave's chunk)
             // (a split node some partition of which failed is redone as a whole: what its other partitions listed is void)
-            const bool stale = !(ts.w & 0x80000000u) && ((unsigned)tk.weight[ts.w & 0x7FFFFFFFu] & 0x80000000u);
-            slot = (stale || cd.z < 0) ? 0xFFFFFFFFu : ts.x;
-            c = cd.z < 0 ? 0 : cd.y;
-            const int32_t *pt = tk.part + ts.y;
-            const int np = (stale || cd.z < 0) ? 0 : (int)ts.z;
-            for (int j = 0; j < np; j += 8) {
-                int tt[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) tt[q] = j + q < np ? pt[j + q] : -1;
-                unsigned bw[8], bb[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    bb[q] = h2_bloom_bit(h2_edge_key(cd.x, tt[q] < 0 ? cd.x : tt[q]), es.bloom_bits);
-                    bw[q] = es.bloom[bb[q] >> 5];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)  // (few pairs are adjacent, and few others pass the bitmap)
-                    if (tt[q] >= 0 && ((bw[q] >> (bb[q] & 31u)) & 1u) && h2_eset_has(es, cd.x, tt[q])) c -= 1;
+            const bool skip = cd.z < 0 || (!(ts.w & 0x80000000u) && ((unsigned)tk.weight[ts.w & 0x7FFFFFFFu] & 0x80000000u));
+            if (!skip) {
+                slot = ts.x;
+                c = cd.y - h2_probe_partners(es, cd.x, tk.part + ts.y, (int)ts.z);
             }
         }
         // the candidates of an edge are adjacent: one pair of atomics per run of equal record slots (segmented scan)
@@ -1030,7 +1257,7 @@ __global__ void __launch_bounds__(256) k_h2_weight(View g, int32_t *weight) {
 
 // ---- plan: class, partitions and weight bucket per node; units laid out heaviest bucket first inside each class -------
 struct H2Lists {
-    int2 *units[H2_CLASSES];
+    int4 *units[H2_CLASSES];  // {node, partitions << 16 | partition, row start, degree}
     int64_t cap[H2_CLASSES];
 };
 constexpr int H2_NB = H2_CLASSES * H2_WB;
@@ -1064,8 +1291,10 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
     if (threadIdx.x < H2_NB) blk_count[threadIdx.x] = 0;
     __syncthreads();
     int bkt = -1, cls = -1, wb = 0, nparts = 0;
+    int2 ru = make_int2(0, 0);
     if (u < g.n) {
-        const int d = g.rowinfo[u].y;
+        ru = g.rowinfo[u];
+        const int d = ru.y;
         if (d > 0 && d <= H2_MAXDEG) {
             h2_classify(d, weight[u], cls, wb, nparts);
             bkt = cls * H2_WB + wb;
@@ -1114,7 +1343,7 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
     if (bkt >= 0) {
         const int64_t first = (int64_t)blk_base[bkt] + my_off;
         if (nparts <= 65535 && first >= 0 && first + nunits <= L.cap[cls]) {
-            for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int2(u, (nparts << 16) | j);
+            for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int4(u, (nparts << 16) | j, ru.x, ru.y);
         } else if (nparts > 65535) {
             res->h2_status = 1;
         }  // (else: reported through h2_count / h2_status above)
@@ -1140,11 +1369,11 @@ __global__ void k_h2_clear(DevResult *res) {
 }
 
 // the records of the nodes on the retry list start from zero again (a split node's partitions add into them)
-__global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int2 *units, const int32_t *count, int64_t unit_cap, uint4 *rec) {
+__global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int4 *units, const int32_t *count, int64_t unit_cap, uint4 *rec) {
     const int total = *count;
     if (total <= 0 || total > unit_cap) return;
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
-        const int2 un = units[it];
+        const int4 un = units[it];
         if ((un.y & 0xFFFF) != 0 || un.x < 0 || un.x >= g.n) continue;
         const int2 ru = g.rowinfo[un.x];
         if (!row_ok(g, ru, 42, un.x, (int)it)) continue;
@@ -1224,7 +1453,7 @@ static int ensure_h2(dcr_graph *g) {
     // triangle step pools: tasks are edges (with the partitions of split nodes: a few times that), candidates and partners
     // adjacency entries of theirs
     // (sized for power-law graphs; a pass that needs more says how much — h2_grow_pools — and is run again)
-    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, std::max<int64_t>(g->cap_total / 2 + 4096, g->h2_want[0])));
+    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, 2 * std::max<int64_t>(g->cap_total / 2 + 4096, g->h2_want[0])));
     DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[1])));
     DCR_TRY(dev_regrow(&g->h2_part, &g->h2_part_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[2])));
     return DCR_OK;
@@ -1243,12 +1472,13 @@ static void launch_h2_small(dcr_graph *g, const View &vw, const H2Retry &rt, hip
     const int64_t units = g->h2_last_count[C] >= 0 ? (int64_t)g->h2_last_count[C] + g->h2_last_count[C] / 32 + 8 : g->n;
     if (grid > (units + H2_WPB - 1) / H2_WPB) grid = (units + H2_WPB - 1) / H2_WPB;  // small graphs: no idle workgroups
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_h2_small<h2_l1(C), h2_exs(C), h2_clcap(C), H2_WPB>), dim3((unsigned)grid), dim3(64 * H2_WPB), 0, st, vw,
+    constexpr int NP = h2_maxw(C) / 256 + 1;  // 64-piece steps: W / 4 pieces and at most one more per row (alignment)
+    hipLaunchKernelGGL((k_h2_small<h2_l1(C), h2_exs(C), h2_clcap(C), H2_WPB, NP>), dim3((unsigned)grid), dim3(64 * H2_WPB), 0, st, vw,
                        g->h2_units[C], &g->dres->h2_count[C], g->h2_units_cap[C], g->h2_rec, rt);
 }
 
 template <int C, bool PARTS>
-static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, const H2Retry &rt, const int2 *units,
+static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, const H2Retry &rt, const int4 *units,
                             const int32_t *count, int64_t cap, int64_t units_hint, int is_retry, hipStream_t st) {
     int64_t grid = units_hint;
     const int64_t most = (int64_t)g->num_cu * (C == 3 ? 3 : 1);
@@ -1274,7 +1504,7 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     }
     int32_t *status = &g->dres->h2_status;
     const H2Retry rt{g->h2_retry, g->h2_retry_cap, g->h2_weight, g->dres};
-    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, g->h2_task_cap, g->h2_cand_cap, g->h2_part_cap, g->dres, g->h2_weight, 0u};
+    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, g->h2_task_cap / 2, g->h2_cand_cap, g->h2_part_cap, g->dres, g->h2_weight, 0u};
     hipLaunchKernelGGL(k_h2_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
     const int64_t sblocks = (g->cap_total + 255) / 256;
@@ -1335,6 +1565,17 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     if (sblocks > 0) hipLaunchKernelGGL(k_h2_final, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status);
     DCR_HIP(hipGetLastError());
     static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;
+#ifdef H2_PROF
+    {
+        unsigned long long h[16];
+        DCR_HIP(hipStreamSynchronize(g->stream));
+        DCR_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(h2_prof), sizeof(h)));
+        fprintf(stderr, "[h2 prof] wave-Mcycles: clear %.1f; seed + prefix %.1f; piece rows + loads %.1f; sweep A (+ wait for the loads) %.1f; "
+                "sweep B + drains %.1f; step C + publish %.1f\n", h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6);
+        unsigned long long z[16] = {0};
+        DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_prof), z, sizeof(z)));
+    }
+#endif
     if (debug) {
         DevResult h;
         DCR_HIP(hipStreamSynchronize(g->stream));
@@ -1342,6 +1583,8 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         fprintf(stderr, "[h2] units per class %d %d %d %d %d, retry units %d, status %d, failed per class %d %d %d %d %d retry %d\n",
                 h.h2_count[0], h.h2_count[1], h.h2_count[2], h.h2_count[3], h.h2_count[4], h.h2_retry, h.h2_status, h.h2_failed[0],
                 h.h2_failed[1], h.h2_failed[2], h.h2_failed[3], h.h2_failed[4], h.h2_failed[5]);
+        fprintf(stderr, "[h2] triangle step: %d edges listed, %d candidates, %d partners (pool slots, chunk tails included)\n", h.h2_ntask,
+                h.h2_ncand, h.h2_npart);
     }
     return DCR_OK;
 }

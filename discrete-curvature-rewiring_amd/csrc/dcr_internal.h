@@ -140,7 +140,7 @@ struct dcr_graph {
 
     // two-hop pass (dcr_bfc_h2.hip)
     int32_t *h2_weight = nullptr;     // [n] sum of the neighbours' degrees
-    int2 *h2_units[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // per class {node, partitions << 16 | partition}
+    int4 *h2_units[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // per class {node, partitions << 16 | partition, row start, degree}
     int64_t h2_units_cap[5] = {0, 0, 0, 0, 0};
     uint4 *h2_task = nullptr;         // triangle step pools (dcr_bfc_h2.hip)
     int4 *h2_cand = nullptr;
@@ -149,7 +149,7 @@ struct dcr_graph {
     int64_t h2_want[3] = {0, 0, 0};   // pool sizes a pass asked for (tasks, candidates, partners)
     unsigned *h2_bloom = nullptr;     // one bit per edge (prefilter of the edge set)
     int h2_bloom_bits = 0;
-    int2 *h2_retry = nullptr;         // units of nodes whose tables filled up in their class (redone by the largest class)
+    int4 *h2_retry = nullptr;         // units of nodes whose tables filled up in their class (redone by the largest class)
     int64_t h2_retry_cap = 0;
     uint4 *h2_rec = nullptr;          // [cap_total] per directed slot {|sq| on the far side, max count, triangles, reverse slot}
     int64_t h2_rec_cap = 0;
