@@ -814,7 +814,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     DCR_TRY(sync_result(g));
     if (g->last_engine == 0) {
         for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
-        if (g->hres->h2_status == 2 && g->hres->misc[0] == 0 && h2_grow_pools(g)) {
+        for (int grow = 0; grow < 4 && g->hres->h2_status == 2 && g->hres->misc[0] == 0 && h2_grow_pools(g); ++grow) {
             // the pools of its triangle step were too small (dense neighbourhoods): run it again with what it asked for
             DCR_TRY(launch_curvature_pass(g, curv_type, false));
             if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));

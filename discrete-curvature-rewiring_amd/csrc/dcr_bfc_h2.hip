@@ -65,6 +65,7 @@ __host__ __device__ constexpr int h2_exs(int c) { return c == 0 ? 128 : c == 1 ?
 __host__ __device__ constexpr int h2_clcap(int c) { return c == 0 ? 192 : c == 1 ? 384 : 768; }
 __host__ __device__ constexpr int h2_waves(int c) { return c == 3 ? 4 : 16; }
 __host__ __device__ constexpr int h2_keycap(int c) { return c == 3 ? 2800 : 5500; }  // keys a block table takes (4-slot buckets)
+constexpr int H2_PLCAP = 192;              // triangle partners of one batch of rows kept in LDS (more: their rows are read again)
 constexpr int H2_WALK = 32;                // longest probe sequence of the exact tables
 
 __device__ inline void h2_wave_sync() {
@@ -337,7 +338,7 @@ __device__ inline void h2_retry_push(const H2Retry rt, int u, int d, int cls) { 
 }
 
 #ifdef H2_PROF  // diagnostic build (tools/build_variant.sh prof -DH2_PROF): wave-cycles per section of the wave classes
-__device__ unsigned long long h2_prof[16];
+__device__ unsigned long long h2_prof[32];
 #define H2_STAMP(i)                                                      \
     {                                                                    \
         const long long now_ = (long long)__builtin_amdgcn_s_memtime();  \
@@ -345,7 +346,7 @@ __device__ unsigned long long h2_prof[16];
         t_prof = now_;                                                   \
     }
 #else
-#define H2_STAMP(i)
+#define H2_STAMP(i) {}
 #endif
 // =====================================================================================================================
 // wave classes: a node of at most 64 neighbours, by one wave
@@ -700,6 +701,13 @@ struct H2Scratch {
     int rowT[64], rowPos[64], rowMx[64], rowRev[64];  // third-sweep accumulators per row of the batch
     unsigned qw[H2_QCAP];       // queued exact-path work: key ...
     unsigned char qr[H2_QCAP];  // ... and row of the batch
+    unsigned plt[H2_PLCAP];       // third sweep: the members of N(u) met in the rows of the batch (triangle partners) ...
+    unsigned char plr[H2_PLCAP];  // ... and the row each was met in
+    int pln;                      // how many (counting past the capacity)
+    unsigned char trank[64];      // rank of each row of the batch among the rows present (its task is tbase + rank)
+#ifdef H2_PROF
+    unsigned long long prof[16];
+#endif
 };
 
 // the LDS arrays of a unit
@@ -784,8 +792,8 @@ __global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int
 // LIST the work — per such edge a task {record slot, candidates (w, M - 1), partners} in device-memory pools — and one
 // dense kernel over all candidates of all tasks (k_h2_triangles) probes and publishes, spread over the whole chip.
 struct H2Tasks {
-    uint4 *task;   // two per edge: {record slot, first partner, partners, node | 0x80000000 when listed by the retry launch},
-                   // {first candidate, candidates, -, -}
+    uint4 *task;   // per row of a block-class unit: {record slot, first partner, partners (0xFFFFFFFF: nothing to correct, its
+                   // candidates are skipped), node | 0x80000000 when listed by the retry launch}
     int4 *cand;    // {w, M_u(w) - 1, task, unused}
     int32_t *part;
     int64_t task_cap, cand_cap, part_cap;
@@ -795,7 +803,7 @@ struct H2Tasks {
 };
 // Pool space is handed out in chunks per wave (a reservation per edge on three shared counters cost more than the whole
 // step: same-address atomics serialise); what a wave leaves of a candidate chunk is marked void.  All members are uniform.
-constexpr int H2_CHUNK_C = 256, H2_CHUNK_P = 128, H2_CHUNK_T = 16;
+constexpr int H2_CHUNK_C = 256, H2_CHUNK_P = 128, H2_CHUNK_T = 64;
 struct H2Alloc {
     int c_cur = 0, c_end = 0, p_cur = 0, p_end = 0, t_cur = 0, t_end = 0;
 };
@@ -807,11 +815,10 @@ __device__ inline int h2_pool_grab(int32_t *counter, int n) {  // all lanes call
 __device__ inline void h2_void_candidates(const H2Tasks tk, int from, int to) {
     for (int64_t i = (int64_t)from + (threadIdx.x & 63); i < to && i < tk.cand_cap; i += 64) tk.cand[i] = make_int4(0, 0, -1, 0);
 }
+constexpr unsigned H2_TASK_VOID = 0xFFFFFFFFu;
 __device__ inline void h2_void_tasks(const H2Tasks tk, int from, int to) {
-    for (int64_t i = (int64_t)from + (threadIdx.x & 63); i < to && i < tk.task_cap; i += 64) {
-        tk.task[2 * i] = make_uint4(0u, 0u, 0u, 0u);
-        tk.task[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int64_t i = (int64_t)from + (threadIdx.x & 63); i < to && i < tk.task_cap; i += 64)
+        tk.task[i] = make_uint4(0u, 0u, H2_TASK_VOID, 0u);
 }
 
 // nt tasks, nc candidates and np partners, each contiguous (all lanes call this; false: the pools are too small)
@@ -851,55 +858,31 @@ __device__ inline bool h2_pool_reserve(const H2Tasks tk, H2Alloc &al, int nt, in
     return true;
 }
 
-// one wave lists the edge to row v (record slot `slot`): ncand candidates and npart partners, as counted by the third sweep
+// Fallback when the partner list of a batch did not fit in LDS (rows of hubs: hundreds of partners each): the members of
+// N(u) in row v are read again, by one wave (long rows) or one LANE per row (rows of at most H2_SHORT_ROW entries).
 template <int L1, int EXS>
-__device__ inline void h2_emit_task(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 rv, int64_t slot, int ncand,
-                                    int npart, const H2Tab t) {
+__device__ inline void h2_partners_of_row(const View &g, const H2Tasks tk, int u, int2 rv, int p0, int npart, const H2Tab t) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    int ti, c0, p0;
-    if (!h2_pool_reserve(tk, al, 1, ncand, npart, ti, c0, p0)) return;
-    if (lane == 0) {
-        tk.task[2 * ti] = make_uint4((unsigned)slot, (unsigned)p0, (unsigned)npart, (unsigned)u | tk.retry_flag);
-        tk.task[2 * ti + 1] = make_uint4((unsigned)c0, (unsigned)ncand, 0u, 0u);
-    }
     const int32_t *rowv = g.col + rv.x;
-    int nc = 0, np = 0;  // running totals (uniform)
+    int np = 0;  // running total (uniform)
     for (int base = 0; base < rv.y; base += 64) {
         const int i = base + lane;
         const int w = i < rv.y ? rowv[i] : -1;
-        bool isC = false, isT = false;
-        int M = 0;
-        if (w >= 0 && w != u) {
-            M = h2_query<L1, EXS>(t, (unsigned)w, isT);
-            isC = !isT && M >= 2;
-        }
-        const unsigned long long mC = __ballot(isC), mT = __ballot(isT);
-        const int ic = nc + __popcll(mC & below), it = np + __popcll(mT & below);
-        if (isC && ic < ncand) tk.cand[c0 + ic] = make_int4(w, M - 1, ti, 0);
+        bool isT = false;
+        if (w >= 0 && w != u) (void)h2_query<L1, EXS>(t, (unsigned)w, isT);
+        const unsigned long long mT = __ballot(isT);
+        const int it = np + __popcll(mT & below);
         if (isT && it < npart) tk.part[p0 + it] = w;
-        nc += __popcll(mC);
         np += __popcll(mT);
     }
-    if (lane == 0 && (nc != ncand || np != npart)) row_ok(g, make_int2(-1, nc), 43, ncand, np);  // cannot happen
+    if (lane == 0 && np != npart) row_ok(g, make_int2(-1, np), 43, npart, u);  // cannot happen
 }
-
-// The same for up to 64 edges at once, a LANE per edge (rows of at most H2_SHORT_ROW entries: most of a hub's rows; a
-// wave per edge is ~4 us of dependent latency for a handful of entries).  `mine`: this lane has an edge to list.
 constexpr int H2_SHORT_ROW = 32;
 template <int L1, int EXS>
-__device__ inline void h2_emit_short(const View &g, const H2Tasks tk, H2Alloc &al, int u, bool mine, int2 rv, int64_t slot,
-                                     int ncand, int npart, const H2Tab t) {
-    int ec, ep, et;
-    const int C = h2_prefix(mine ? ncand : 0, ec), Pn = h2_prefix(mine ? npart : 0, ep), Tn = h2_prefix(mine ? 1 : 0, et);
-    int t0, c0, p0;
-    if (!h2_pool_reserve(tk, al, Tn, C, Pn, t0, c0, p0)) return;
-    if (!mine) return;
-    const int ti = t0 + et;
-    int ci = c0 + ec, pi = p0 + ep;
-    const int cend = ci + ncand, pend = pi + npart;
-    tk.task[2 * ti] = make_uint4((unsigned)slot, (unsigned)pi, (unsigned)npart, (unsigned)u | tk.retry_flag);
-    tk.task[2 * ti + 1] = make_uint4((unsigned)ci, (unsigned)ncand, 0u, 0u);
+__device__ inline void h2_partners_short(const View &g, const H2Tasks tk, int u, int2 rv, int p0, int npart, const H2Tab t) {
+    int pi = p0;
+    const int pend = p0 + npart;
     for (int q0 = 0; q0 < rv.y; q0 += 8) {  // (eight loads in flight: a lane walks its row alone)
         int ww[8];
 #pragma unroll
@@ -909,50 +892,90 @@ __device__ inline void h2_emit_short(const View &g, const H2Tasks tk, H2Alloc &a
             const int w = ww[q];
             if (w < 0 || w == u) continue;
             bool isT;
-            const int M = h2_query<L1, EXS>(t, (unsigned)w, isT);
+            (void)h2_query<L1, EXS>(t, (unsigned)w, isT);
             if (isT) {
                 if (pi < pend) tk.part[pi] = w;
                 ++pi;
-            } else if (M >= 2) {
-                if (ci < cend) tk.cand[ci] = make_int4(w, M - 1, ti, 0);
-                ++ci;
             }
         }
     }
-    if (ci != cend || pi != pend) row_ok(g, make_int2(-1, ci - cend), 43, ncand, pi - pend);  // cannot happen
+    if (pi != pend) row_ok(g, make_int2(-1, pi - pend), 43, npart, u);  // cannot happen
 }
 
 // ---- the three sweeps: the rows of the neighbours of u, in batches of 64 rows per wave -----------------------------------
 // the queued exact-path work of one wave: n is uniform and lives in a register
+// PHASE 2 also LISTS what the triangle step needs, on the spot (no row is read again for it): every candidate occurrence
+// (w outside N(u), c = M_u(w) - 1 > 0) goes to the device-memory pool with the task of its row (tbase + row: a task
+// per row of the batch, filled in when the batch is complete), every member of N(u) met (a triangle partner of its row)
+// to the batch's LDS list.
 template <int L1, int EXS, int PHASE>
-__device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n) {
+__device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Tasks tk, H2Alloc &al, int tbase) {
     const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
     h2_wave_sync();
+    int pln = PHASE == 2 ? sc->pln : 0;  // uniform
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        if (i >= n) continue;
-        const unsigned w = sc->qw[i];
+        const unsigned w = i < n ? sc->qw[i] : 0u;
         if (PHASE == 1) {
-            const int s = h2_insert<EXS>(t.key, w);
-            if (s < 0) *t.full = 1;
-            else h2_cnt_add(t.cnt, s);
+            if (i < n) {
+                const int s = h2_insert<EXS>(t.key, w);
+                if (s < 0) *t.full = 1;
+                else h2_cnt_add(t.cnt, s);
+            }
         } else {
-            const int s = h2_find<EXS>(t.key, w);
-            if (s >= 0) {
-                const int r = sc->qr[i];
-                const unsigned c16 = h2_cnt_get(t.cnt, s);
-                if (c16 & 0x8000u) {
-                    atomicAdd(&sc->rowT[r], 1);
-                } else {
-                    const int c = (int)(c16 & 0x7FFFu) - 1;
-                    if (c > 0) {
-                        atomicAdd(&sc->rowPos[r], 1);
-                        atomicMax(&sc->rowMx[r], c);
+            bool cand = false, partner = false;
+            int c = 0, r = 0;
+            if (i < n) {
+                const int s = h2_find<EXS>(t.key, w);
+                if (s >= 0) {
+                    r = sc->qr[i];
+                    const unsigned c16 = h2_cnt_get(t.cnt, s);
+                    if (c16 & 0x8000u) {
+                        atomicAdd(&sc->rowT[r], 1);
+                        partner = true;
+                    } else {
+                        c = (int)(c16 & 0x7FFFu) - 1;
+                        if (c > 0) {
+                            atomicAdd(&sc->rowPos[r], 1);
+                            atomicMax(&sc->rowMx[r], c);
+                            cand = true;
+                        }
                     }
                 }
             }
+            const unsigned long long mC = __ballot(cand), mT = __ballot(partner);
+            if (mC != 0ull && tbase >= 0) {  // uniform
+                const int nc = __popcll(mC);
+                if (al.c_end - al.c_cur < nc) {
+                    h2_void_candidates(tk, al.c_cur, al.c_end);
+                    al.c_cur = h2_pool_grab(&tk.res->h2_ncand, H2_CHUNK_C);
+                    al.c_end = al.c_cur + H2_CHUNK_C;
+                }
+                const int c0 = al.c_cur;
+                al.c_cur += nc;
+                if (c0 < 0 || (int64_t)c0 + nc > tk.cand_cap) {
+                    if (lane == 0) {
+                        if (c0 < 0) tk.res->h2_status = 1;
+                        else atomicCAS(&tk.res->h2_status, 0, 2);  // the pool is too small: the host grows it and runs the pass again
+                    }
+                } else if (cand) {
+                    tk.cand[c0 + __popcll(mC & below)] = make_int4((int)w, c, tbase + (int)sc->trank[r], 0);
+                }
+            }
+            if (mT != 0ull) {  // uniform
+                if (partner) {
+                    const int idx = pln + __popcll(mT & below);
+                    if (idx < H2_PLCAP) {
+                        sc->plt[idx] = w;
+                        sc->plr[idx] = (unsigned char)r;
+                    }
+                }
+                pln += __popcll(mT);
+            }
         }
     }
+    if (PHASE == 2 && lane == 0) sc->pln = pln;
     h2_wave_sync();
     n = 0;
 }
@@ -967,6 +990,10 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
     const int wid = (int)(threadIdx.x >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
     int qn = 0;  // queued items (uniform)
+#ifdef H2_PROF
+    long long t_prof = (long long)__builtin_amdgcn_s_memtime();
+    H2Scratch *s = sc;
+#endif
     for (int base = 0; base < ru.y; base += 64 * NW) {
         const int i = base + lane * NW + wid;
         int k = -1;
@@ -987,13 +1014,22 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
         sc->desc[lane] = rk;
         sc->poff[lane] = poff_lane;
         if (lane == 0) sc->poff[64] = P;
+        int tbase = -1, trow = 0;  // third sweep: the tasks of this batch's rows (tbase uniform; trow: this lane's row)
         if (PHASE == 2) {
             sc->rowT[lane] = 0;
             sc->rowPos[lane] = 0;
             sc->rowMx[lane] = 0;
             sc->rowRev[lane] = -1;
+            if (lane == 0) sc->pln = 0;
+            int dummy_c, dummy_p;
+            const unsigned long long rows = __ballot(k >= 0);  // a task per row of the batch
+            if (!h2_pool_reserve(tk, al, __popcll(rows), 0, 0, tbase, dummy_c, dummy_p)) tbase = -1;
+            trow = __popcll(rows & below);  // rank of this lane's row among them (the drain needs rank by row: sc->trank)
+            sc->trank[lane] = (unsigned char)trow;
+            trow += tbase;
         }
         h2_wave_sync();
+        if (PHASE == 2) H2_STAMP(8)
         auto flags = [&](const int4 w, unsigned vm, int r, int a) -> unsigned {
             const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
             const unsigned isu = h2_eq4(kk, (unsigned)u) & vm;
@@ -1017,36 +1053,58 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
                                  sc->qw[idx] = key;
                                  if (PHASE == 2) sc->qr[idx] = (unsigned char)r;
                              },
-                             [&]() { h2_drain<L1, EXS, PHASE>(t, sc, qn); });
+                             [&]() { h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, tbase); });
+        if (PHASE == 2) H2_STAMP(9)
         if (PHASE == 2) {
-            h2_drain<L1, EXS, PHASE>(t, sc, qn);  // the row totals are read next
+            h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, tbase);  // the row totals are read next
+            H2_STAMP(10)
             int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
             const int rev = sc->rowRev[lane];
-            // triangles AND positive counts: the counts of this edge still include the triangle partners.  The edge is
-            // listed for k_h2_triangles, which publishes its counts; here it contributes none
-            const bool listed = k >= 0 && T > 0 && pos > 0 && rev >= 0 && rev < g.cap_total;
-            const bool shortrow = listed && rk.y <= H2_SHORT_ROW;
-            unsigned long long todo = __ballot(listed && !shortrow);
+            // Triangles AND positive counts: the counts of this edge still include the triangle partners.  Its candidates
+            // are in the pool already (listed by the drain); its partners go there now and its task says where they are:
+            // k_h2_triangles publishes its counts, here it contributes none.  The tasks of all other rows are void.
+            bool listed = tbase >= 0 && k >= 0 && T > 0 && pos > 0 && rev >= 0 && rev < g.cap_total;
 #ifdef H2_NO_STEPC  // timing-only build (results wrong)
-            todo = 0;
-#else
-            if (__ballot(shortrow) != 0ull) {
-                h2_emit_short<L1, EXS>(g, tk, al, u, shortrow, rk, (int64_t)ru.x + i, pos, T, t);
-                if (shortrow) {
-                    pos = 0;
-                    mx = 0;
+            listed = false;
+#endif
+            int ep;
+            const int Pn = h2_prefix(listed ? T : 0, ep);
+            int p0 = 0;
+            if (Pn > 0) {  // uniform
+                int dummy_t, dummy_c;
+                if (!h2_pool_reserve(tk, al, 0, 0, Pn, dummy_t, dummy_c, p0)) listed = false;
+            }
+            if (__ballot(listed) != 0ull) {
+                const int pln = sc->pln;
+                if (pln <= H2_PLCAP) {
+                    // the partners were kept: each goes to the range of its row (sc->poff is free now: a cursor per row)
+                    sc->poff[lane] = listed ? p0 + ep : -1;
+                    h2_wave_sync();
+                    for (int j = lane; j < pln; j += 64) {
+                        const int r = sc->plr[j];
+                        if (sc->poff[r] >= 0) tk.part[atomicAdd(&sc->poff[r], 1)] = (int32_t)sc->plt[j];
+                    }
+                    h2_wave_sync();
+                } else {
+                    // too many for the list (rows of hubs): the rows are read again for their partners
+                    const bool shortrow = listed && rk.y <= H2_SHORT_ROW;
+                    if (shortrow) h2_partners_short<L1, EXS>(g, tk, u, rk, p0 + ep, T, t);
+                    unsigned long long todo = __ballot(listed && !shortrow);
+                    while (todo) {
+                        const int l = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int2 rv = make_int2(__shfl(rk.x, l), __shfl(rk.y, l));
+                        h2_partners_of_row<L1, EXS>(g, tk, u, rv, __shfl(p0 + ep, l), __shfl(T, l), t);
+                    }
                 }
             }
-#endif
-            while (todo) {
-                const int l = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int2 rv = make_int2(__shfl(rk.x, l), __shfl(rk.y, l));
-                h2_emit_task<L1, EXS>(g, tk, al, u, rv, (int64_t)ru.x + __shfl(i, l), __shfl(pos, l), __shfl(T, l), t);
-                if (lane == l) {
-                    pos = 0;
-                    mx = 0;
-                }
+            if (tbase >= 0 && k >= 0) {
+                tk.task[trow] = listed ? make_uint4((unsigned)(ru.x + i), (unsigned)(p0 + ep), (unsigned)T, (unsigned)u | tk.retry_flag)
+                                       : make_uint4(0u, 0u, H2_TASK_VOID, 0u);
+            }
+            if (listed) {
+                pos = 0;
+                mx = 0;
             }
             if (k >= 0) {
                 const int64_t slot = (int64_t)ru.x + i;
@@ -1066,8 +1124,9 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
             }
         }
         h2_wave_sync();  // the scratch is rewritten by the next batch
+        if (PHASE == 2) H2_STAMP(11)
     }
-    if (qn > 0) h2_drain<L1, EXS, PHASE>(t, sc, qn);  // (after the loop: a wave's last batches may be empty)
+    if (qn > 0) h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, -1);  // (after the loop: a wave's last batches may be empty; PHASE 1 only)
 }
 
 // one unit: node u, key partition `part` of `nparts`, by NW waves sharing the tables `t`; false: the table filled up
@@ -1076,6 +1135,10 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
                                const H2Tab t, H2Scratch *sc, uint4 *rec) {
     const int tid = (int)threadIdx.x;
     constexpr int NT = 64 * NW;
+#ifdef H2_PROF
+    long long t_prof = (long long)__builtin_amdgcn_s_memtime();
+    H2Scratch *s = sc;
+#endif
     {
         uint4 *z = reinterpret_cast<uint4 *>(t.b1);  // b1 and b2 are adjacent
         constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;
@@ -1097,13 +1160,17 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
         }
     }
     __syncthreads();
+    H2_STAMP(8 - 8 + (PARTS ? 4 : 0))
     h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec);
     __syncthreads();
+    H2_STAMP(1 + (PARTS ? 4 : 0))
     h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec);
     __syncthreads();
+    H2_STAMP(2 + (PARTS ? 4 : 0))
     const bool ok = *t.full == 0;  // uniform
     if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec);
     __syncthreads();  // the tables are rewritten by the next unit
+    H2_STAMP(3 + (PARTS ? 4 : 0))
     return ok;
 }
 
@@ -1124,6 +1191,9 @@ __global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const 
     }
     const H2Tab t{bits, bits + (1 << L1) / 32, key, cnt, &full};
     H2Alloc al;
+#ifdef H2_PROF
+    if ((threadIdx.x & 63) < 16) sc_all[wid].prof[threadIdx.x & 63] = 0ull;
+#endif
     for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {  // every value steering the barriers is uniform
         const int4 un = units[it];
         const int u = un.x;
@@ -1148,6 +1218,10 @@ __global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const 
     }
     h2_void_candidates(tk, al.c_cur, al.c_end);
     h2_void_tasks(tk, al.t_cur, al.t_end);
+#ifdef H2_PROF
+    h2_wave_sync();
+    if ((threadIdx.x & 63) < 16) atomicAdd(&h2_prof[8 + (threadIdx.x & 63)], sc_all[wid].prof[threadIdx.x & 63]);
+#endif
 }
 
 // how many of the partners pt[0..np) are adjacent to w: one probe of the edge set per pair, eight in flight, most of
@@ -1197,12 +1271,16 @@ __global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, 
         unsigned slot = 0xFFFFFFFFu;
         if (i < total) {
             const int4 cd = tk.cand[i];
-            const uint4 ts = cd.z >= 0 ? tk.task[2 * (int64_t)cd.z] : make_uint4(0u, 0u, 0u, 0x80000000u);  // (void: the tail of a wave's chunk)
+            const uint4 ts = (cd.z >= 0 && cd.z < tk.task_cap) ? tk.task[cd.z] : make_uint4(0u, 0u, H2_TASK_VOID, 0u);  // (void: the tail of a wave's chunk)
             // (a split node some partition of which failed is redone as a whole: what its other partitions listed is void)
-            const bool skip = cd.z < 0 || (!(ts.w & 0x80000000u) && ((unsigned)tk.weight[ts.w & 0x7FFFFFFFu] & 0x80000000u));
+            const bool skip = ts.z == H2_TASK_VOID || (!(ts.w & 0x80000000u) && ((unsigned)tk.weight[ts.w & 0x7FFFFFFFu] & 0x80000000u));
             if (!skip) {
                 slot = ts.x;
+#ifdef H2_NO_PROBE  // timing-only build (results wrong)
+                c = cd.y;
+#else
                 c = cd.y - h2_probe_partners(es, cd.x, tk.part + ts.y, (int)ts.z);
+#endif
             }
         }
         // the candidates of an edge are adjacent: one pair of atomics per run of equal record slots (segmented scan)
@@ -1417,9 +1495,10 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
 bool h2_grow_pools(dcr_graph *g) {
     const int64_t t = g->hres->h2_ntask, c = g->hres->h2_ncand, p = g->hres->h2_npart;
     if (t < 0 || c < 0 || p < 0) return false;  // the 31-bit counters wrapped: not a case for this engine
-    g->h2_want[0] = t + t / 4 + 4096;
-    g->h2_want[1] = c + c / 4 + 65536;
-    g->h2_want[2] = p + p / 4 + 65536;
+    // (a pass that ran out of one pool stopped listing into the others too: ask for twice what it counted)
+    g->h2_want[0] = std::max<int64_t>(g->h2_want[0], 2 * t + 4096);
+    g->h2_want[1] = std::max<int64_t>(g->h2_want[1], 2 * c + 65536);
+    g->h2_want[2] = std::max<int64_t>(g->h2_want[2], 2 * p + 65536);
     return true;
 }
 
@@ -1453,8 +1532,8 @@ static int ensure_h2(dcr_graph *g) {
     // triangle step pools: tasks are edges (with the partitions of split nodes: a few times that), candidates and partners
     // adjacency entries of theirs
     // (sized for power-law graphs; a pass that needs more says how much — h2_grow_pools — and is run again)
-    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, 2 * std::max<int64_t>(g->cap_total / 2 + 4096, g->h2_want[0])));
-    DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[1])));
+    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, std::max<int64_t>(g->cap_total + 4096, g->h2_want[0])));
+    DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, std::max<int64_t>(2 * g->cap_total + 65536, g->h2_want[1])));
     DCR_TRY(dev_regrow(&g->h2_part, &g->h2_part_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[2])));
     return DCR_OK;
 }
@@ -1504,22 +1583,11 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     }
     int32_t *status = &g->dres->h2_status;
     const H2Retry rt{g->h2_retry, g->h2_retry_cap, g->h2_weight, g->dres};
-    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, g->h2_task_cap / 2, g->h2_cand_cap, g->h2_part_cap, g->dres, g->h2_weight, 0u};
+    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, g->h2_task_cap, g->h2_cand_cap, g->h2_part_cap, g->dres, g->h2_weight, 0u};
     hipLaunchKernelGGL(k_h2_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
     const int64_t sblocks = (g->cap_total + 255) / 256;
     const H2EdgeSet es{g->h2_eset, g->h2_eset_bits, g->h2_bloom, g->h2_bloom_bits};
-    // the edge set (triangle step of the block classes) depends on the graph only: rebuilt on a stream of its own
-    // while weights and plan are computed
-    hipStream_t sa = serial ? g->stream : g->aux;
-    if (!serial) {
-        DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        DCR_HIP(hipStreamWaitEvent(sa, g->ev_fork, 0));
-    }
-    DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, sa));
-    DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), sa));
-    if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, sa, vw, es, status);
-    if (!serial) DCR_HIP(hipEventRecord(g->ev_aux, sa));
     DCR_HIP(hipMemsetAsync(g->h2_weight, 0, sizeof(int32_t) * (size_t)(g->n > 0 ? g->n : 1), g->stream));
     if (sblocks > 0) hipLaunchKernelGGL(k_h2_weight, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_weight);
     const int64_t pblocks = (g->n + H2_PLAN_THREADS - 1) / H2_PLAN_THREADS;
@@ -1541,6 +1609,10 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         s2 = g->side[3];
         s3 = g->side[2];  // (the low-priority stream: the finest-grained kernel)
     }
+    // The edge set (probed by k_h2_triangles only) is rebuilt on a stream of its own beside the class kernels.  (Beside
+    // weights and plan, which are short and on the critical path, its 32 MB memset and 1 M atomics tripled their time.)
+    hipStream_t sa = serial ? g->stream : g->aux;
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sa, g->ev_fork, 0));
     // the block classes first (the longest units), then the wave classes
     const int64_t hint4 = g->h2_last_count[4] >= 0 ? (int64_t)g->h2_last_count[4] + 8 : g->num_cu;
     const int64_t hint3 = g->h2_last_count[3] >= 0 ? (int64_t)g->h2_last_count[3] + 8 : 3 * (int64_t)g->num_cu;
@@ -1549,6 +1621,10 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     launch_h2_small<2>(g, vw, rt, s0);
     launch_h2_small<1>(g, vw, rt, s1);
     launch_h2_small<0>(g, vw, rt, s3);
+    DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, sa));
+    DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), sa));
+    if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, sa, vw, es, status);
+    if (!serial) DCR_HIP(hipEventRecord(g->ev_aux, sa));
     if (!serial) {
         for (int b = 0; b < 4; ++b) {
             DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
@@ -1567,12 +1643,17 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;
 #ifdef H2_PROF
     {
-        unsigned long long h[16];
+        unsigned long long h[32];
         DCR_HIP(hipStreamSynchronize(g->stream));
         DCR_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(h2_prof), sizeof(h)));
         fprintf(stderr, "[h2 prof] wave-Mcycles: clear %.1f; seed + prefix %.1f; piece rows + loads %.1f; sweep A (+ wait for the loads) %.1f; "
                 "sweep B + drains %.1f; step C + publish %.1f\n", h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5] / 1e6);
-        unsigned long long z[16] = {0};
+        fprintf(stderr, "[h2 prof] block classes, wave-Mcycles: M: clear + seed %.1f; sweep A %.1f; sweep B %.1f; sweep C + listing %.1f | "
+                "L: clear + seed %.1f; sweep A %.1f; sweep B %.1f; sweep C + listing %.1f\n", h[8] / 1e6, h[9] / 1e6, h[10] / 1e6,
+                h[11] / 1e6, h[12] / 1e6, h[13] / 1e6, h[14] / 1e6, h[15] / 1e6);
+        fprintf(stderr, "[h2 prof] sweep C of both block classes: batch set-up %.1f; pieces + drains %.1f; last drain %.1f; batch end %.1f\n",
+                h[16] / 1e6, h[17] / 1e6, h[18] / 1e6, h[19] / 1e6);
+        unsigned long long z[32] = {0};
         DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_prof), z, sizeof(z)));
     }
 #endif
@@ -1583,8 +1664,8 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         fprintf(stderr, "[h2] units per class %d %d %d %d %d, retry units %d, status %d, failed per class %d %d %d %d %d retry %d\n",
                 h.h2_count[0], h.h2_count[1], h.h2_count[2], h.h2_count[3], h.h2_count[4], h.h2_retry, h.h2_status, h.h2_failed[0],
                 h.h2_failed[1], h.h2_failed[2], h.h2_failed[3], h.h2_failed[4], h.h2_failed[5]);
-        fprintf(stderr, "[h2] triangle step: %d edges listed, %d candidates, %d partners (pool slots, chunk tails included)\n", h.h2_ntask,
-                h.h2_ncand, h.h2_npart);
+        fprintf(stderr, "[h2] triangle step: %d tasks, %d candidates, %d partners (pool slots, chunk tails included; pools %lld %lld %lld)\n",
+                h.h2_ntask, h.h2_ncand, h.h2_npart, (long long)g->h2_task_cap, (long long)g->h2_cand_cap, (long long)g->h2_part_cap);
     }
     return DCR_OK;
 }

@@ -1021,11 +1021,18 @@ int dcr_sdrf_tail_at_pass_argmin(dcr_graph *g, int64_t cand_index, int do_remove
     DCR_TRY(tail_prepare(g, -2, -2, do_remove, removal_bound, &tc));
     for (int attempt = 0; attempt < 2; ++attempt) {
         DCR_TRY(tail_enqueue(g, tc, attempt == 0));
-        if (attempt == 0) g->max_deg_bound++;  // the pass below sizes its launches by this upper bound: count the add in
+        // the pass below sizes its launches by this upper bound (which class kernels run at all): count the pending add in,
+        // on the replay too — relayout() has just reset the bound to the exact maximum BEFORE the add
+        g->max_deg_bound++;
         const int rc = dcr_curvature_pass_argmin(g, curv_type, incremental, out_u, out_v, out_val);  // synchronises
-        if (attempt == 0) g->max_deg_bound--;  // (tail_finish counts it once the add is known to have happened)
+        g->max_deg_bound--;  // (tail_finish counts it once the add is known to have happened)
         if (g->hres->add_status != 1) {
-            DCR_TRY(rc);
+            if (rc != DCR_OK) {
+                // the edit did happen on the device (the result block is from a completed synchronisation unless the
+                // failure was the HIP call itself): keep the host's edge count and degree bound in step before reporting
+                if (rc != DCR_EHIP) tail_finish(g, tc, out_removed, nullptr, false);
+                return rc;
+            }
             break;
         }
         if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
