@@ -980,6 +980,95 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Ta
     n = 0;
 }
 
+// third sweep, start of a batch of rows: row accumulators, partner list, a task per row present
+__device__ inline void h2_batch_begin(const H2Tasks tk, H2Alloc &al, H2Scratch *sc, int k, int &tbase, int &trow) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    sc->rowT[lane] = 0;
+    sc->rowPos[lane] = 0;
+    sc->rowMx[lane] = 0;
+    sc->rowRev[lane] = -1;
+    if (lane == 0) sc->pln = 0;
+    int dummy_c, dummy_p;
+    const unsigned long long rows = __ballot(k >= 0);  // a task per row of the batch
+    if (!h2_pool_reserve(tk, al, __popcll(rows), 0, 0, tbase, dummy_c, dummy_p)) tbase = -1;
+    trow = __popcll(rows & below);  // rank of this lane's row among them (the drain needs rank by row: sc->trank)
+    sc->trank[lane] = (unsigned char)trow;
+    trow += tbase;
+}
+
+// third sweep, end of a batch (the queue is drained): partners to the pool, tasks, records.  i: this lane's position in
+// row u; k, rk: its member of N(u) and that one's row
+template <int L1, int EXS, bool PARTS>
+__device__ inline void h2_batch_end(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int i, int k, int2 rk, int tbase,
+                                    int trow, int part, const H2Tab t, H2Scratch *sc, uint4 *rec) {
+    const int lane = threadIdx.x & 63;
+    int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
+    const int rev = sc->rowRev[lane];
+    // Triangles AND positive counts: the counts of this edge still include the triangle partners.  Its candidates
+    // are in the pool already (listed by the drain); its partners go there now and its task says where they are:
+    // k_h2_triangles publishes its counts, here it contributes none.  The tasks of all other rows are void.
+    bool listed = tbase >= 0 && k >= 0 && T > 0 && pos > 0 && rev >= 0 && rev < g.cap_total;
+#ifdef H2_NO_STEPC  // timing-only build (results wrong)
+    listed = false;
+#endif
+    int ep;
+    const int Pn = h2_prefix(listed ? T : 0, ep);
+    int p0 = 0;
+    if (Pn > 0) {  // uniform
+        int dummy_t, dummy_c;
+        if (!h2_pool_reserve(tk, al, 0, 0, Pn, dummy_t, dummy_c, p0)) listed = false;
+    }
+    if (__ballot(listed) != 0ull) {
+        const int pln = sc->pln;
+        if (pln <= H2_PLCAP) {
+            // the partners were kept: each goes to the range of its row (sc->poff is free now: a cursor per row)
+            sc->poff[lane] = listed ? p0 + ep : -1;
+            h2_wave_sync();
+            for (int j = lane; j < pln; j += 64) {
+                const int r = sc->plr[j];
+                if (sc->poff[r] >= 0) tk.part[atomicAdd(&sc->poff[r], 1)] = (int32_t)sc->plt[j];
+            }
+            h2_wave_sync();
+        } else {
+            // too many for the list (rows of hubs): the rows are read again for their partners
+            const bool shortrow = listed && rk.y <= H2_SHORT_ROW;
+            if (shortrow) h2_partners_short<L1, EXS>(g, tk, u, rk, p0 + ep, T, t);
+            unsigned long long todo = __ballot(listed && !shortrow);
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int2 rv = make_int2(__shfl(rk.x, l), __shfl(rk.y, l));
+                h2_partners_of_row<L1, EXS>(g, tk, u, rv, __shfl(p0 + ep, l), __shfl(T, l), t);
+            }
+        }
+    }
+    if (tbase >= 0 && k >= 0) {
+        tk.task[trow] = listed ? make_uint4((unsigned)(ru.x + i), (unsigned)(p0 + ep), (unsigned)T, (unsigned)u | tk.retry_flag)
+                               : make_uint4(0u, 0u, H2_TASK_VOID, 0u);
+    }
+    if (listed) {
+        pos = 0;
+        mx = 0;
+    }
+    if (k >= 0) {
+        const int64_t slot = (int64_t)ru.x + i;
+        if (rev < 0 || rev >= g.cap_total) {
+            row_ok(g, make_int2(-1, rev), 33, u, k);  // adjacency not symmetric: report, never publish
+        } else if (!PARTS) {
+            rec[slot] = make_uint4((unsigned)pos, (unsigned)mx, (unsigned)T, (unsigned)rev);
+        } else {
+            unsigned *r4 = reinterpret_cast<unsigned *>(rec + slot);
+            if (pos) atomicAdd(&r4[0], (unsigned)pos);
+            if (mx) atomicMax(&r4[1], (unsigned)mx);
+            if (part == 0) {  // the flagged neighbours live in every partition's table: T and the slot are whole
+                r4[2] = (unsigned)T;
+                r4[3] = (unsigned)rev;
+            }
+        }
+    }
+}
+
 // Wave `wid` of NW takes the rows i = wid, wid + NW, ... of row u (strided: a hub's heaviest rows, adjacent at the
 // front of its row, spread over the waves); lane l of the batch starting at `base` stands for row base + l * NW + wid.
 // PHASE 0: bitmaps; 1: occurrences of the repeated keys; 2: per-row statistics, triangle step, records.
@@ -1015,19 +1104,7 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
         sc->poff[lane] = poff_lane;
         if (lane == 0) sc->poff[64] = P;
         int tbase = -1, trow = 0;  // third sweep: the tasks of this batch's rows (tbase uniform; trow: this lane's row)
-        if (PHASE == 2) {
-            sc->rowT[lane] = 0;
-            sc->rowPos[lane] = 0;
-            sc->rowMx[lane] = 0;
-            sc->rowRev[lane] = -1;
-            if (lane == 0) sc->pln = 0;
-            int dummy_c, dummy_p;
-            const unsigned long long rows = __ballot(k >= 0);  // a task per row of the batch
-            if (!h2_pool_reserve(tk, al, __popcll(rows), 0, 0, tbase, dummy_c, dummy_p)) tbase = -1;
-            trow = __popcll(rows & below);  // rank of this lane's row among them (the drain needs rank by row: sc->trank)
-            sc->trank[lane] = (unsigned char)trow;
-            trow += tbase;
-        }
+        if (PHASE == 2) h2_batch_begin(tk, al, sc, k, tbase, trow);
         h2_wave_sync();
         if (PHASE == 2) H2_STAMP(8)
         auto flags = [&](const int4 w, unsigned vm, int r, int a) -> unsigned {
@@ -1058,75 +1135,161 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
         if (PHASE == 2) {
             h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, tbase);  // the row totals are read next
             H2_STAMP(10)
-            int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
-            const int rev = sc->rowRev[lane];
-            // Triangles AND positive counts: the counts of this edge still include the triangle partners.  Its candidates
-            // are in the pool already (listed by the drain); its partners go there now and its task says where they are:
-            // k_h2_triangles publishes its counts, here it contributes none.  The tasks of all other rows are void.
-            bool listed = tbase >= 0 && k >= 0 && T > 0 && pos > 0 && rev >= 0 && rev < g.cap_total;
-#ifdef H2_NO_STEPC  // timing-only build (results wrong)
-            listed = false;
-#endif
-            int ep;
-            const int Pn = h2_prefix(listed ? T : 0, ep);
-            int p0 = 0;
-            if (Pn > 0) {  // uniform
-                int dummy_t, dummy_c;
-                if (!h2_pool_reserve(tk, al, 0, 0, Pn, dummy_t, dummy_c, p0)) listed = false;
-            }
-            if (__ballot(listed) != 0ull) {
-                const int pln = sc->pln;
-                if (pln <= H2_PLCAP) {
-                    // the partners were kept: each goes to the range of its row (sc->poff is free now: a cursor per row)
-                    sc->poff[lane] = listed ? p0 + ep : -1;
-                    h2_wave_sync();
-                    for (int j = lane; j < pln; j += 64) {
-                        const int r = sc->plr[j];
-                        if (sc->poff[r] >= 0) tk.part[atomicAdd(&sc->poff[r], 1)] = (int32_t)sc->plt[j];
-                    }
-                    h2_wave_sync();
-                } else {
-                    // too many for the list (rows of hubs): the rows are read again for their partners
-                    const bool shortrow = listed && rk.y <= H2_SHORT_ROW;
-                    if (shortrow) h2_partners_short<L1, EXS>(g, tk, u, rk, p0 + ep, T, t);
-                    unsigned long long todo = __ballot(listed && !shortrow);
-                    while (todo) {
-                        const int l = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1;
-                        const int2 rv = make_int2(__shfl(rk.x, l), __shfl(rk.y, l));
-                        h2_partners_of_row<L1, EXS>(g, tk, u, rv, __shfl(p0 + ep, l), __shfl(T, l), t);
-                    }
-                }
-            }
-            if (tbase >= 0 && k >= 0) {
-                tk.task[trow] = listed ? make_uint4((unsigned)(ru.x + i), (unsigned)(p0 + ep), (unsigned)T, (unsigned)u | tk.retry_flag)
-                                       : make_uint4(0u, 0u, H2_TASK_VOID, 0u);
-            }
-            if (listed) {
-                pos = 0;
-                mx = 0;
-            }
-            if (k >= 0) {
-                const int64_t slot = (int64_t)ru.x + i;
-                if (rev < 0 || rev >= g.cap_total) {
-                    row_ok(g, make_int2(-1, rev), 33, u, k);  // adjacency not symmetric: report, never publish
-                } else if (!PARTS) {
-                    rec[slot] = make_uint4((unsigned)pos, (unsigned)mx, (unsigned)T, (unsigned)rev);
-                } else {
-                    unsigned *r4 = reinterpret_cast<unsigned *>(rec + slot);
-                    if (pos) atomicAdd(&r4[0], (unsigned)pos);
-                    if (mx) atomicMax(&r4[1], (unsigned)mx);
-                    if (part == 0) {  // the flagged neighbours live in every partition's table: T and the slot are whole
-                        r4[2] = (unsigned)T;
-                        r4[3] = (unsigned)rev;
-                    }
-                }
-            }
+            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
         }
         h2_wave_sync();  // the scratch is rewritten by the next batch
         if (PHASE == 2) H2_STAMP(11)
     }
     if (qn > 0) h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, -1);  // (after the loop: a wave's last batches may be empty; PHASE 1 only)
+}
+
+// A unit whose rows fit one batch (at most 64 per wave) and whose pieces fit NPB per lane: rows, descriptors and pieces
+// are read ONCE and stay in registers for all three sweeps (the streaming version pays the chain unit -> row of u -> rows'
+// descriptors -> pieces three times, with a handful of pieces per wave to hide it behind).  false: does not fit (decided
+// before anything is written; the caller streams).  `ok` is set like h2_node's return value.
+constexpr int H2_NPB = 12;
+template <int L1, int EXS, int NW, bool PARTS>
+__device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
+                                    const H2Tab t, H2Scratch *sc, uint4 *rec, bool &ok) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NT = 64 * NW, NP = H2_NPB;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (ru.y > 64 * NW) return false;  // uniform
+    const int i = lane * NW + wid;
+    int k = -1;
+    int2 rk = make_int2(0, 0);
+    if (i < ru.y) {
+        k = g.col[ru.x + i];
+        if (k >= 0 && k < g.n && k != u) {
+            rk = g.rowinfo[k];
+            if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
+        } else {
+            k = -1;
+        }
+    }
+    const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
+    int poff_lane;
+    const int P = h2_prefix(np, poff_lane);
+    if (__syncthreads_or(P > 64 * NP)) return false;  // some wave's share is too long for the registers
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(t.b1);  // b1 and b2 are adjacent
+        constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;
+        for (int j = tid; j < NZ; j += NT) z[j] = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *k4 = reinterpret_cast<uint4 *>(t.key);
+        for (int j = tid; j < EXS / 4; j += NT) k4[j] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
+        uint4 *c4 = reinterpret_cast<uint4 *>(t.cnt);
+        for (int j = tid; j < EXS / 8; j += NT) c4[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) *t.full = 0;
+    }
+    sc->desc[lane] = rk;
+    sc->poff[lane] = poff_lane;
+    if (lane == 0) sc->poff[64] = P;
+    h2_wave_sync();
+    // every piece of this wave's rows: meta = entries inside the row | those of this unit's key partition << 4 | row << 8 |
+    // first slot of the piece << 16
+    int4 w[NP];
+    unsigned long long meta[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int j = 64 * q + lane;
+        w[q] = make_int4(0, 0, 0, 0);
+        meta[q] = 0ull;
+        const int jf = 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+        if (jf >= P) continue;  // uniform
+        const int r = h2_piece_row(sc->poff, poff_lane, j < P ? j : jl, jf, jl);
+        if (j < P) {
+            const int2 d = sc->desc[r];
+            const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
+            w[q] = load_piece(g.col, a);
+            meta[q] = (unsigned long long)h2_piece_mask(a, d.x, d.x + d.y) | ((unsigned long long)r << 8) | ((unsigned long long)(unsigned)a << 16);
+        }
+    }
+    __syncthreads();  // the tables are cleared
+    if (k >= 0) {     // the members of N(u): flagged table entries (in every partition's tables)
+        const int sl = h2_insert<EXS>(t.key, (unsigned)k);
+        if (sl < 0) *t.full = 1;
+        else h2_cnt_flag(t.cnt, sl);
+        h2_seed(t.b1, t.b2, h2_bit<L1>((unsigned)k));
+    }
+    __syncthreads();
+    // sweep A
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        if (64 * q >= P) continue;  // uniform
+        const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+        unsigned valid = (unsigned)meta[q] & 0xFu & ~h2_eq4(kk, (unsigned)u);
+        if (PARTS) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (h2_part(kk[jj], nparts) != part) valid &= ~(1u << jj);
+        }
+        meta[q] |= (unsigned long long)valid << 4;
+        h2_mark4<L1>(t.b1, t.b2, kk, valid);
+    }
+    __syncthreads();
+    // sweeps B and C: flagged entries are queued, the drain has one call site per sweep
+    int qn = 0, tbase = -1, trow = 0;
+#pragma unroll 1
+    for (int phase = 1; phase <= 2; ++phase) {
+        unsigned fl[NP];
+        if (phase == 2) h2_batch_begin(tk, al, sc, k, tbase, trow);
+        h2_wave_sync();
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            fl[q] = 0u;
+            if (64 * q >= P) continue;  // uniform
+            const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+            unsigned valid = (unsigned)(meta[q] >> 4) & 0xFu;
+            if (phase == 2) {
+                // (third sweep: no partition test — a key of another partition is simply not in the table, and the flagged
+                //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole)
+                const unsigned vm = (unsigned)meta[q] & 0xFu, isu = h2_eq4(kk, (unsigned)u) & vm;
+                if (isu) sc->rowRev[(int)((meta[q] >> 8) & 0xFFull)] = (int)(meta[q] >> 16) + __ffs((int)isu) - 1;
+                valid = vm & ~isu;
+            }
+            fl[q] = h2_again4<L1>(t.b2, kk, valid);
+        }
+#pragma unroll 1
+        while (true) {
+            bool stop = false;  // uniform: the queue is full, the rest waits for the drain
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (64 * q >= P) continue;  // uniform
+                const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const bool p = (fl[q] >> jj) & 1u;
+                    const unsigned long long m = __ballot(p);
+                    if (m == 0ull) continue;  // uniform
+                    if (stop || qn + __popcll(m) > H2_QCAP) {
+                        stop = true;
+                        continue;
+                    }
+                    if (p) {
+                        const int idx = qn + __popcll(m & below);
+                        sc->qw[idx] = kk[jj];
+                        sc->qr[idx] = (unsigned char)((meta[q] >> 8) & 0xFFull);
+                        fl[q] &= ~(1u << jj);
+                    }
+                    qn += __popcll(m);
+                }
+            }
+            if (qn > 0) {
+                if (phase == 1) h2_drain<L1, EXS, 1>(t, sc, qn, tk, al, -1);
+                else h2_drain<L1, EXS, 2>(t, sc, qn, tk, al, tbase);
+            }
+            if (!stop) break;
+        }
+        if (phase == 1) {
+            __syncthreads();
+            ok = *t.full == 0;  // uniform
+            if (!ok) break;
+        } else {
+            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
+        }
+    }
+    __syncthreads();  // the tables are rewritten by the next unit
+    return true;
 }
 
 // one unit: node u, key partition `part` of `nparts`, by NW waves sharing the tables `t`; false: the table filled up
@@ -1135,6 +1298,12 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
                                const H2Tab t, H2Scratch *sc, uint4 *rec) {
     const int tid = (int)threadIdx.x;
     constexpr int NT = 64 * NW;
+#ifndef H2_NO_FAST
+    if constexpr (!PARTS) {  // (with 16 waves per unit the registers it needs spill: measured slower for the split class)
+        bool ok_fast = true;
+        if (h2_node_fast<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, sc, rec, ok_fast)) return ok_fast;
+    }
+#endif
 #ifdef H2_PROF
     long long t_prof = (long long)__builtin_amdgcn_s_memtime();
     H2Scratch *s = sc;
@@ -1260,12 +1429,17 @@ __device__ inline int h2_probe_partners(const H2EdgeSet es, int w, const int32_t
 // the listed (candidate, partner) pairs: a thread per candidate probes the edge set for each partner of its edge
 // and adds its corrected count to the record of the edge; the candidates of an edge are adjacent, so lanes that share a
 // record reduce first
-__global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status) {
+// Launched twice: `second` = 0 as soon as the block classes have finished (beside the wave classes, which list nothing),
+// for the candidates there are then; `second` = 1 after the retry launch for what that one listed.  (The split is read
+// from / left in the result block: h2_ncand_done is only written by the kernel that marks the first launch's end.)
+__global__ void k_h2_triangles_mark(DevResult *res) { res->h2_ncand_done = res->h2_ncand; }
+__global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status, int second) {
     if (*status != 0) return;
-    const int total = tk.res->h2_ncand;
-    if (total <= 0 || total > tk.cand_cap) return;  // (beyond the pool: the pass is run again with larger pools)
+    const int first = second ? tk.res->h2_ncand_done : 0;
+    const int total = second ? tk.res->h2_ncand : tk.res->h2_ncand_done;
+    if (total <= first || first < 0 || total > tk.cand_cap) return;  // (beyond the pool: the pass is run again with larger pools)
     const int lane = threadIdx.x & 63;
-    for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll; base < total; base += (int64_t)gridDim.x * 256) {
+    for (int64_t base = first + (((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll); base < total; base += (int64_t)gridDim.x * 256) {
         const int64_t i = base + lane;
         int c = 0;
         unsigned slot = 0xFFFFFFFFu;
@@ -1600,44 +1774,57 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     // records of split nodes are accumulated with atomics: start from zero
     hipLaunchKernelGGL(k_h2_retry_zero, dim3(64), dim3(256), 0, g->stream, vw, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4],
                        g->h2_rec);
-    hipStream_t s0 = g->stream, s1 = g->stream, s2 = g->stream, s3 = g->stream;
+    // Streams: the block classes (long units; the triangle step waits for them only) on two high-priority streams, the
+    // wave classes on three low-priority ones, the edge set on a stream of its own, the triangle step on a fourth
+    // high-priority stream as soon as block classes and edge set are done — beside the wave classes, which list nothing.
+    hipStream_t sL = g->stream, sM = g->stream, sS2 = g->stream, sS1 = g->stream, sS0 = g->stream, sT = g->stream, sa = g->stream;
     if (!serial) {
+        // (the split class stays on the main stream, launched first: its workgroups need most of a CU's LDS and find no
+        //  CU free once the other kernels are resident — measured: started 60 us late, finished last)
+        sM = g->side[1];
+        sT = g->side[3];
+        sS2 = g->low[0];
+        sS1 = g->low[1];
+        sS0 = g->side[2];
+        sa = g->aux;
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        for (int b = 0; b < 4; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
-        s0 = g->side[0];
-        s1 = g->side[1];
-        s2 = g->side[3];
-        s3 = g->side[2];  // (the low-priority stream: the finest-grained kernel)
+        for (hipStream_t st : {sM, sS2, sS1, sS0, sa}) DCR_HIP(hipStreamWaitEvent(st, g->ev_fork, 0));
     }
-    // The edge set (probed by k_h2_triangles only) is rebuilt on a stream of its own beside the class kernels.  (Beside
-    // weights and plan, which are short and on the critical path, its 32 MB memset and 1 M atomics tripled their time.)
-    hipStream_t sa = serial ? g->stream : g->aux;
-    if (!serial) DCR_HIP(hipStreamWaitEvent(sa, g->ev_fork, 0));
-    // the block classes first (the longest units), then the wave classes
     const int64_t hint4 = g->h2_last_count[4] >= 0 ? (int64_t)g->h2_last_count[4] + 8 : g->num_cu;
     const int64_t hint3 = g->h2_last_count[3] >= 0 ? (int64_t)g->h2_last_count[3] + 8 : 3 * (int64_t)g->num_cu;
-    launch_h2_block<4, true>(g, vw, tk, rt, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4], hint4, 0, g->stream);
-    launch_h2_block<3, false>(g, vw, tk, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, s2);
-    launch_h2_small<2>(g, vw, rt, s0);
-    launch_h2_small<1>(g, vw, rt, s1);
-    launch_h2_small<0>(g, vw, rt, s3);
+    launch_h2_block<4, true>(g, vw, tk, rt, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4], hint4, 0, sL);
+    launch_h2_block<3, false>(g, vw, tk, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, sM);
+    launch_h2_small<2>(g, vw, rt, sS2);
+    launch_h2_small<1>(g, vw, rt, sS1);
+    launch_h2_small<0>(g, vw, rt, sS0);
+    // the edge set (probed by k_h2_triangles only).  (Beside weights and plan, which are short and on the critical path,
+    // its 32 MB memset and 1 M atomics tripled their time.)
     DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, sa));
     DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), sa));
     if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, sa, vw, es, status);
-    if (!serial) DCR_HIP(hipEventRecord(g->ev_aux, sa));
     if (!serial) {
-        for (int b = 0; b < 4; ++b) {
-            DCR_HIP(hipEventRecord(g->ev_join[b], g->side[b]));
-            DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[b], 0));
-        }
+        DCR_HIP(hipEventRecord(g->ev_aux, sa));
+        DCR_HIP(hipEventRecord(g->ev_join[0], sL));
+        DCR_HIP(hipEventRecord(g->ev_join[1], sM));
+        DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[0], 0));
+        DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[1], 0));
+        DCR_HIP(hipStreamWaitEvent(sT, g->ev_aux, 0));
+    }
+    hipLaunchKernelGGL(k_h2_triangles_mark, dim3(1), dim3(1), 0, sT, g->dres);
+    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sT, es, tk, g->h2_rec, status, 0);
+    if (!serial) {
+        DCR_HIP(hipEventRecord(g->ev_join[3], sT));
+        DCR_HIP(hipEventRecord(g->ev_join[2], sS0));
+        DCR_HIP(hipEventRecord(g->ev_aux2, sS1));
+        DCR_HIP(hipEventRecord(g->ev_fork, sS2));
+        for (hipEvent_t ev : {g->ev_join[3], g->ev_join[2], g->ev_aux2, g->ev_fork}) DCR_HIP(hipStreamWaitEvent(g->stream, ev, 0));
     }
     // nodes whose tables filled up in their class: zero their records, redo them with worst-case partitions
     hipLaunchKernelGGL(k_h2_retry_zero, dim3(64), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
                        g->h2_rec);
     tk.retry_flag = 0x80000000u;
     launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
-    if (!serial) DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_aux, 0));  // the edge set is probed from here on only
-    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status);
+    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 2)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status, 1);
     if (sblocks > 0) hipLaunchKernelGGL(k_h2_final, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status);
     DCR_HIP(hipGetLastError());
     static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;

@@ -390,6 +390,8 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
         DCR_HIP(hipStreamCreateWithPriority(&g->side[b], hipStreamNonBlocking, b == 2 ? prio_low : prio_high));
         DCR_HIP(hipEventCreateWithFlags(&g->ev_join[b], hipEventDisableTiming));
     }
+    for (int b = 0; b < 2; ++b) DCR_HIP(hipStreamCreateWithPriority(&g->low[b], hipStreamNonBlocking, prio_low));
+    DCR_HIP(hipEventCreateWithFlags(&g->ev_aux2, hipEventDisableTiming));
     DCR_TRY(dev_alloc(&g->rowinfo, n));
     DCR_TRY(dev_alloc(&g->rowcap, n));
     DCR_TRY(alloc_layout(g, tot));
@@ -441,6 +443,9 @@ int dcr_graph_destroy(dcr_graph *g) {
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_aux) (void)hipEventDestroy(g->ev_aux);
     if (g->aux) (void)hipStreamDestroy(g->aux);
+    for (int b = 0; b < 2; ++b)
+        if (g->low[b]) (void)hipStreamDestroy(g->low[b]);
+    if (g->ev_aux2) (void)hipEventDestroy(g->ev_aux2);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);

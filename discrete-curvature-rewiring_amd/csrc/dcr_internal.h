@@ -71,6 +71,7 @@ struct DevResult {
     int32_t h2_count[5];
     int32_t h2_failed[6];  // diagnostic: nodes whose tables filled up, per class (5: on the retry list itself)
     int32_t h2_ntask, h2_ncand, h2_npart;  // triangle step: listed edges, candidates, partners
+    int32_t h2_ncand_done;                 // candidates the first k_h2_triangles launch has taken
     int32_t h2_retry;   // units on the retry list (nodes whose tables filled up in their class, redone by the largest class)
     int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels)
 };
@@ -204,6 +205,8 @@ struct dcr_graph {
     hipEvent_t ev_fork = nullptr;
     hipStream_t aux = nullptr;   // two-hop pass: the edge set is rebuilt here while the plan runs
     hipEvent_t ev_aux = nullptr;
+    hipStream_t low[2] = {nullptr, nullptr};  // low priority (with side[2]): the fine-grained kernels of the two-hop pass
+    hipEvent_t ev_aux2 = nullptr;
     hipEvent_t ev_join[dcr::NBINS - 1] = {nullptr, nullptr, nullptr, nullptr};
     int num_cu = 0;
 
