@@ -826,7 +826,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
             // a table of the two-hop pass filled up (keys of a split node hashed unevenly) or a unit list overflowed:
             // nothing it wrote is kept, the node-centric kernels redo the whole pass
             const int keep = g->pass_impl;
-            g->pass_impl = 0;
+            g->pass_impl = 2;
             const int rc = launch_curvature_pass(g, curv_type, false);
             g->pass_impl = keep;
             DCR_TRY(rc);

@@ -1677,7 +1677,15 @@ bool h2_grow_pools(dcr_graph *g) {
 }
 
 bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental) {
-    return g->pass_impl == 3 && curv_type == DCR_CURV_BFC && !incremental && g->max_deg_bound <= H2_MAXDEG && g->cap_total < (int64_t)1 << 31;
+    if (curv_type != DCR_CURV_BFC || incremental || g->max_deg_bound > H2_MAXDEG || g->cap_total >= (int64_t)1 << 30) return false;
+    if (g->pass_impl == 3) return true;
+    // automatic: this engine pays off while a node's 2-hop neighbourhood (sum of its neighbours' degrees, on average
+    // sum d^2 / n) is a small part of the graph, so that few of its keys repeat; on small dense graphs nearly all do, the
+    // wave classes' tables fill up and the nodes are redone one class up (measured, tools/probe_engines.py, pass ms
+    // node-centric / two-hop: 2,485 nodes x 2: 0.27 / 0.20; 2,500 x 10: 0.46 / 3.1; 10,000 x 10: 0.52 / 1.5; 30,000 x 10:
+    // 0.77 / 0.75; 100,000 x 10: 1.94 / 1.36; 300,000 x 10: 5.6 / 3.6)
+    static const double max_share = getenv("DCR_H2_MAX_SHARE") ? atof(getenv("DCR_H2_MAX_SHARE")) : 0.03;
+    return g->pass_impl == 0 && g->n > 0 && g->sum_deg2 <= max_share * (double)g->n * (double)g->n;
 }
 
 static int ensure_h2(dcr_graph *g) {

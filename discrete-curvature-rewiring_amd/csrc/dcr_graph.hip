@@ -373,8 +373,9 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     g->n_edges = (int64_t)keep.size();
     for (int64_t u = 0; u < n; ++u)
         if (deg[(size_t)u] > g->max_deg_bound) g->max_deg_bound = deg[(size_t)u];
+    for (int64_t u = 0; u < n; ++u) g->sum_deg2 += (double)deg[(size_t)u] * (double)deg[(size_t)u];
     if (const char *impl = getenv("DCR_PASS"))
-        g->pass_impl = (std::string(impl) == "edge") ? 1 : (std::string(impl) == "h2") ? 3 : 0;
+        g->pass_impl = (std::string(impl) == "edge") ? 1 : (std::string(impl) == "nc" || std::string(impl) == "node") ? 2 : (std::string(impl) == "h2") ? 3 : 0;
     *out = g;  // caller destroys on failure
     DCR_HIP(hipStreamCreate(&g->stream));
     DCR_HIP(hipEventCreate(&g->ev0));

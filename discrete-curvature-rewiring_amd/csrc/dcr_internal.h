@@ -134,8 +134,11 @@ struct dcr_graph {
     int32_t *nc_queues = nullptr;  // dequeue cursors of the two wave-class kernels, one cache line each
     uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
     int64_t nc_touch_cap = 0;
+    double sum_deg2 = 0.0;        // sum of squared degrees when the graph was created (engine choice: size of the 2-hop neighbourhoods)
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
-    int pass_impl = 0;            // 0: node-centric (default); 1: edge-centric kernels only (DCR_PASS=edge); 3: two-hop
+    int pass_impl = 0;            // 0: automatic (default: two-hop kernels for full Balanced Forman passes of graphs large enough to
+                                  // pay for their fixed cost, node-centric otherwise); 1: edge-centric kernels only (DCR_PASS=edge);
+                                  // 2: node-centric (DCR_PASS=nc); 3: two-hop
                                   // kernels for full Balanced Forman passes, node-centric otherwise (DCR_PASS=h2)
     int last_engine = -1;         // which implementation ran the last pass: 0 two-hop, 1 edge-centric, 2 node-centric
 

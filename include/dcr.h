@@ -123,9 +123,10 @@ int dcr_sdrf_tail(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remove, dou
 int dcr_sdrf_tail_at(dcr_graph *g, int64_t cand_index, int do_remove, double removal_bound, int32_t out_added[2],
                      int32_t out_removed[2], double *out_max_val);
 
-/* Which implementation ran the last curvature pass: 2 node-centric kernels (csrc/dcr_bfc_nc.hip, the default), 1 edge-centric
- * kernels (DCR_PASS=edge when the graph is created), 0 two-hop kernels (csrc/dcr_bfc_h2.hip, DCR_PASS=h2, full Balanced
- * Forman passes only); -1 before the first pass.  All three produce the same bits. */
+/* Which implementation ran the last curvature pass: 0 two-hop kernels (csrc/dcr_bfc_h2.hip: full Balanced Forman passes of
+ * graphs whose 2-hop neighbourhoods are a small part of the graph — the default there — or always with DCR_PASS=h2 when the
+ * graph is created), 2 node-centric kernels (csrc/dcr_bfc_nc.hip: everything else, or DCR_PASS=nc), 1 edge-centric kernels
+ * (DCR_PASS=edge); -1 before the first pass.  All three produce the same bits. */
 int dcr_pass_engine(dcr_graph *g, int *out);
 
 /* dcr_sdrf_tail_at followed by dcr_curvature_pass_argmin of the NEXT iteration (sdrf_no_cuda.py:51,56-66 then :24,:27) with

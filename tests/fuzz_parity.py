@@ -59,7 +59,7 @@ while time.time() < t_end:
         continue
     n_graphs += 1
     C = c_oracle.CGraph(ei, n)
-    for impl in ('node', 'edge'):
+    for impl in ('nc', 'edge'):
         os.environ['DCR_PASS'] = impl
         G = DcrGraph(ei, n)
         os.environ.pop('DCR_PASS')

@@ -533,7 +533,7 @@ def test_two_pass_implementations_agree_at_scale(dcr):
     from dcr import synthetic
     ei, nn = synthetic.powerlaw_graph(300000, 10, seed=4242)
     out = {}
-    for impl in ('node', 'edge'):
+    for impl in ('nc', 'edge'):
         os.environ['DCR_PASS'] = impl
         try:
             G = dcr(ei, nn)
@@ -541,7 +541,7 @@ def test_two_pass_implementations_agree_at_scale(dcr):
             os.environ.pop('DCR_PASS', None)
         out[impl] = [G.curvature_all(ct)[2] for ct in ('bfc', 'augmented')]
         del G
-    for a, b in zip(out['node'], out['edge']):
+    for a, b in zip(out['nc'], out['edge']):
         assert a.shape[0] == ei.shape[1] // 2 and np.array_equal(a, b)
 
 

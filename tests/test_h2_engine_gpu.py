@@ -1,6 +1,7 @@
-"""The alternative curvature-pass engine (csrc/dcr_bfc_h2.hip, selected with DCR_PASS=h2 when the graph is created):
-row u of A.A as an LDS hash map instead of per-edge neighbourhood streaming.  Same bits as the default engine, the CPU
-oracle and the reference's fixtures (curvature/bfc_naive.py:7-40)."""
+"""The two-hop curvature-pass engine (csrc/dcr_bfc_h2.hip; the default for full Balanced Forman passes of graphs whose 2-hop
+neighbourhoods are a small part of the graph, forced here with DCR_PASS=h2 when the graph is created): row u of A.A from
+Bloom bitmaps and an exact table of the repeated keys instead of per-edge neighbourhood streaming.  Same bits as the
+node-centric engine, the CPU oracle and the reference's fixtures (curvature/bfc_naive.py:7-40)."""
 import numpy as np
 import pytest
 
@@ -83,8 +84,9 @@ def test_engines_agree_on_the_bench_graph_and_after_edits(h2graph, monkeypatch):
     from dcr.graph import DcrGraph
     ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
     H = h2graph(ei, n)
-    monkeypatch.delenv('DCR_PASS')
+    monkeypatch.setenv('DCR_PASS', 'nc')
     D = DcrGraph(ei, n)
+    monkeypatch.delenv('DCR_PASS')
     rng = np.random.Generator(np.random.PCG64(3))
     for rnd in range(3):
         hu, hv, hc = H.curvature_all('bfc')
@@ -102,3 +104,29 @@ def test_engines_agree_on_the_bench_graph_and_after_edits(h2graph, monkeypatch):
             if D.has_edge(a, b):
                 H.remove_edge(a, b)
                 D.remove_edge(a, b)
+
+
+def test_automatic_engine_choice(monkeypatch):
+    """Without DCR_PASS the two-hop kernels take the full Balanced Forman passes of sparse graphs, the node-centric ones
+    small dense graphs (where nearly every 2-hop key repeats), every incremental pass and the classical curvatures."""
+    from dcr import synthetic
+    from dcr.graph import DcrGraph
+    monkeypatch.delenv('DCR_PASS', raising=False)
+    ei, n = synthetic.powerlaw_graph(20000, 4, seed=5)
+    G = DcrGraph(ei, n)
+    G.curvature_pass('bfc')
+    assert G.pass_engine() == 'two-hop'
+    G.curvature_pass('augmented')
+    assert G.pass_engine() == 'node-centric'
+    ei, n = synthetic.powerlaw_graph(1500, 12, seed=2)
+    G = DcrGraph(ei, n)
+    G.curvature_pass('bfc')
+    assert G.pass_engine() == 'node-centric'
+
+
+def test_dense_neighbourhoods_are_redone_one_class_up(h2graph):
+    """Small dense graph under the forced engine: the wave classes' tables fill up, the nodes go to the retry list and are
+    redone by the largest class with worst-case partitions; the pools of the triangle step grow on demand."""
+    from dcr import synthetic
+    ei, n = synthetic.powerlaw_graph(2500, 10, seed=11)
+    _check_against_oracle(h2graph(ei, n), ei, n)
