@@ -48,7 +48,8 @@ namespace dcr {
 
 constexpr unsigned H2_EMPTY = 0xFFFFFFFFu;
 constexpr unsigned H2_NBR = 0x80000000u;  // on a key of the small classes' EX: member of N(u) (node ids stay below 2^30)
-constexpr int H2_MAXDEG = 4094;           // flagged neighbours live in every partition's table (5,500 keys in the largest class)
+constexpr int H2_MAXDEG = 5000;           // flagged neighbours live in every partition's table (5,500 keys in the largest class:
+                                          // a hub near the limit is split into many partitions, one workgroup each)
 constexpr int H2_CLASSES = 5;             // 0-2: one wave per node (<= 64 neighbours), 3-4: one workgroup per unit
 constexpr int H2_WB = 4;                  // weight buckets per class (units are laid out heaviest bucket first)
 constexpr int H2_SMALL_DEG = 64;

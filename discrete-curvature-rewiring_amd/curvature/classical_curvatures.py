@@ -12,7 +12,70 @@ from dcr.graph import DcrGraph, curv_code
 CURV_TYPES = ('1d', 'augmented', 'haantjes', 'bfc')
 
 
-def as_dcr_graph(G, device=0):
+# A networkx.Graph handed to these functions is uploaded ONCE and then mirrored: the reference's loop calls
+# compute_curvature_edge twice per candidate with an add_edge / remove_edge in between (sdrf_no_cuda.py:41-46), and an
+# upload per call is O(E) host work per candidate.  The graph object is switched to a subclass of its own class whose
+# add_edge / remove_edge repeat the edit on the device copy (both containers append to the ends of the two rows and
+# delete in place: same adjacency order); every other mutating method drops the copy, which is then rebuilt at the next
+# call.  Edits that bypass the methods (writing into G.adj / G._adj directly) are not seen: pass refresh=True then.
+_MIRRORS = None      # WeakKeyDictionary: networkx graph -> [DcrGraph or None]
+_MIRROR_CLASS = {}   # networkx class -> its mirroring subclass
+
+
+def _mirror_class(cls):
+    if cls in _MIRROR_CLASS:
+        return _MIRROR_CLASS[cls]
+
+    def _drop(self):
+        m = _MIRRORS.get(self)
+        if m is not None:
+            m[0] = None
+
+    def add_edge(self, u, v, **attr):
+        m = _MIRRORS.get(self)
+        live = m is not None and m[0] is not None
+        if live and (u == v or u not in self._adj or v not in self._adj):
+            m[0], live = None, False          # new node or self-loop: rebuilt at the next call
+        fresh = live and v not in self._adj[u]
+        cls.add_edge(self, u, v, **attr)
+        if fresh:
+            m[0].add_edge(int(u), int(v))
+
+    def remove_edge(self, u, v):
+        m = _MIRRORS.get(self)
+        cls.remove_edge(self, u, v)           # raises NetworkXError for a missing edge, before the copy is touched
+        if m is not None and m[0] is not None:
+            if u == v:
+                m[0] = None
+            else:
+                m[0].remove_edge(int(u), int(v))
+
+    def _dropping(name):
+        base = getattr(cls, name)
+
+        def method(self, *a, **k):
+            _drop(self)
+            return base(self, *a, **k)
+        method.__name__ = name
+        return method
+
+    body = {'add_edge': add_edge, 'remove_edge': remove_edge, '__reduce_ex__': lambda self, proto: _reduce_plain(self, cls, proto)}
+    for name in ('add_node', 'add_nodes_from', 'remove_node', 'remove_nodes_from', 'add_edges_from', 'add_weighted_edges_from',
+                 'remove_edges_from', 'update', 'clear', 'clear_edges'):
+        if hasattr(cls, name):
+            body[name] = _dropping(name)
+    sub = type('Mirrored' + cls.__name__, (cls,), body)
+    _MIRROR_CLASS[cls] = sub
+    return sub
+
+
+def _reduce_plain(self, cls, proto):
+    # pickles and deep copies are plain graphs of the original class (a copy has no device mirror)
+    state = dict(self.__dict__)
+    return (cls.__new__, (cls,), state)
+
+
+def as_dcr_graph(G, device=0, refresh=False):
     """``G`` as a device-resident graph whose adjacency rows are in the SAME order as ``G.adj[u]`` for every node, so
     that ``G.edges`` order, and with it every first-extremum tie-break (sdrf_no_cuda.py:27,59,61), is networkx's.
 
@@ -20,9 +83,31 @@ def as_dcr_graph(G, device=0):
     of one edge-insertion sequence; that sequence is recovered here by merging the rows (an edge is emitted once it is
     the next one in the rows of both its endpoints) and replayed into the container.  Node labels must be 0..n-1 in
     insertion order, as curvature/bfc_naive.py:34-37 (positional rows of ``nx.adj_matrix``) needs them too.
+
+    A ``networkx.Graph`` is uploaded once and mirrored afterwards (see above); ``refresh=True`` uploads again.
     """
     if isinstance(G, DcrGraph):
         return G
+    global _MIRRORS
+    if _MIRRORS is None:
+        import weakref
+        _MIRRORS = weakref.WeakKeyDictionary()
+    m = _MIRRORS.get(G)
+    if m is not None and m[0] is not None and not refresh:
+        return m[0]
+    g = _upload(G, device)
+    try:
+        import networkx as nx
+        if type(G) is nx.Graph or type(G) in _MIRROR_CLASS.values():
+            if type(G) is nx.Graph:
+                G.__class__ = _mirror_class(nx.Graph)
+            _MIRRORS[G] = [g]
+    except ImportError:
+        pass
+    return g
+
+
+def _upload(G, device=0):
     import numpy as np
     n = G.number_of_nodes()
     if list(G.nodes) != list(range(n)):
@@ -35,6 +120,8 @@ def as_dcr_graph(G, device=0):
         u = stack.pop()
         while nxt[u] < len(rows[u]):
             v = rows[u][nxt[u]]
+            if not 0 <= v < n or nxt[v] >= len(rows[v]):
+                break           # rows that are not symmetric (a DiGraph, a hand-built adjacency): reported below
             if rows[v][nxt[v]] != u:
                 break           # (u, v) waits for earlier edges of v; v's turn will come back to it
             nxt[u] += 1

@@ -1,8 +1,11 @@
 """Row-partitioned data-parallel GCN — one process per GPU, RCCL over xGMI.
 
-The reference trains on one device; this is the multi-GPU path BASELINE.json asks for.  Nodes are split into P
-contiguous blocks.  Rank p holds its block of X, y, the masks and the rows of Â = D^-1/2 (A+I) D^-1/2 that belong to
-its nodes (all columns); the weights are replicated.  Per layer:
+The reference trains on one device; this is the multi-GPU path BASELINE.json asks for.  Nodes are dealt to the P ranks
+by degree (the node of s-th largest degree goes to rank s mod P: ``balanced_partition``), so every rank holds the same
+number of nodes AND of non-zeros of Â within a fraction of a per cent — contiguous blocks of ids gave rank 0 of 8 a
+third of the non-zeros of a preferential-attachment graph, whose early ids are the hubs (2.7 x the ideal share: the
+aggregations, the set-up Â_p·X and with them the whole step waited for that rank).  Rank p holds its nodes' rows of X,
+y, the masks and of Â = D^-1/2 (A+I) D^-1/2 (all columns, renumbered rank-major); the weights are replicated.  Per layer:
 
     Z_p = H_p · Wᵀ                      local GEMM (matrix cores)
     Z   = all_gather(Z_p)               the one exchange step of the layer      [backward: reduce_scatter]
@@ -25,6 +28,18 @@ def block_range(n, world, rank):
     per = (n + world - 1) // world
     r0 = min(rank * per, n)
     return r0, min(r0 + per, n), per
+
+
+def balanced_partition(edge_index, num_nodes, world):
+    """Deal the nodes to ``world`` ranks by degree: ``order`` = node ids by decreasing degree (ties: smaller id), rank p
+    owns order[p::world].  Returns (owner rank, index inside the owner's block, nodes per rank incl. padding), the first
+    two as int64 tensors over the node ids.  Deterministic: every rank computes the same partition from the edge list."""
+    deg = torch.bincount(edge_index[0].reshape(-1), minlength=num_nodes)[:num_nodes]
+    order = torch.sort(-deg, stable=True).indices
+    pos = torch.empty_like(order)
+    pos[order] = torch.arange(num_nodes, device=order.device)
+    per = (num_nodes + world - 1) // world
+    return pos % world, pos // world, per
 
 
 class _GatherRows(torch.autograd.Function):
@@ -109,12 +124,21 @@ class ShardedGCN(torch.nn.Module):
         super().__init__()
         self.gcn = gcn
         self.group = group
-        self.n = int(num_nodes)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.r0, self.r1, self.per = block_range(self.n, self.world, self.rank)
+        # Nodes are renumbered rank-major: node v -> owner(v) * per + index(v).  Blocks are padded to ``per`` nodes each;
+        # a padding id is an isolated node with zero features, outside every mask: it changes nothing and keeps every
+        # rank's block, gather and reduce-scatter the same size.
+        owner, index, self.per = balanced_partition(edge_index, int(num_nodes), self.world)
+        self.n_real = int(num_nodes)
+        self.n = self.world * self.per
+        self.r0, self.r1 = self.rank * self.per, (self.rank + 1) * self.per
+        new_id = owner * self.per + index
+        mine = (owner == self.rank).nonzero().squeeze(1)
+        self.owned = mine[torch.sort(index[mine]).indices]   # this rank's nodes (original ids) in block order
         # rows of Â owned by this rank; normalisation uses the full graph's degrees
-        self.csr = gcn_norm_csr(edge_index, None, self.n, add_self_loops=True, row_range=(self.r0, self.r1))
+        self.csr = gcn_norm_csr(new_id[edge_index], None, self.n, add_self_loops=True, row_range=(self.r0, self.r1))
+        self.nnz_local = int(self.csr.col.shape[0])
         for p in self.gcn.parameters():  # replicate rank 0's initialisation
             dist.broadcast(p.data, src=0, group=group)
         # One flat gradient buffer for the whole model, every parameter's .grad a view into it: backward accumulates in
@@ -128,7 +152,20 @@ class ShardedGCN(torch.nn.Module):
             off += p.numel()
 
     def shard(self, t):
-        return t[self.r0:self.r1]
+        """This rank's rows of a per-node tensor (original node order), in block order, zero-padded to ``per`` rows."""
+        mine = t.index_select(0, self.owned.to(t.device))
+        if mine.shape[0] == self.per:
+            return mine.contiguous()
+        pad = torch.zeros((self.per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:mine.shape[0]] = mine
+        return pad
+
+    def nnz_shares(self):
+        """Non-zeros of Â per rank as a fraction of the ideal share 1 / P (list over ranks; a collective)."""
+        t = torch.zeros(self.world, dtype=torch.float64, device=self.csr.col.device)
+        t[self.rank] = float(self.nnz_local)
+        dist.all_reduce(t, group=self.group)
+        return (t / t.sum() * self.world).tolist()
 
     def forward(self, x_local):
         h = x_local

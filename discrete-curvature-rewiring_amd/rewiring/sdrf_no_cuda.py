@@ -128,6 +128,7 @@ class SdrfRun:
         self.trace = trace
         self.G = DcrGraph.from_data(data, device=device)
         self._next_argmin = None  # (x, y) of the pass already run for the coming iteration (see step)
+        self.last = (None, None, None)  # (x, y, candidates) of the last iteration (bench.py: bytes of the improvement step)
 
     def step(self, more=True):
         """One iteration.  ``more``: another iteration will follow (the default; ``sdrf_no_cuda`` passes False for the last
@@ -165,6 +166,7 @@ class SdrfRun:
                     rec['candidates'] = np.stack([ci, cj], 1).tolist()
                     rec['improvements'] = imp.tolist()
                     rec['choice'] = idx
+        self.last = (x, y, int(n_cand))
         if want_trace and not n_cand:
             rec.update(candidates=[], improvements=[], choice=None)
 

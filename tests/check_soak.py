@@ -1,6 +1,6 @@
-"""GPU-box checker (not collected by pytest): a long SDRF run on the north-star graph, full recompute against the
-incremental pass, final edge lists compared; then the final graph's full pass against the C oracle on sampled edges.
-Usage: ITERS=3000 python tests/check_soak.py"""
+"""GPU-box checker: a long SDRF run on the north-star graph, full recompute against the incremental pass, final edge lists
+compared; then the final graph's full pass against the C oracle on sampled edges.  tests/test_checkers_gpu.py runs it with
+200 iterations; the long version: ITERS=3000 python tests/check_soak.py"""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,27 +10,34 @@ from dcr import synthetic
 from dcr.data import Data
 from oracle import c_oracle
 from rewiring.sdrf_no_cuda import SdrfRun
-iters = int(os.environ.get('ITERS', 3000))
-ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
-out = {}
-for inc in (False, True):
-    np.random.seed(0)
-    run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0, incremental=inc)
-    t = time.time()
-    done = 0
-    for _ in range(iters):
-        if not run.step():
-            break
-        done += 1
-    print(f'incremental={inc}: {done} iterations in {time.time() - t:.1f} s, {run.G.number_of_edges()} edges', flush=True)
-    out[inc] = run.result().edge_index.numpy()
-    if inc:
-        run.G.curvature_pass('bfc')
-        eu, ev, cv = run.G.curvature_read()
-assert np.array_equal(out[False], out[True]), 'edge lists differ'
-C = c_oracle.CGraph(out[True], n)
-rng = np.random.Generator(np.random.PCG64(1))
-pick = rng.choice(eu.shape[0], size=20000, replace=False)
-want = C.curv_edges(eu[pick], ev[pick], 'bfc', nthreads=16)
-assert np.array_equal(cv[pick], want), 'curvatures of the rewired graph differ from the oracle'
-print('soak ok: identical edge lists, 20000 sampled curvatures of the rewired graph identical to the oracle', flush=True)
+
+
+def run(iters=3000, samples=20000):
+    ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+    out = {}
+    for inc in (False, True):
+        np.random.seed(0)
+        run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0, incremental=inc)
+        t = time.time()
+        done = 0
+        for _ in range(iters):
+            if not run.step():
+                break
+            done += 1
+        print(f'incremental={inc}: {done} iterations in {time.time() - t:.1f} s, {run.G.number_of_edges()} edges', flush=True)
+        out[inc] = run.result().edge_index.numpy()
+        if inc:
+            run.G.curvature_pass('bfc')
+            eu, ev, cv = run.G.curvature_read()
+    assert np.array_equal(out[False], out[True]), 'edge lists differ'
+    C = c_oracle.CGraph(out[True], n)
+    rng = np.random.Generator(np.random.PCG64(1))
+    pick = rng.choice(eu.shape[0], size=min(samples, eu.shape[0]), replace=False)
+    want = C.curv_edges(eu[pick], ev[pick], 'bfc', nthreads=16)
+    assert np.array_equal(cv[pick], want), 'curvatures of the rewired graph differ from the oracle'
+    print(f'soak ok: identical edge lists, {samples} sampled curvatures of the rewired graph identical to the oracle', flush=True)
+    return done
+
+
+if __name__ == '__main__':
+    run(int(os.environ.get('ITERS', 3000)))

@@ -180,7 +180,7 @@ def _dp_worker(rank, world, port, ret):
     ref.eval(); sh.eval()
     full = ref(data)
     local = sh(xl)
-    err_fwd = (local - full[sh.r0:sh.r1]).abs().max().item()
+    err_fwd = (local[:sh.owned.shape[0]] - full[sh.owned]).abs().max().item()   # this rank's nodes, in its block order
     opt = torch.optim.SGD(base.parameters(), lr=0.1)
     sh.train_step(opt, xl, yl, tl, n_train)
     ref.train()
@@ -419,7 +419,7 @@ def _dp_worker_gpu(rank, world, port, ret):
     n_train = int(data.train_mask.sum())
     ref.eval(); sh.eval()
     with torch.no_grad():
-        err_fwd = (sh(xl) - ref(data)[sh.r0:sh.r1]).abs().max().item()
+        err_fwd = (sh(xl)[:sh.owned.shape[0]] - ref(data)[sh.owned]).abs().max().item()
     opt = torch.optim.SGD(base.parameters(), lr=0.1)
     sh.train_step(opt, xl, yl, tl, n_train)
     ref.train()
@@ -471,3 +471,26 @@ def test_cora_shaped_logits_within_tolerance():
         want = dense_reference_logits(model, data.x, data.edge_index, n)
     err = (got.double() - want).abs().max().item()
     assert err < 1e-5, err
+
+
+def test_balanced_partition_deals_nodes_by_degree():
+    """The data-parallel partition (models/gcn_dp.py::balanced_partition): every rank the same number of nodes and, on a
+    preferential-attachment graph whose early ids are the hubs, the same share of the non-zeros within 10 %
+    (contiguous blocks of ids: 2.7 x the ideal share on rank 0 of 8)."""
+    from dcr import synthetic
+    from models.gcn_dp import balanced_partition
+    ei_np, n = synthetic.powerlaw_graph(20001, 10, seed=3)
+    ei = torch.from_numpy(ei_np)
+    deg = torch.bincount(ei[0], minlength=n)
+    for world in (2, 3, 8):
+        owner, index, per = balanced_partition(ei, n, world)
+        assert per == (n + world - 1) // world
+        new_id = owner * per + index
+        assert torch.unique(new_id).numel() == n and int(new_id.max()) < world * per        # a permutation into the padded range
+        nodes = torch.bincount(owner, minlength=world)
+        assert int(nodes.max() - nodes.min()) <= 1
+        nnz = torch.zeros(world, dtype=torch.int64).index_add_(0, owner, deg + 1)             # rows of A + I
+        share = nnz.double() / nnz.sum() * world
+        assert float(share.max()) < 1.1 and float(share.min()) > 0.9, share
+        blocks = torch.zeros(world, dtype=torch.int64).index_add_(0, torch.arange(n) // per, deg + 1)
+        assert float(blocks.max()) / float(blocks.sum()) * world > float(share.max())          # what contiguous blocks would give

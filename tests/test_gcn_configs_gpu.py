@@ -111,8 +111,10 @@ def _s1m_worker(rank, world, port, rows_path, ret):
         local = sh(sh.shard(x))
     saved = torch.load(rows_path)
     rows, want = saved['rows'].to(dev), saved['logits'].to(dev)
-    mine = (rows >= sh.r0) & (rows < sh.r1)
-    err = (local[rows[mine] - sh.r0] - want[mine]).abs().max().item() if bool(mine.any()) else 0.0
+    where = torch.full((n,), -1, dtype=torch.int64, device=dev)      # position of a node inside this rank's block, or -1
+    where[sh.owned] = torch.arange(sh.owned.shape[0], device=dev)
+    mine = where[rows] >= 0
+    err = (local[where[rows[mine]]] - want[mine]).abs().max().item() if bool(mine.any()) else 0.0
     ret[rank] = (err, int(mine.sum()))
     dist.destroy_process_group()
 

@@ -132,3 +132,55 @@ def test_gcn_caches_cannot_alias_a_recycled_tensor():
         want = dense_reference_logits(model, xs, t, n)
         assert (got.double() - want).abs().max().item() < 1e-5
         del xs
+
+
+def test_networkx_graph_is_uploaded_once_and_mirrored(monkeypatch):
+    """The reference's improvement loop on a networkx.Graph (sdrf_no_cuda.py:41-46: before, add_edge, after, remove_edge,
+    per candidate): one upload, the edits mirrored onto the device copy, values equal to the oracle replaying the same
+    edits; a mutation the mirror does not follow (add_node) drops the copy; pickles and deep copies are plain graphs."""
+    import copy
+    import pickle
+    import networkx as nx
+    from curvature import classical_curvatures as cc
+    from curvature.classical_curvatures import compute_curvature_edge, compute_curvature_graph
+    from oracle import sdrf_oracle as so
+    G, O = _edited_networkx_graph()
+    uploads = []
+    real = cc._upload
+    monkeypatch.setattr(cc, '_upload', lambda g, device=0: (uploads.append(1), real(g, device))[1])
+    x, y = next(iter(G.edges))
+    cands = [(i, j) for i in list(G[x]) + [x] for j in list(G[y]) + [y] if i != j and not G.has_edge(i, j)][:40]
+    assert cands
+    for ct in ('bfc', 'augmented'):
+        for (i, j) in cands:
+            before = compute_curvature_edge(G, (x, y), ct)
+            G.add_edge(i, j)
+            O.add_edge(i, j)
+            after = compute_curvature_edge(G, (x, y), ct)
+            assert after == so.curvature_edge(O, x, y, ct) and (ct == 'bfc' or isinstance(after, int))
+            G.remove_edge(i, j)
+            O.remove_edge(i, j)
+            assert compute_curvature_edge(G, (x, y), ct) == before
+    assert len(uploads) == 1 and isinstance(G, nx.Graph)
+    # the whole-graph entry on the mirrored copy, after all those edits: networkx's G.edges order and the oracle's values
+    d = compute_curvature_graph(G, 'bfc')
+    assert [(u, v) for u in d for v in d[u]] == list(G.edges)
+    assert all(d[u][v] == so.curvature_edge(O, u, v, 'bfc') for u, v in G.edges)
+    assert len(uploads) == 1
+    G.add_node(G.number_of_nodes())           # not followed by the mirror: the copy is dropped and rebuilt
+    compute_curvature_edge(G, (x, y), 'bfc')
+    assert len(uploads) == 2
+    assert type(pickle.loads(pickle.dumps(G))) is nx.Graph and type(copy.deepcopy(G)) is nx.Graph
+    with pytest.raises(nx.NetworkXError):
+        G.remove_edge(x, x + 10**6)
+
+
+def test_adjacency_that_is_no_undirected_graph_is_refused():
+    """A DiGraph's successor rows are not the projections of one undirected edge sequence: ValueError, not IndexError."""
+    import networkx as nx
+    from curvature.classical_curvatures import as_dcr_graph
+    D = nx.DiGraph()
+    D.add_nodes_from(range(4))
+    D.add_edges_from([(0, 1), (1, 2), (2, 3), (0, 3)])
+    with pytest.raises(ValueError):
+        as_dcr_graph(D)

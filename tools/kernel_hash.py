@@ -9,9 +9,9 @@ PASS_SOURCES = ('dcr_bfc_common.h', 'dcr_internal.h', 'dcr_bfc.hip', 'dcr_bfc_nc
                 'build.sh')
 
 
-def pass_sources_hash():
+def pass_sources_hash(names=PASS_SOURCES):
     h = hashlib.sha256()
-    for name in PASS_SOURCES:
+    for name in names:
         p = os.path.join(CSRC, name)
         if os.path.exists(p):
             h.update(name.encode())
