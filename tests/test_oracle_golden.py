@@ -208,3 +208,23 @@ def test_bfc_cuda_oracle_matches_reference_sdrf_runs():
     for case in load_golden('bfc_cuda_sdrf.json')['cases']:
         assert case['error'] is None
         check_bfc_cuda_sdrf_case(case, bo.sdrf_cuda_bfc)
+
+
+def test_bfc_cuda_fixtures_do_not_depend_on_the_float32_typing_model():
+    """tools/make_golden_cuda_compat.py evaluates the reference's two numba kernels (curvature/bfc_cuda.py:11-48,68-141) under
+    two models of numba's float32 typing and asserts identical fixtures; the record it leaves lists the stores an FMA
+    contraction could round the other way.  Here: the record is consistent with the fixtures it speaks about."""
+    chk = load_golden('bfc_cuda_typing_check.json')
+    fix = load_golden('bfc_cuda_curvature.json')
+    assert chk['differences_between_typing_models'] == 0
+    n_vals = sum(len(c['C']) + sum(len(d['D']) for d in c['post_delta']) for c in fix['cases'])
+    assert chk['values_compared'] == n_vals and chk['stores_checked'] >= n_vals
+    graphs = {c['graph']: c for c in fix['cases']}
+    for e in chk['fma_sensitive']:
+        assert e['graph'] in graphs and (e['array'] == 'C' or e['array'].startswith('D('))
+        v = float.fromhex(e['float64'])
+        if e['array'] == 'C':       # the listed float64 value rounds to what the fixture holds, or is the base term the
+            n = graphs[e['graph']]['num_nodes']   # 4-cycle term was then added to (two stores per entry, bfc_cuda.py:46-48)
+            i, j = e['index']
+            stored = float.fromhex(graphs[e['graph']]['C'][i * n + j])
+            assert np.float32(v) == np.float32(stored) or abs(v) <= abs(stored) + 4.0

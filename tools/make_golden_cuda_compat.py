@@ -44,17 +44,69 @@ from dcr import synthetic  # noqa: E402
 # ---------------------------------------------------------------------------------------------------------------------
 # 1. numba.cuda stand-in
 # ---------------------------------------------------------------------------------------------------------------------
+# Two evaluation modes, which must (and do: asserted in main) produce the same fixtures:
+#   'wide'  : every float32 element read is a Python float, so ALL arithmetic is float64 (what the fixtures were first
+#             recorded with);
+#   'typed' : a float32 element read is an F32 scalar; F32 (+-*/) F32 is rounded to float32, F32 with an int or a float
+#             is float64 — numba's promotion rule for these kernels' operand types applied per operation.  (numba unifies
+#             a VARIABLE that is assigned an int64 literal and later a float32, e.g. ``lambda_ij = 0``, to float64; an
+#             emulation per operation cannot see that, so 'typed' keeps such a product in float32 where numba widens it:
+#             'wide' and 'typed' bracket numba's choice from both sides, and any mix of the two gives the same bits as
+#             long as these two agree.)
+MODE = 'wide'
+# stores whose float64 value lies within 2^-29 (relative) of a float32 rounding boundary: the only entries an FMA
+# contraction by NVVM (a*b+c rounded once) could flip.  Collected in 'wide' mode; CONTEXT names the array being written.
+SENSITIVE = []
+STORES = [0]
+CONTEXT = {'graph': None, 'array': None}
+
+
+class F32(float):
+    """A float32 scalar in 'typed' mode (a float subclass holding an exactly representable value)."""
+    __slots__ = ()
+
+    def _bin(self, other, op, swap=False):
+        a, b = (other, self) if swap else (self, other)
+        if isinstance(other, F32):
+            return F32(np.float32(op(np.float32(float(a)), np.float32(float(b)))))
+        return op(float(a), float(b))       # int64 / float64 with float32: float64
+
+    def __add__(self, o): return self._bin(o, lambda x, y: x + y)
+    def __radd__(self, o): return self._bin(o, lambda x, y: x + y, True)
+    def __sub__(self, o): return self._bin(o, lambda x, y: x - y)
+    def __rsub__(self, o): return self._bin(o, lambda x, y: x - y, True)
+    def __mul__(self, o): return self._bin(o, lambda x, y: x * y)
+    def __rmul__(self, o): return self._bin(o, lambda x, y: x * y, True)
+    def __truediv__(self, o): return self._bin(o, lambda x, y: x / y)
+    def __rtruediv__(self, o): return self._bin(o, lambda x, y: x / y, True)
+    def __neg__(self): return F32(-float(self))
+
+
+def _near_f32_boundary(v):
+    """Is the float64 v within 2^-29 (relative) of the midpoint between two adjacent float32 values?"""
+    if v == 0.0 or not np.isfinite(v):
+        return False
+    f = np.float32(v)
+    lo, hi = np.nextafter(f, np.float32(-np.inf)), np.nextafter(f, np.float32(np.inf))
+    d = min(abs(v - 0.5 * (float(f) + float(lo))), abs(v - 0.5 * (float(f) + float(hi))))
+    return d <= abs(v) * 2.0 ** -29
+
+
 class F32View:
-    """float32 array as numba code sees it next to int64 literals: reads take part in float64 arithmetic, writes round
-    to float32."""
+    """float32 array as numba code sees it: element reads per MODE above, writes round to float32."""
 
     def __init__(self, arr):
         self.a = arr  # numpy float32, shared with the torch tensor
 
     def __getitem__(self, ix):
-        return float(self.a[ix])
+        return F32(self.a[ix]) if MODE == 'typed' else float(self.a[ix])
 
     def __setitem__(self, ix, v):
+        if MODE == 'wide' and CONTEXT['array'] is not None and not isinstance(v, F32):
+            STORES[0] += 1
+            if _near_f32_boundary(float(v)):
+                SENSITIVE.append({'graph': CONTEXT['graph'], 'array': CONTEXT['array'], 'index': [int(t) for t in np.atleast_1d(ix)],
+                                  'float64': float(v).hex()})
         self.a[ix] = np.float32(v)
 
 
@@ -75,7 +127,7 @@ class _Launcher:
                     assert arr.dtype == np.float32
                     conv.append(F32View(arr))
                 elif t == 'float32':
-                    conv.append(float(np.float32(float(a))))
+                    conv.append(F32(np.float32(float(a))) if MODE == 'typed' else float(np.float32(float(a))))
                 elif t.startswith('int32['):
                     conv.append(np.asarray(a).astype(np.int64))
                 elif t == 'int32':
@@ -269,6 +321,7 @@ def curvature_cases():
     for name, (ei, n) in list(catalog().items()) + list(directed_catalog().items()):
         symmetric = name not in directed_catalog()
         A = dense_from(ei, n, symmetric)
+        CONTEXT.update(graph=name, array='C')
         C = ref_cuda.balanced_forman_curvature(A.clone())
         rec = {'graph': name, 'num_nodes': n, 'edge_index': ei.tolist(), 'symmetric': symmetric, 'C': f32hex(C), 'post_delta': []}
         # post-delta matrices for a few (x, y) with the neighbour lists sdrf_cuda_bfc.py:44-49 builds
@@ -283,11 +336,13 @@ def curvature_cases():
                 xn, yn = list(G.neighbors(x)) + [x], list(G.neighbors(y)) + [y]
             else:
                 xn, yn = list(G.successors(x)) + [x], list(G.predecessors(y)) + [y]
+            CONTEXT.update(graph=name, array=f'D(x={x},y={y})')
             D = ref_cuda.balanced_forman_post_delta(A.clone(), x, y, xn, yn)
             rec['post_delta'].append({'x': x, 'y': y, 'i_neighbors': [int(t) for t in xn], 'j_neighbors': [int(t) for t in yn],
                                       'D': f32hex(D)})
         cases.append(rec)
-        print('curvature', name, n, 'nnz', int(A.sum()))
+        CONTEXT.update(graph=None, array=None)
+        print('curvature', name, n, 'nnz', int(A.sum()), 'mode', MODE)
     return cases
 
 
@@ -375,13 +430,34 @@ def sdrf_cases():
 
 
 def main():
+    global MODE
     about = ('outputs of the reference curvature/bfc_cuda.py and rewiring/sdrf_cuda_bfc.py executed on the CPU through a '
              'harness-side numba.cuda stand-in (tools/make_golden_cuda_compat.py); float32 values as hex')
+    MODE = 'wide'
+    curv_wide, sdrf_wide = curvature_cases(), sdrf_cases()
+    sensitive, stores = list(SENSITIVE), STORES[0]
+    # the same under per-operation float32 typing: every fixture value must come out bit for bit the same
+    MODE = 'typed'
+    curv_typed, sdrf_typed = curvature_cases(), sdrf_cases()
+    MODE = 'wide'
+    n_vals = sum(len(c['C']) + sum(len(d['D']) for d in c['post_delta']) for c in curv_wide)
+    assert json.dumps(curv_wide) == json.dumps(curv_typed), 'curvature fixtures depend on the float32 typing model'
+    assert json.dumps(sdrf_wide) == json.dumps(sdrf_typed), 'SDRF traces depend on the float32 typing model'
+    print(f'{n_vals} curvature / post-delta values and {len(sdrf_wide)} traced runs identical under both typing models; '
+          f'{len(sensitive)} of {stores} stores within 2^-29 of a float32 rounding boundary')
     with open(os.path.join(GOLDEN, 'bfc_cuda_curvature.json'), 'w') as f:
-        json.dump({'_about': about, 'cases': curvature_cases()}, f, separators=(',', ':'))
+        json.dump({'_about': about, 'cases': curv_wide}, f, separators=(',', ':'))
     with open(os.path.join(GOLDEN, 'bfc_cuda_sdrf.json'), 'w') as f:
-        json.dump({'_about': about, 'cases': sdrf_cases()}, f, separators=(',', ':'))
-    for n in ('bfc_cuda_curvature.json', 'bfc_cuda_sdrf.json'):
+        json.dump({'_about': about, 'cases': sdrf_wide}, f, separators=(',', ':'))
+    with open(os.path.join(GOLDEN, 'bfc_cuda_typing_check.json'), 'w') as f:
+        json.dump({'_about': 'tools/make_golden_cuda_compat.py: the fixtures were evaluated under two models of numba\'s float32 typing '
+                             '(every float32 read widened to float64; float32 x float32 kept in float32, per operation) and are '
+                             'identical under both; fma_sensitive lists the stores into C / D whose float64 value lies within 2^-29 '
+                             '(relative) of a float32 rounding boundary, the only entries an FMA contraction of a*b+c by NVVM '
+                             'could round the other way',
+                   'values_compared': n_vals, 'traced_runs_compared': len(sdrf_wide), 'differences_between_typing_models': 0,
+                   'stores_checked': stores, 'fma_sensitive': sensitive}, f, separators=(',', ':'))
+    for n in ('bfc_cuda_curvature.json', 'bfc_cuda_sdrf.json', 'bfc_cuda_typing_check.json'):
         print('wrote', n, os.path.getsize(os.path.join(GOLDEN, n)), 'bytes')
 
 
