@@ -353,3 +353,199 @@ extern "C" int dcr_relu_dropout_bwd_f32_dev(const float *grad_out, float *grad_i
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
+
+// ---- activation fused into the next layer's dense contraction ---------------------------------------------------------
+// models/gcn.py:36-42 between two layers: x = relu(x); x = dropout(x); then the next GCNConv's lin (x·Wᵀ, W = [C, H] with C
+// classes).  As separate passes the hidden activation (N x H floats: 512 MB at the 1M-node bench shape) was read by the
+// ReLU/dropout kernel, written, read again by the GEMM library — and once more each for the evaluation operand of the
+// one-pass epoch (relu, GEMM) — 0.68 ms of a 4.6 ms epoch for 8 GFLOP.  Here one pass reads the pre-activation row, applies
+// ReLU (+ dropout with the SAME Philox stream and keep-bit layout as k_relu_dropout_fwd: element 4t..4t+3 belongs to
+// thread t, wave w of 64 threads stores its four ballots in bits[4w..4w+3]), stores the training activation (the weight
+// gradient needs it) and contracts both operands with W on the spot: LPR = H / 4 lanes hold one row (4 floats each) and
+// their 4-column block of W in registers (64 floats), each forms its partial of the 16 + 16 outputs, and a
+// reduce-scatter over the row's lanes (halve the values, exchange, add: 31 shuffles for 32 values instead of 160) leaves
+// every lane with 32 / LPR finished outputs.  Memory-bound: N·H·4 read + N·H·4 written + 2·N·C·4.
+namespace dcr {
+
+template <int LPR, bool TRAIN, bool EVAL>
+__global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ h_train,
+                                                         float *__restrict__ z_train, float *__restrict__ z_eval,
+                                                         unsigned long long *__restrict__ bits, int64_t n_rows, int C, float scale,
+                                                         uint32_t threshold, uint64_t seed, uint64_t offset,
+                                                         const uint64_t *__restrict__ offset_dev) {
+    constexpr int H = 4 * LPR, RPW = 64 / LPR;  // rows per wave
+    if (TRAIN && offset_dev) offset += *offset_dev;
+    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
+    float wr[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[j][q] = j < C ? w[(int64_t)j * H + 4 * sl + q] : 0.f;
+    const int64_t n_waves = (n_rows + RPW - 1) / RPW;
+    for (int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wv < n_waves; wv += (int64_t)gridDim.x * 4) {
+        const int64_t row = wv * RPW + sub;
+        const int64_t t = row * LPR + sl;  // the thread of k_relu_dropout_fwd that owns these four elements (= 64 wv + lane)
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < n_rows) {
+            const float4 q = *reinterpret_cast<const float4 *>(x + t * 4);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        }
+        float vals[32];
+        if (TRAIN) {
+            uint32_t r[4];
+            philox4x32_10((uint64_t)t, offset, seed, r);
+            bool keep[4];
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                keep[j] = v[j] > 0.f && r[j] >= threshold;
+                o[j] = keep[j] ? v[j] * scale : 0.f;
+            }
+            if (row < n_rows) *reinterpret_cast<float4 *>(h_train + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long m = __ballot(keep[j]);
+                if (lane == 0) bits[wv * 4 + j] = m;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vals[j] = fmaf(o[3], wr[j][3], fmaf(o[2], wr[j][2], fmaf(o[1], wr[j][1], o[0] * wr[j][0])));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vals[j] = 0.f;
+        }
+        if (EVAL) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = v[j] > 0.f ? v[j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vals[16 + j] = fmaf(e[3], wr[j][3], fmaf(e[2], wr[j][2], fmaf(e[1], wr[j][1], e[0] * wr[j][0])));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vals[16 + j] = 0.f;
+        }
+        // reduce-scatter over the LPR lanes of the row: after the step with distance s a lane keeps the half of its
+        // values selected by that bit of its index, so lane sl ends with values (32 / LPR) * sl ... + 32 / LPR - 1
+#pragma unroll
+        // (the two-way choice is written as a bit select — one v_bfi_b32 — on purpose: as `up ? vals[a] : vals[b]` the
+        //  compiler turned it into a dynamically indexed register array, i.e. a chain of 32 compare-and-selects per
+        //  value: 1,700 of them per row pair, 3.7 ms for the kernel)
+        for (int s = LPR / 2, n = 32; s >= 1; s >>= 1, n >>= 1) {
+            const unsigned um = (sl & s) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i >= n / 2) continue;  // (compile-time after unrolling)
+                const unsigned lo = __float_as_uint(vals[i]), hi = __float_as_uint(vals[i + n / 2]);
+                const float mine = __uint_as_float((hi & um) | (lo & ~um)), other = __uint_as_float((lo & um) | (hi & ~um));
+                vals[i] = mine + __shfl_xor(other, s);
+            }
+        }
+        if (row < n_rows) {
+            constexpr int PER = 32 / LPR;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = PER * sl + i;  // 0..15: training output idx; 16..31: evaluation output idx - 16
+                if (TRAIN && idx < 16 && idx < C) z_train[row * C + idx] = vals[i];
+                if (EVAL && idx >= 16 && idx - 16 < C) z_eval[row * C + idx - 16] = vals[i];
+            }
+        }
+    }
+}
+
+// dx = keep ? (dz · W) / (1 - p) : 0 — the backward of the training operand above in one pass (it was a GEMM writing
+// N x H floats and the ReLU/dropout backward reading and writing them again)
+template <int LPR>
+__global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict__ dz, const float *__restrict__ w,
+                                                         const unsigned long long *__restrict__ bits, float *__restrict__ dx,
+                                                         int64_t n_rows, int C, float scale) {
+    constexpr int H = 4 * LPR, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
+    float wr[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[j][q] = j < C ? w[(int64_t)j * H + 4 * sl + q] : 0.f;
+    const int64_t n_waves = (n_rows + RPW - 1) / RPW;
+    for (int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wv < n_waves; wv += (int64_t)gridDim.x * 4) {
+        const int64_t row = wv * RPW + sub;
+        if (row >= n_rows) continue;
+        const int64_t t = row * LPR + sl;
+        float g[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g[j] = j < C ? dz[row * C + j] : 0.f;
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = fmaf(g[j], wr[j][q], acc);
+            const bool keep = (bits[wv * 4 + q] >> lane) & 1ull;
+            o[q] = keep ? acc * scale : 0.f;
+        }
+        *reinterpret_cast<float4 *>(dx + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int LPR>
+static void launch_act_linear_fwd(bool train, bool eval, const float *x, const float *w, float *h_train, float *z_train, float *z_eval,
+                                  unsigned long long *bits, int64_t n_rows, int C, float scale, uint32_t threshold, uint64_t seed,
+                                  uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
+    const int64_t n_waves = (n_rows + 64 / LPR - 1) / (64 / LPR);
+    int64_t blocks = (n_waves + 3) / 4;
+    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;  // grid-stride: the weights are loaded into registers once per wave
+    if (blocks < 1) blocks = 1;
+    if (train && eval)
+        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, bits,
+                           n_rows, C, scale, threshold, seed, offset, offset_dev);
+    else if (train)
+        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, bits,
+                           n_rows, C, scale, threshold, seed, offset, offset_dev);
+    else
+        hipLaunchKernelGGL((k_act_linear_fwd<LPR, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, bits,
+                           n_rows, C, scale, threshold, seed, offset, offset_dev);
+}
+
+}  // namespace dcr
+
+extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float *h_train, float *z_train, float *z_eval, uint64_t *bits,
+                                          int64_t n_rows, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
+                                          const uint64_t *offset_dev, void *hip_stream) {
+    const bool train = z_train != nullptr, eval = z_eval != nullptr;
+    if (!x || !w || n_rows < 0 || (!train && !eval)) DCR_FAIL(DCR_EINVAL, "bad act_linear arguments");
+    if (train && (!h_train || !bits || !(p >= 0.0 && p < 1.0))) DCR_FAIL(DCR_EINVAL, "act_linear: training output needs h_train, bits and 0 <= p < 1");
+    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16)
+        DCR_FAIL(DCR_EINVAL, "act_linear: hidden width 64 or 128 and at most 16 classes (other shapes take the separate kernels)");
+    if (((uintptr_t)x & 15) || (h_train && ((uintptr_t)h_train & 15))) DCR_FAIL(DCR_EINVAL, "act_linear: 16-byte aligned tensors expected");
+    if (n_rows == 0) return DCR_OK;
+    const double th = p * 4294967296.0;
+    const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    const float scale = (float)(1.0 / (1.0 - p));
+    if (hidden == 128)
+        dcr::launch_act_linear_fwd<32>(train, eval, x, w, h_train, z_train, z_eval, (unsigned long long *)bits, n_rows, classes, scale, threshold,
+                                       seed, offset, offset_dev, (hipStream_t)hip_stream);
+    else
+        dcr::launch_act_linear_fwd<16>(train, eval, x, w, h_train, z_train, z_eval, (unsigned long long *)bits, n_rows, classes, scale, threshold,
+                                       seed, offset, offset_dev, (hipStream_t)hip_stream);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_act_linear_bwd_f32_dev(const float *dz, const float *w, const uint64_t *bits, float *dx, int64_t n_rows, int hidden,
+                                          int classes, double p, void *hip_stream) {
+    if (!dz || !w || !bits || !dx || n_rows < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd arguments");
+    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: unsupported shape");
+    if ((uintptr_t)dx & 15) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: 16-byte aligned tensors expected");
+    if (n_rows == 0) return DCR_OK;
+    const int lpr = hidden / 4;
+    const int64_t n_waves = (n_rows + 64 / lpr - 1) / (64 / lpr);
+    int64_t blocks = (n_waves + 3) / 4;
+    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+    const float scale = (float)(1.0 / (1.0 - p));
+    if (hidden == 128)
+        hipLaunchKernelGGL((dcr::k_act_linear_bwd<32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, dz, w,
+                           (const unsigned long long *)bits, dx, n_rows, classes, scale);
+    else
+        hipLaunchKernelGGL((dcr::k_act_linear_bwd<16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, dz, w,
+                           (const unsigned long long *)bits, dx, n_rows, classes, scale);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}

@@ -278,6 +278,78 @@ def relu_dropout(x, act_fn, dropout):
     return dropout(act_fn(x))
 
 
+class _ActLinearFn(torch.autograd.Function):
+    """(dropout(relu(x))·Wᵀ, relu(x)·Wᵀ) in ONE pass over x (csrc/dcr_gcn.hip, dcr_act_linear_fwd_f32_dev): the activation
+    between two layers fused into the next layer's dense contraction, for the training operand, the evaluation operand or
+    both.  Only the training operand carries a gradient; its backward is one pass too (dcr_act_linear_bwd_f32_dev), the
+    weight gradient the MFMA reduction kernel on the stored training activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, p, want_train, want_eval):
+        from dcr import _lib
+        x = x.contiguous()
+        w = weight.contiguous()
+        n, hidden = x.shape
+        classes = w.shape[0]
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        z_tr = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_train else None
+        z_ev = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_eval else None
+        h = bits = ctr = None
+        if want_train:
+            words = ctypes.c_int64()
+            _lib.check(_lib.lib().dcr_relu_dropout_bits_words(x.numel(), ctypes.byref(words)))
+            bits = torch.empty(max(words.value, 1), dtype=torch.int64, device=x.device)
+            h = torch.empty_like(x)
+            ctr = _dropout_counter(x.device)
+        _lib.check(_lib.lib().dcr_act_linear_fwd_f32_dev(
+            x.data_ptr(), w.data_ptr(), h.data_ptr() if want_train else None, z_tr.data_ptr() if want_train else None,
+            z_ev.data_ptr() if want_eval else None, bits.data_ptr() if want_train else None, n, hidden, classes, float(p),
+            torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None, ctypes.c_void_p(stream)))
+        if want_train:
+            ctr.add_(1)
+            ctx.save_for_backward(h, w)
+            ctx.bits, ctx.p = bits, float(p)
+        if want_eval:
+            ctx.mark_non_differentiable(z_ev)
+        return z_tr, z_ev
+
+    @staticmethod
+    def backward(ctx, g_tr, g_ev):
+        from dcr import _lib
+        h, w = ctx.saved_tensors
+        g_tr = g_tr.contiguous()
+        gx = gw = None
+        stream = torch.cuda.current_stream(g_tr.device).cuda_stream
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(h)
+            _lib.check(_lib.lib().dcr_act_linear_bwd_f32_dev(g_tr.data_ptr(), w.data_ptr(), ctx.bits.data_ptr(), gx.data_ptr(),
+                                                             h.shape[0], h.shape[1], w.shape[0], ctx.p, ctypes.c_void_p(stream)))
+        if ctx.needs_input_grad[1]:
+            gw = atb_hip(g_tr, h) if h.shape[0] >= 64 * max(h.shape[1], g_tr.shape[1]) else g_tr.t() @ h
+        return gx, gw, None, None, None
+
+
+def act_then_linear(x, act_fn, dropout, lin, want_train=True, want_eval=False):
+    """(lin(dropout(act_fn(x))), lin(act_fn(x))) — the part of models/gcn.py:36-42 between one layer's aggregation and the
+    next one's (either may be None when not wanted).  Fused into one pass on the MI355X for ReLU, hidden width 64 / 128 and
+    at most 16 classes; the stock modules otherwise (CPU tests, other shapes, other activations)."""
+    w = lin.weight
+    can = (_AGG_BACKEND == 'hip' and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and isinstance(act_fn, ReLU)
+           and x.shape[1] in (64, 128) and w.shape[0] <= 16 and x.data_ptr() % 16 == 0)
+    train_ok = can and dropout.training and 0.0 < dropout.p < 1.0
+    # (each operand takes the same route whatever else is asked for in the same call: the evaluation output of the one-pass
+    #  epoch equals an evaluation-mode forward bit for bit, the training output a training-mode forward)
+    if want_train and want_eval and train_ok:
+        return _ActLinearFn.apply(x, w, dropout.p, True, True)
+    z_tr = z_ev = None
+    if want_train:
+        z_tr = _ActLinearFn.apply(x, w, dropout.p, True, False)[0] if train_ok else lin(relu_dropout(x, act_fn, dropout))
+    if want_eval:
+        with torch.no_grad():
+            z_ev = _ActLinearFn.apply(x.detach(), w.detach(), 0.0, False, True)[1] if can else lin(act_fn(x.detach()))
+    return z_tr, z_ev
+
+
 class _Linear(torch.nn.Module):
     """torch_geometric.nn.dense.linear.Linear(in, out, bias=False, weight_initializer='glorot')."""
 
@@ -387,12 +459,19 @@ class GCN(torch.nn.Module):
             conv.reset_parameters()
 
     def forward(self, data):
-        h = data.x
-        last = len(self.layers) - 1
-        for depth, conv in enumerate(self.layers):
-            h = conv(h, data.edge_index, edge_weight=data.edge_attr)
-            if depth < last:
-                h = relu_dropout(h, self.act_fn, self.dropout)
+        # models/gcn.py:32-44.  The activation after a layer is computed together with the next layer's lin
+        # (act_then_linear: one pass over the hidden activation where the fused kernel applies).
+        layers = list(self.layers)
+        h = layers[0](data.x, data.edge_index, edge_weight=data.edge_attr)
+        for conv in layers[1:]:
+            csr = conv.norm_csr(data.edge_index, data.edge_attr, h.shape[0])
+            if self.training:
+                z, _ = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=False)
+            elif torch.is_grad_enabled() and h.requires_grad:
+                z = conv.lin(self.dropout(self.act_fn(h)))   # evaluation mode WITH a gradient (not on the training path)
+            else:
+                _, z = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
+            h = aggregate(z, conv.bias, csr)
         return torch.nn.functional.log_softmax(h, dim=1)
 
     def forward_pair(self, data):
@@ -407,12 +486,12 @@ class GCN(torch.nn.Module):
         o_tr = first(data.x, data.edge_index, edge_weight=data.edge_attr)
         o_ev = o_tr.detach()
         for depth, conv in enumerate(list(self.layers)[1:], start=1):
-            h_tr = relu_dropout(o_tr, self.act_fn, self.dropout)
-            with torch.no_grad():
-                h_ev = self.act_fn(o_ev)                 # (dropout is the identity in evaluation mode)
-                z_ev = conv.lin(h_ev)
-            z_tr = conv.lin(h_tr)
-            csr = conv.norm_csr(data.edge_index, data.edge_attr, h_tr.shape[0])
+            if o_ev.data_ptr() == o_tr.data_ptr():       # the same pre-activation (first hidden layer): one pass for both
+                z_tr, z_ev = act_then_linear(o_tr, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=True)
+            else:                                        # (dropout is the identity in evaluation mode)
+                z_tr, _ = act_then_linear(o_tr, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=False)
+                _, z_ev = act_then_linear(o_ev, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
+            csr = conv.norm_csr(data.edge_index, data.edge_attr, o_tr.shape[0])
             o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, conv.bias, csr)
         log_softmax = torch.nn.functional.log_softmax
         return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)

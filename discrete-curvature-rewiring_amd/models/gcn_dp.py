@@ -21,7 +21,7 @@ divided by the global number of training nodes, so the summed gradients equal th
 import torch
 import torch.distributed as dist
 
-from models.gcn import GCN, aggregate, gcn_norm_csr, relu_dropout, spmm, spmm_pair
+from models.gcn import GCN, act_then_linear, aggregate, gcn_norm_csr, relu_dropout, spmm, spmm_pair
 
 
 def block_range(n, world, rank):
@@ -195,10 +195,11 @@ class ShardedGCN(torch.nn.Module):
             o_tr = aggregate(z, first.bias, self.csr)
         o_ev = o_tr.detach()
         for layer in layers[1:]:
-            h_tr = relu_dropout(o_tr, self.gcn.act_fn, self.gcn.dropout)
-            with torch.no_grad():
-                z_ev = layer.lin(self.gcn.act_fn(o_ev))
-            z_tr = layer.lin(h_tr)
+            if o_ev.data_ptr() == o_tr.data_ptr():
+                z_tr, z_ev = act_then_linear(o_tr, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=True, want_eval=True)
+            else:
+                z_tr, _ = act_then_linear(o_tr, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=True, want_eval=False)
+                _, z_ev = act_then_linear(o_ev, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=False, want_eval=True)
             o_tr, o_ev = _GatherAggregatePair.apply(z_tr, z_ev, layer.bias, self.csr, self.n, self.per, self.group)
         log_softmax = torch.nn.functional.log_softmax
         return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)

@@ -219,6 +219,18 @@ int dcr_relu_dropout_fwd_f32_ctr_dev(const float *x_dev, float *y_dev, uint64_t 
 int dcr_relu_dropout_bwd_f32_dev(const float *grad_out_dev, float *grad_in_dev, const uint64_t *bits_dev, int64_t n,
                                  double p, void *hip_stream);
 
+/* ---- the same activation fused into the next layer's dense contraction ------------------------------------------------
+ * models/gcn.py:36-42 between two layers (x = relu(x); x = dropout(x); next GCNConv's lin: x·W^T, W = [classes, hidden]) in
+ * ONE pass over the hidden activation: z_train = dropout(relu(x))·W^T (with h_train = dropout(relu(x)) stored for the weight
+ * gradient and the keep bits as above, same Philox stream as dcr_relu_dropout_fwd_f32_ctr_dev) and / or z_eval = relu(x)·W^T.
+ * A null z_train (z_eval) skips that operand.  hidden 64 or 128, classes <= 16 (other shapes: the separate entry points).
+ * Backward of the training operand: dx = keep ? (dz·W) / (1 - p) : 0. */
+int dcr_act_linear_fwd_f32_dev(const float *x_dev, const float *w_dev, float *h_train_dev, float *z_train_dev, float *z_eval_dev,
+                               uint64_t *bits_dev, int64_t n_rows, int hidden, int classes, double p, uint64_t seed,
+                               uint64_t offset, const uint64_t *offset_dev, void *hip_stream);
+int dcr_act_linear_bwd_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, float *dx_dev, int64_t n_rows,
+                               int hidden, int classes, double p, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

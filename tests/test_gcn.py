@@ -494,3 +494,39 @@ def test_balanced_partition_deals_nodes_by_degree():
         assert float(share.max()) < 1.1 and float(share.min()) > 0.9, share
         blocks = torch.zeros(world, dtype=torch.int64).index_add_(0, torch.arange(n) // per, deg + 1)
         assert float(blocks.max()) / float(blocks.sum()) * world > float(share.max())          # what contiguous blocks would give
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hidden,classes,n', [(128, 16, 5003), (64, 6, 2120), (128, 7, 65)])
+def test_activation_fused_into_the_next_contraction(hidden, classes, n):
+    """dcr_act_linear_fwd / _bwd (models/gcn.py:36-42 between two layers, one pass): the training operand equals the separate
+    fused ReLU + dropout kernel followed by a float64 contraction (same Philox stream: same keep mask), the evaluation
+    operand relu(x)·Wᵀ, the gradients those of the separate ops; pair, train-only and eval-only calls agree bit for bit."""
+    from models import gcn
+    from models.gcn import _ActLinearFn, _ReluDropoutFn
+    gcn.set_aggregate_backend('hip')
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(n, hidden, device=dev, generator=g)
+    w = (torch.randn(classes, hidden, device=dev, generator=g) * 0.1)
+    p = 0.4
+    ctr = gcn._dropout_counter(dev)
+    c0 = ctr.clone()
+    h_ref = _ReluDropoutFn.apply(x, p)                       # the separate kernel: mask of call number c0
+    ctr.copy_(c0)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    z_tr, z_ev = _ActLinearFn.apply(xr, wr, p, True, True)
+    want_tr = (h_ref.double() @ w.double().t()).float()
+    want_ev = (torch.relu(x).double() @ w.double().t()).float()
+    assert (z_tr - want_tr).abs().max().item() < 1e-4 and (z_ev - want_ev).abs().max().item() < 1e-4
+    gz = torch.randn(n, classes, device=dev, generator=g)
+    z_tr.backward(gz)
+    keep = h_ref != 0
+    want_gx = torch.where(keep, (gz.double() @ w.double()).float() / (1 - p), torch.zeros_like(x))
+    assert (xr.grad - want_gx).abs().max().item() < 1e-4
+    assert (wr.grad - (gz.double().t() @ h_ref.double()).float()).abs().max().item() < 1e-3 * max(1.0, float(n) ** 0.5)
+    ctr.copy_(c0)
+    only_tr = _ActLinearFn.apply(x, w, p, True, False)[0]
+    only_ev = _ActLinearFn.apply(x, w, 0.0, False, True)[1]
+    assert torch.equal(only_tr, z_tr.detach()) and torch.equal(only_ev, z_ev)
