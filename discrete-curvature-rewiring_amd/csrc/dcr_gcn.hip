@@ -72,7 +72,7 @@ template <int LPR, int VEC, int NBLK>
 __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const float *__restrict__ val, const float *__restrict__ B,
                                                    float *__restrict__ C, int64_t n_rows, int n_feat, int64_t ldb,
-                                                   int64_t ldc, const float *__restrict__ bias, int relu, int blk) {
+                                                   int64_t ldc, const float *__restrict__ bias, int relu, int blk, int64_t blk_c) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     constexpr int G = ROWS_PER_BLOCK;        // lane groups per workgroup
     constexpr int U = LPR <= 8 ? 8 : 4;      // narrow rows of B: more gathers in flight per group
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
                 spmm_accumulate<VEC, U, NBLK>(col, val, B, ldb, f0, e0, e1, 1, blk, acc);
 #pragma unroll
                 for (int k = 0; k < NBLK; ++k) {
-                    float *dst = C + row * ldc + f0 + k * blk;
+                    float *dst = C + row * ldc + f0 + k * blk_c;
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         float r = acc[k][q];
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
                 for (int q = 0; q < VEC; ++q) red[threadIdx.x * VEC + q] = acc[k][q];
                 __syncthreads();
                 if (sub == 0 && f0 < n_feat) {
-                    float *dst = C + lrow * ldc + f0 + k * blk;
+                    float *dst = C + lrow * ldc + f0 + k * blk_c;
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         float r = 0.f;
@@ -149,15 +149,15 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
 template <int LPR, int VEC>
 static void launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
                         int64_t n_rows, int n_feat, int64_t ldb, int64_t ldc, const float *bias, int relu, int n_blocks,
-                        hipStream_t st) {
+                        int64_t blk_c, hipStream_t st) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     const int64_t blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (n_blocks == 2)
         hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 2>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                           n_feat, ldb, ldc, bias, relu, n_feat);
+                           n_feat, ldb, ldc, bias, relu, n_feat, blk_c);
     else
         hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 1>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                           n_feat, ldb, ldc, bias, relu, 0);
+                           n_feat, ldb, ldc, bias, relu, 0, (int64_t)0);
 }
 
 }  // namespace dcr
@@ -166,10 +166,12 @@ using namespace dcr;
 
 static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
                          int64_t n_rows, int64_t n_feat, int64_t n_blocks, int64_t ldb, int64_t ldc, const float *bias, int relu,
-                         void *hip_stream) {
+                         void *hip_stream, int64_t blk_c = -1) {
+    // blk_c: where the second block of the output starts relative to the first (floats); -1: next to it (n_feat)
     if (!rowptr || !B || !C || n_rows < 0 || n_feat <= 0 || n_blocks < 1 || n_blocks > 2 || ldb < n_feat * n_blocks ||
-        ldc < n_feat * n_blocks)
+        ldc < (blk_c < 0 ? n_feat * n_blocks : n_feat))
         DCR_FAIL(DCR_EINVAL, "bad SpMM arguments");
+    if (blk_c < 0) blk_c = n_feat;
     if (n_rows == 0) return DCR_OK;
     if (n_feat > INT32_MAX / 2) DCR_FAIL(DCR_EINVAL, "n_feat too large");
     hipStream_t st = (hipStream_t)hip_stream;
@@ -177,7 +179,7 @@ static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float 
     // (the template is chosen by the width of ONE block: a block of a two-block call is accumulated exactly like a call of its own)
     const bool v4 = (F % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)B & 15) == 0);
     const bool v2 = (F % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) && (((uintptr_t)B & 7) == 0);
-#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, st)
+#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, blk_c, st)
     if (v4) {
         const int lanes = F / 4;
         if (lanes <= 4) GO(4, 4);
@@ -214,6 +216,13 @@ extern "C" int dcr_spmm_csr_f32_pair_dev(const int64_t *rowptr, const int32_t *c
                                          float *C, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
                                          const float *bias, int relu, void *hip_stream) {
     return spmm_dispatch(rowptr, col, val, B, C, n_rows, n_feat, 2, ldb, ldc, bias, relu, hip_stream);
+}
+
+extern "C" int dcr_spmm_csr_f32_pair_split_dev(const int64_t *rowptr, const int32_t *col, const float *val, const float *B,
+                                               float *C0, float *C1, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
+                                               const float *bias, int relu, void *hip_stream) {
+    if (!C0 || !C1 || ((C1 - C0) % 4) != 0) DCR_FAIL(DCR_EINVAL, "bad SpMM arguments (the two outputs 16 bytes apart modulo 16)");
+    return spmm_dispatch(rowptr, col, val, B, C0, n_rows, n_feat, 2, ldb, ldc, bias, relu, hip_stream, (int64_t)(C1 - C0));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -369,7 +378,7 @@ namespace dcr {
 
 template <int LPR, bool TRAIN, bool EVAL>
 __global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ h_train,
-                                                         float *__restrict__ z_train, float *__restrict__ z_eval,
+                                                         float *__restrict__ z_train, float *__restrict__ z_eval, int64_t ldz,
                                                          unsigned long long *__restrict__ bits, int64_t n_rows, int C, float scale,
                                                          uint32_t threshold, uint64_t seed, uint64_t offset,
                                                          const uint64_t *__restrict__ offset_dev) {
@@ -444,8 +453,8 @@ __global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict_
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int idx = PER * sl + i;  // 0..15: training output idx; 16..31: evaluation output idx - 16
-                if (TRAIN && idx < 16 && idx < C) z_train[row * C + idx] = vals[i];
-                if (EVAL && idx >= 16 && idx - 16 < C) z_eval[row * C + idx - 16] = vals[i];
+                if (TRAIN && idx < 16 && idx < C) z_train[row * ldz + idx] = vals[i];
+                if (EVAL && idx >= 16 && idx - 16 < C) z_eval[row * ldz + idx - 16] = vals[i];
             }
         }
     }
@@ -487,43 +496,43 @@ __global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict_
 
 template <int LPR>
 static void launch_act_linear_fwd(bool train, bool eval, const float *x, const float *w, float *h_train, float *z_train, float *z_eval,
-                                  unsigned long long *bits, int64_t n_rows, int C, float scale, uint32_t threshold, uint64_t seed,
+                                  int64_t ldz, unsigned long long *bits, int64_t n_rows, int C, float scale, uint32_t threshold, uint64_t seed,
                                   uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
     const int64_t n_waves = (n_rows + 64 / LPR - 1) / (64 / LPR);
     int64_t blocks = (n_waves + 3) / 4;
     if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;  // grid-stride: the weights are loaded into registers once per wave
     if (blocks < 1) blocks = 1;
     if (train && eval)
-        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, bits,
+        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
                            n_rows, C, scale, threshold, seed, offset, offset_dev);
     else if (train)
-        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, bits,
+        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
                            n_rows, C, scale, threshold, seed, offset, offset_dev);
     else
-        hipLaunchKernelGGL((k_act_linear_fwd<LPR, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, bits,
+        hipLaunchKernelGGL((k_act_linear_fwd<LPR, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
                            n_rows, C, scale, threshold, seed, offset, offset_dev);
 }
 
 }  // namespace dcr
 
-extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float *h_train, float *z_train, float *z_eval, uint64_t *bits,
-                                          int64_t n_rows, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
-                                          const uint64_t *offset_dev, void *hip_stream) {
+extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float *h_train, float *z_train, float *z_eval, int64_t ldz,
+                                          uint64_t *bits, int64_t n_rows, int hidden, int classes, double p, uint64_t seed,
+                                          uint64_t offset, const uint64_t *offset_dev, void *hip_stream) {
     const bool train = z_train != nullptr, eval = z_eval != nullptr;
     if (!x || !w || n_rows < 0 || (!train && !eval)) DCR_FAIL(DCR_EINVAL, "bad act_linear arguments");
     if (train && (!h_train || !bits || !(p >= 0.0 && p < 1.0))) DCR_FAIL(DCR_EINVAL, "act_linear: training output needs h_train, bits and 0 <= p < 1");
-    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16)
-        DCR_FAIL(DCR_EINVAL, "act_linear: hidden width 64 or 128 and at most 16 classes (other shapes take the separate kernels)");
+    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16 || ldz < classes)
+        DCR_FAIL(DCR_EINVAL, "act_linear: hidden width 64 or 128, at most 16 classes, ldz >= classes (other shapes take the separate kernels)");
     if (((uintptr_t)x & 15) || (h_train && ((uintptr_t)h_train & 15))) DCR_FAIL(DCR_EINVAL, "act_linear: 16-byte aligned tensors expected");
     if (n_rows == 0) return DCR_OK;
     const double th = p * 4294967296.0;
     const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
     const float scale = (float)(1.0 / (1.0 - p));
     if (hidden == 128)
-        dcr::launch_act_linear_fwd<32>(train, eval, x, w, h_train, z_train, z_eval, (unsigned long long *)bits, n_rows, classes, scale, threshold,
+        dcr::launch_act_linear_fwd<32>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,
                                        seed, offset, offset_dev, (hipStream_t)hip_stream);
     else
-        dcr::launch_act_linear_fwd<16>(train, eval, x, w, h_train, z_train, z_eval, (unsigned long long *)bits, n_rows, classes, scale, threshold,
+        dcr::launch_act_linear_fwd<16>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,
                                        seed, offset, offset_dev, (hipStream_t)hip_stream);
     DCR_HIP(hipGetLastError());
     return DCR_OK;

@@ -81,9 +81,16 @@ class GraphedEpoch:
             return False
         return int(data['val_mask'].sum()) > 0 and int(data.train_mask.sum()) > 0
 
+    def _nll(self, log_probs):
+        """F.nll_loss(log_probs[train_mask], y[train_mask]) (training_loop.py:51) with the same gradient, bit for bit (-1 / n at
+        the selected entries): the stock kernel reduces the 100k selected rows in ONE workgroup (0.10 ms forward, 0.07
+        backward at the bench shape), a gather and a mean are a few small multi-workgroup kernels."""
+        picked = log_probs.index_select(0, self.train_idx).gather(1, self.y_train.unsqueeze(1))
+        return -picked.mean()
+
     def _train_step(self):
         log_probs = self.model(self.data)
-        loss = F.nll_loss(log_probs.index_select(0, self.train_idx), self.y_train)
+        loss = self._nll(log_probs)
         loss.backward()
         self.optimizer.step()
         return loss
@@ -152,7 +159,7 @@ class LaggedGraphedEpoch(GraphedEpoch):
             dst.copy_(src)
         lp_train, lp_eval = self.model.forward_pair(self.data)
         correct_prev = lp_eval.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
-        loss = F.nll_loss(lp_train.index_select(0, self.train_idx), self.y_train)
+        loss = self._nll(lp_train)
         loss.backward()
         self.optimizer.step()
         return correct_prev

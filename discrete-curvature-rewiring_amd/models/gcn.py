@@ -120,23 +120,31 @@ def spmm(rowptr, col, val, B, n_rows, bias=None, relu=False):
     return fn(rowptr, col, val, B, n_rows, bias, relu)
 
 
-def spmm_pair(rowptr, col, val, B2, n_rows, n_feat, bias=None):
+def spmm_pair(rowptr, col, val, B2, n_rows, n_feat, bias=None, split=False):
     """[Â·B0 + bias | Â·B1 + bias] for B2 = [B0 | B1] (two blocks of ``n_feat`` columns) in ONE sweep of the indices
-    (``dcr_spmm_csr_f32_pair_dev``): every block bit-identical to a ``spmm`` call of its own."""
+    (``dcr_spmm_csr_f32_pair_dev``): every block bit-identical to a ``spmm`` call of its own.  ``split``: the two blocks
+    as two contiguous matrices (written there by the kernel: no copies afterwards)."""
     if _AGG_BACKEND != 'hip':
-        return torch.cat([_spmm_torch(rowptr, col, val, B2[:, :n_feat], n_rows, bias),
-                          _spmm_torch(rowptr, col, val, B2[:, n_feat:], n_rows, bias)], 1)
+        a, b = (_spmm_torch(rowptr, col, val, B2[:, :n_feat], n_rows, bias), _spmm_torch(rowptr, col, val, B2[:, n_feat:], n_rows, bias))
+        return (a, b) if split else torch.cat([a, b], 1)
     if not B2.is_cuda:
         raise RuntimeError('GCN aggregation runs on the MI355X HIP kernel (there is no CPU fallback)')
     from dcr import _lib
     B2 = B2.contiguous()
-    C = torch.empty((n_rows, 2 * n_feat), dtype=torch.float32, device=B2.device)
     stream = torch.cuda.current_stream(B2.device).cuda_stream
+    if split and n_feat % 4 == 0:
+        C = torch.empty((2, n_rows, n_feat), dtype=torch.float32, device=B2.device)
+        _lib.check(_lib.lib().dcr_spmm_csr_f32_pair_split_dev(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), B2.data_ptr(),
+                                                              C[0].data_ptr(), C[1].data_ptr(), n_rows, n_feat, 2 * n_feat, n_feat,
+                                                              bias.data_ptr() if bias is not None else None, 0,
+                                                              ctypes.c_void_p(stream)))
+        return C[0], C[1]
+    C = torch.empty((n_rows, 2 * n_feat), dtype=torch.float32, device=B2.device)
     _lib.check(_lib.lib().dcr_spmm_csr_f32_pair_dev(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), B2.data_ptr(),
                                                     C.data_ptr(), n_rows, n_feat, 2 * n_feat, 2 * n_feat,
                                                     bias.data_ptr() if bias is not None else None, 0,
                                                     ctypes.c_void_p(stream)))
-    return C
+    return (C[:, :n_feat].contiguous(), C[:, n_feat:].contiguous()) if split else C
 
 
 class _Aggregate(torch.autograd.Function):
@@ -169,8 +177,12 @@ class _AggregatePair(torch.autograd.Function):
         ctx.csr = csr
         ctx.has_bias = bias is not None
         f = z_train.shape[1]
-        out = spmm_pair(csr.rowptr, csr.col, csr.val, torch.cat([z_train, z_eval], 1), csr.n_rows, f, bias=bias)
-        return out[:, :f].contiguous(), out[:, f:].contiguous()
+        if (z_train.is_cuda and z_train.stride() == (2 * f, 1) and z_eval.stride() == (2 * f, 1)
+                and z_eval.data_ptr() == z_train.data_ptr() + 4 * f and z_train.dtype == torch.float32):
+            b2 = torch.as_strided(z_train, (z_train.shape[0], 2 * f), (2 * f, 1))   # the two halves of one buffer (act_then_linear)
+        else:
+            b2 = torch.cat([z_train, z_eval], 1)
+        return spmm_pair(csr.rowptr, csr.col, csr.val, b2, csr.n_rows, f, bias=bias, split=True)
 
     @staticmethod
     def backward(ctx, grad_train, grad_eval):
@@ -292,8 +304,13 @@ class _ActLinearFn(torch.autograd.Function):
         n, hidden = x.shape
         classes = w.shape[0]
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        z_tr = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_train else None
-        z_ev = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_eval else None
+        if want_train and want_eval:  # one buffer [z_train | z_eval]: what the pair aggregation reads, without a concatenation
+            both = torch.empty((n, 2 * classes), dtype=x.dtype, device=x.device)
+            z_tr, z_ev = both[:, :classes], both[:, classes:]
+        else:
+            z_tr = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_train else None
+            z_ev = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_eval else None
+        ldz = 2 * classes if (want_train and want_eval) else classes
         h = bits = ctr = None
         if want_train:
             words = ctypes.c_int64()
@@ -303,7 +320,7 @@ class _ActLinearFn(torch.autograd.Function):
             ctr = _dropout_counter(x.device)
         _lib.check(_lib.lib().dcr_act_linear_fwd_f32_dev(
             x.data_ptr(), w.data_ptr(), h.data_ptr() if want_train else None, z_tr.data_ptr() if want_train else None,
-            z_ev.data_ptr() if want_eval else None, bits.data_ptr() if want_train else None, n, hidden, classes, float(p),
+            z_ev.data_ptr() if want_eval else None, ldz, bits.data_ptr() if want_train else None, n, hidden, classes, float(p),
             torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None, ctypes.c_void_p(stream)))
         if want_train:
             ctr.add_(1)

@@ -193,6 +193,10 @@ int dcr_spmm_csr_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, cons
 int dcr_spmm_csr_f32_pair_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const float *B_dev,
                               float *C_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc, const float *bias_dev,
                               int relu, void *hip_stream);
+/* the same with the two output blocks in matrices of their own (C1 - C0 a multiple of 4 floats; ldc the row stride of both) */
+int dcr_spmm_csr_f32_pair_split_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const float *B_dev,
+                                    float *C0_dev, float *C1_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
+                                    const float *bias_dev, int relu, void *hip_stream);
 
 /* ---- GCN weight gradient on the matrix cores (device pointers, caller's stream)
  * C[M x N] = A^T * B with A [K x M] and B [K x N] row-major fp32 (lda/ldb/ldc in
@@ -226,8 +230,8 @@ int dcr_relu_dropout_bwd_f32_dev(const float *grad_out_dev, float *grad_in_dev, 
  * A null z_train (z_eval) skips that operand.  hidden 64 or 128, classes <= 16 (other shapes: the separate entry points).
  * Backward of the training operand: dx = keep ? (dz·W) / (1 - p) : 0. */
 int dcr_act_linear_fwd_f32_dev(const float *x_dev, const float *w_dev, float *h_train_dev, float *z_train_dev, float *z_eval_dev,
-                               uint64_t *bits_dev, int64_t n_rows, int hidden, int classes, double p, uint64_t seed,
-                               uint64_t offset, const uint64_t *offset_dev, void *hip_stream);
+                               int64_t ldz, uint64_t *bits_dev, int64_t n_rows, int hidden, int classes, double p, uint64_t seed,
+                               uint64_t offset, const uint64_t *offset_dev, void *hip_stream);  /* ldz: row stride of both z */
 int dcr_act_linear_bwd_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, float *dx_dev, int64_t n_rows,
                                int hidden, int classes, double p, void *hip_stream);
 
