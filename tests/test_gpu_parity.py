@@ -764,3 +764,54 @@ def test_fused_tail_and_next_pass_including_row_overflow(dcr, oracle, incrementa
         fused += run._next_argmin is not None
     assert fused >= loops - 5                       # nearly every iteration took the one-sync path
     assert np.array_equal(run.result().edge_index.numpy(), want)
+
+
+@pytest.mark.parametrize('d0,limit', [(50, 62), (818, 1022)])
+def test_fused_tail_replay_when_the_add_crosses_a_degree_class(dcr, oracle, monkeypatch, d0, limit):
+    """The hub sits exactly at the largest degree of its node-centric class AND its row is full: the add inside
+    dcr_sdrf_tail_at_pass_argmin overflows (seen only after the pass has run), the call lays the rows out again, replays
+    the tail and redoes the pass — by then the hub belongs to the next class, whose kernel must be among those launched
+    on both attempts (the bound on the degrees is raised before the pass, not after the add is confirmed)."""
+    monkeypatch.setenv('DCR_PASS', 'nc')
+    rng = np.random.Generator(np.random.PCG64(d0))
+    n = 4 * limit + 200
+    src = [0] * d0
+    dst = list(range(1, d0 + 1))
+    a = rng.integers(1, n, size=3 * n)            # background: every other node far below the hub's class
+    b = rng.integers(1, n, size=3 * n)
+    src += a.tolist()
+    dst += b.tolist()
+    from dcr import synthetic
+    ei = synthetic.coalesced_edge_index(np.array(src), np.array(dst), n)
+    G = dcr(ei, n)
+    C = oracle.CGraph(ei, n)
+    assert G.degree(0) == d0 and max(G.degree(u) for u in range(1, n)) < min(limit, 62)
+    for w in range(d0 + 1, limit + 1):            # capacity d0 + max(8, d0 // 4) == limit: the row is now full
+        G.add_edge(0, w)
+        C.add_edge(0, w)
+    assert G.degree(0) == limit
+    G.curvature_pass('bfc')
+    assert G.pass_engine() == 'node-centric'
+    y = next(v for v in G.neighbors(0) if any(not G.has_edge(0, j) and j != 0 for j in G.neighbors(v)))
+    imp, ci, cj = G.improvements(0, y, 'bfc', want_candidates=True)
+    idx = next(k for k in range(len(ci)) if 0 in (int(ci[k]), int(cj[k])))
+    pair = (int(ci[idx]), int(cj[idx]))
+    added, removed, (mu, mv, mval) = G.sdrf_tail_at_pass_argmin(idx, False, 0.0, 'bfc')
+    assert tuple(added) == pair and removed is None and G.degree(0) == limit + 1
+    C.add_edge(*pair)
+    ou, ov, oc = C.curv_all('bfc', nthreads=4)
+    ru, rv, rc = G.curvature_read()
+    assert np.array_equal(ru, ou) and np.array_equal(rv, ov)
+    bad = np.flatnonzero(rc != oc)
+    assert bad.size == 0, [(int(ru[i]), int(rv[i]), rc[i], oc[i]) for i in bad[:6]]
+    k = int(np.argmin(oc))
+    assert (mu, mv, mval) == (int(ou[k]), int(ov[k]), float(oc[k]))
+    # and a second add right behind it, into the fresh slack, with the hub now inside the next class
+    imp, ci, cj = G.improvements(0, y, 'bfc', want_candidates=True)
+    idx = next(k for k in range(len(ci)) if 0 in (int(ci[k]), int(cj[k])))
+    pair = (int(ci[idx]), int(cj[idx]))
+    G.sdrf_tail_at_pass_argmin(idx, False, 0.0, 'bfc')
+    C.add_edge(*pair)
+    ou, ov, oc = C.curv_all('bfc', nthreads=4)
+    ru, rv, rc = G.curvature_read()
+    assert np.array_equal(ru, ou) and np.array_equal(rv, ov) and np.array_equal(rc, oc)
