@@ -72,7 +72,9 @@ template <int LPR, int VEC, int NBLK>
 __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const float *__restrict__ val, const float *__restrict__ B,
                                                    float *__restrict__ C, int64_t n_rows, int n_feat, int64_t ldb,
-                                                   int64_t ldc, const float *__restrict__ bias, int relu, int blk, int64_t blk_c) {
+                                                   int64_t ldc, const float *__restrict__ bias, int relu, int blk, int64_t blk_c,
+                                                   const int64_t *__restrict__ rows) {
+    // rows: nullptr, or the n_rows rows of the matrix to compute (output row k = row rows[k] of the product)
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     constexpr int G = ROWS_PER_BLOCK;        // lane groups per workgroup
     constexpr int U = LPR <= 8 ? 8 : 4;      // narrow rows of B: more gathers in flight per group
@@ -86,7 +88,8 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
     if (threadIdx.x == 0) n_long = 0;
     __syncthreads();
     if (row < n_rows) {
-        const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+        const int64_t mrow = rows ? rows[row] : row;
+        const int64_t e0 = rowptr[mrow], e1 = rowptr[mrow + 1];
         if (e1 - e0 > SPMM_LONG) {
             if (sl == 0) long_rows[atomicAdd(&n_long, 1)] = sub;
         } else {
@@ -115,7 +118,8 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
     const int nl = n_long;  // uniform
     for (int li = 0; li < nl; ++li) {
         const int64_t lrow = (int64_t)long_rows[li] * gridDim.x + blockIdx.x;
-        const int64_t e0 = rowptr[lrow], e1 = rowptr[lrow + 1];
+        const int64_t lmrow = rows ? rows[lrow] : lrow;
+        const int64_t e0 = rowptr[lmrow], e1 = rowptr[lmrow + 1];
         for (int fb = 0; fb < n_feat; fb += LPR * VEC) {  // uniform trip count
             const int f0 = fb + sl * VEC;
             float acc[NBLK][VEC];
@@ -149,15 +153,15 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
 template <int LPR, int VEC>
 static void launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
                         int64_t n_rows, int n_feat, int64_t ldb, int64_t ldc, const float *bias, int relu, int n_blocks,
-                        int64_t blk_c, hipStream_t st) {
+                        int64_t blk_c, hipStream_t st, const int64_t *rows) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     const int64_t blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (n_blocks == 2)
         hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 2>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                           n_feat, ldb, ldc, bias, relu, n_feat, blk_c);
+                           n_feat, ldb, ldc, bias, relu, n_feat, blk_c, rows);
     else
         hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 1>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                           n_feat, ldb, ldc, bias, relu, 0, (int64_t)0);
+                           n_feat, ldb, ldc, bias, relu, 0, (int64_t)0, rows);
 }
 
 }  // namespace dcr
@@ -166,7 +170,7 @@ using namespace dcr;
 
 static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
                          int64_t n_rows, int64_t n_feat, int64_t n_blocks, int64_t ldb, int64_t ldc, const float *bias, int relu,
-                         void *hip_stream, int64_t blk_c = -1) {
+                         void *hip_stream, int64_t blk_c = -1, const int64_t *rows = nullptr) {
     // blk_c: where the second block of the output starts relative to the first (floats); -1: next to it (n_feat)
     if (!rowptr || !B || !C || n_rows < 0 || n_feat <= 0 || n_blocks < 1 || n_blocks > 2 || ldb < n_feat * n_blocks ||
         ldc < (blk_c < 0 ? n_feat * n_blocks : n_feat))
@@ -179,7 +183,7 @@ static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float 
     // (the template is chosen by the width of ONE block: a block of a two-block call is accumulated exactly like a call of its own)
     const bool v4 = (F % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)B & 15) == 0);
     const bool v2 = (F % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) && (((uintptr_t)B & 7) == 0);
-#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, blk_c, st)
+#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, blk_c, st, rows)
     if (v4) {
         const int lanes = F / 4;
         if (lanes <= 4) GO(4, 4);
@@ -223,6 +227,16 @@ extern "C" int dcr_spmm_csr_f32_pair_split_dev(const int64_t *rowptr, const int3
                                                const float *bias, int relu, void *hip_stream) {
     if (!C0 || !C1 || ((C1 - C0) % 4) != 0) DCR_FAIL(DCR_EINVAL, "bad SpMM arguments (the two outputs 16 bytes apart modulo 16)");
     return spmm_dispatch(rowptr, col, val, B, C0, n_rows, n_feat, 2, ldb, ldc, bias, relu, hip_stream, (int64_t)(C1 - C0));
+}
+
+// Rows rows_dev[0..n_sel) of Â·B (+ bias) only, output row k = row rows_dev[k]: the last layer of a training epoch is read at
+// the training rows (loss) and the validation rows (accuracy) and nowhere else (experiment/training_loop.py:50-51,64-71 index
+// the model's output with the split masks).  Every computed row is accumulated exactly as dcr_spmm_csr_f32_dev does it.
+extern "C" int dcr_spmm_csr_rows_f32_dev(const int64_t *rowptr, const int32_t *col, const float *val, const int64_t *rows,
+                                         int64_t n_sel, const float *B, float *C, int64_t n_feat, int64_t ldb, int64_t ldc,
+                                         const float *bias, int relu, void *hip_stream) {
+    if (!rows && n_sel > 0) DCR_FAIL(DCR_EINVAL, "bad SpMM arguments (no row list)");
+    return spmm_dispatch(rowptr, col, val, B, C, n_sel, n_feat, 1, ldb, ldc, bias, relu, hip_stream, -1, rows);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

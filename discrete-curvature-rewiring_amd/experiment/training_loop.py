@@ -24,13 +24,22 @@ import torch
 import torch.nn.functional as F
 
 
+def _takes_rows(model):
+    """Models of this package compute ``model(data)[mask]`` as ``model(data, rows=mask)``: the last aggregation evaluated at
+    the rows the caller reads (models/gcn.py).  ``DCR_GCN_ALL_ROWS=1``: always the full output, indexed afterwards."""
+    return getattr(model, 'supports_rows', False) and os.environ.get('DCR_GCN_ALL_ROWS', '0') != '1'
+
+
 def train(model, optimizer, data):
     """One optimisation step on the training nodes; returns the loss value (training_loop.py:40-54)."""
     model.train()
     optimizer.zero_grad()
-    log_probs = model(data)
     mask = data.train_mask
-    loss = F.nll_loss(log_probs[mask], data.y[mask])
+    if _takes_rows(model):
+        loss = F.nll_loss(model(data, rows=mask), data.y[mask])
+    else:
+        log_probs = model(data)
+        loss = F.nll_loss(log_probs[mask], data.y[mask])
     loss.backward()
     optimizer.step()
     return loss.item()
@@ -44,6 +53,11 @@ def _accuracy(log_probs, labels, mask):
 def evaluate(model, data, test):
     """Accuracy on the validation split, plus the test split when ``test`` is true (training_loop.py:57-75)."""
     model.eval()
+    if not test and _takes_rows(model):
+        mask = data['val_mask']
+        with torch.no_grad():
+            predicted = model(data, rows=mask).max(1)[1]
+        return {'val_acc': predicted.eq(data.y[mask]).sum().item() / mask.sum().item()}
     with torch.no_grad():
         log_probs = model(data)
     splits = ('val', 'test') if test else ('val',)
@@ -69,6 +83,7 @@ class GraphedEpoch:
         self.y_train = data.y.index_select(0, self.train_idx)
         self.y_val = data.y.index_select(0, self.val_idx)
         self.n_val = int(self.val_idx.numel())
+        self.rows = _takes_rows(model)
 
     @staticmethod
     def supported(model, optimizer, data):
@@ -85,11 +100,12 @@ class GraphedEpoch:
         """F.nll_loss(log_probs[train_mask], y[train_mask]) (training_loop.py:51) with the same gradient, bit for bit (-1 / n at
         the selected entries): the stock kernel reduces the 100k selected rows in ONE workgroup (0.10 ms forward, 0.07
         backward at the bench shape), a gather and a mean are a few small multi-workgroup kernels."""
-        picked = log_probs.index_select(0, self.train_idx).gather(1, self.y_train.unsqueeze(1))
-        return -picked.mean()
+        if not self.rows:
+            log_probs = log_probs.index_select(0, self.train_idx)
+        return -log_probs.gather(1, self.y_train.unsqueeze(1)).mean()
 
     def _train_step(self):
-        log_probs = self.model(self.data)
+        log_probs = self.model(self.data, rows=self.train_idx) if self.rows else self.model(self.data)
         loss = self._nll(log_probs)
         loss.backward()
         self.optimizer.step()
@@ -97,6 +113,8 @@ class GraphedEpoch:
 
     def _val_correct(self):
         with torch.no_grad():
+            if self.rows:
+                return self.model(self.data, rows=self.val_idx).max(1)[1].eq(self.y_val).sum()
             log_probs = self.model(self.data)
         return log_probs.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
 
@@ -157,8 +175,12 @@ class LaggedGraphedEpoch(GraphedEpoch):
     def _fused_step(self):
         for dst, src in zip(self.prev, self.model.state_dict().values()):
             dst.copy_(src)
-        lp_train, lp_eval = self.model.forward_pair(self.data)
-        correct_prev = lp_eval.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
+        if self.rows:
+            lp_train, lp_eval = self.model.forward_pair(self.data, rows_train=self.train_idx, rows_eval=self.val_idx)
+            correct_prev = lp_eval.max(1)[1].eq(self.y_val).sum()
+        else:
+            lp_train, lp_eval = self.model.forward_pair(self.data)
+            correct_prev = lp_eval.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
         loss = self._nll(lp_train)
         loss.backward()
         self.optimizer.step()

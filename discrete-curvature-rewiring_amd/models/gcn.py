@@ -193,6 +193,84 @@ class _AggregatePair(torch.autograd.Function):
         return gz, None, gb, None
 
 
+class RowSelection:
+    """The rows of the last aggregation an epoch reads — the nodes of a split (experiment/training_loop.py:50-51,64-71 index
+    the model's output with the split masks and use nothing else) — and, for the backward pass, Âᵀ restricted to those
+    columns: the gradient of the loss is zero outside them, so dZ = Âᵀ·dOut needs the selected columns only."""
+
+    def __init__(self, csr, rows):
+        idx = rows.nonzero().squeeze(1) if rows.dtype == torch.bool else rows
+        self.idx = idx.to(torch.int64).contiguous()
+        self.n = int(self.idx.numel())
+        self._csr = csr
+        self._t = None
+
+    def transposed(self):
+        """(rowptr, col, val) of Âᵀ[:, idx] with the columns renumbered 0..n-1 (positions in ``idx``); built once."""
+        if self._t is None:
+            csr, dev = self._csr, self.idx.device
+            pos = torch.full((csr.n_rows,), -1, dtype=torch.int32, device=dev)
+            pos[self.idx] = torch.arange(self.n, dtype=torch.int32, device=dev)
+            p = pos[csr.col_t.long()]
+            keep = p >= 0
+            cs = torch.zeros(keep.numel() + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(keep, 0, out=cs[1:])
+            self._t = (cs[csr.rowptr_t].contiguous(), p[keep].contiguous(), csr.val_t[keep].contiguous())
+        return self._t
+
+
+def spmm_rows(csr, sel, B, bias=None):
+    """Rows ``sel.idx`` of Â·B + bias (``dcr_spmm_csr_rows_f32_dev``): [sel.n, F], every row bit-identical to that row of
+    ``spmm``.  ``B`` may be a column block of a wider matrix (stride (ld, 1))."""
+    F = B.shape[1]
+    if _AGG_BACKEND != 'hip':
+        return _spmm_torch(csr.rowptr, csr.col, csr.val, B, csr.n_rows, bias).index_select(0, sel.idx)
+    if not B.is_cuda:
+        raise RuntimeError('GCN aggregation runs on the MI355X HIP kernel (there is no CPU fallback)')
+    if B.dtype != torch.float32:
+        raise TypeError('dcr_spmm_csr_rows_f32_dev is fp32')
+    if B.dim() != 2 or B.stride(1) != 1 or B.stride(0) < F:
+        B = B.contiguous()
+    C = torch.empty((sel.n, F), dtype=torch.float32, device=B.device)
+    if sel.n == 0:
+        return C
+    from dcr import _lib
+    stream = torch.cuda.current_stream(B.device).cuda_stream
+    _lib.check(_lib.lib().dcr_spmm_csr_rows_f32_dev(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(),
+                                                    sel.idx.data_ptr(), sel.n, B.data_ptr(), C.data_ptr(), F, B.stride(0), F,
+                                                    bias.data_ptr() if bias is not None else None, 0, ctypes.c_void_p(stream)))
+    return C
+
+
+class _AggregateRows(torch.autograd.Function):
+    """out = (Â·Z + b)[rows] ; dZ = Âᵀ[:, rows]·dout ; db = Σ dout."""
+
+    @staticmethod
+    def forward(ctx, z, bias, csr, sel):
+        ctx.csr, ctx.sel = csr, sel
+        ctx.has_bias = bias is not None
+        ctx.z_shape = z.shape
+        return spmm_rows(csr, sel, z, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        csr, sel = ctx.csr, ctx.sel
+        grad_out = grad_out.contiguous()
+        gz = None
+        if ctx.needs_input_grad[0]:
+            if sel.n == 0:
+                gz = grad_out.new_zeros(ctx.z_shape)
+            else:
+                rp, ci, va = sel.transposed()
+                gz = spmm(rp, ci, va, grad_out, csr.n_cols)
+        gb = grad_out.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gz, gb, None, None
+
+
+def aggregate_rows(z, bias, csr, sel):
+    return _AggregateRows.apply(z, bias, csr, sel)
+
+
 def atb_hip(a, b):
     """``a.t() @ b`` for tall-skinny fp32 operands [K, M], [K, N] on the hand-written MFMA kernel
     (csrc/dcr_gemm.hip, ``dcr_atb_f32_dev``)."""
@@ -408,6 +486,7 @@ class GCNConv(torch.nn.Module):
         self._ax_key = None
         self._ax = None
         self._ax_ref = None
+        self._rowsel = {}
 
     def reset_parameters(self):
         self.lin.reset_parameters()
@@ -432,6 +511,18 @@ class GCNConv(torch.nn.Module):
         """Drop the cached Â and Â·x (they are rebuilt at the next forward)."""
         self._cache_key = self._cache_csr = self._cache_ref = None
         self._ax_key = self._ax = self._ax_ref = None
+        self._rowsel = {}
+
+    def row_selection(self, rows, csr):
+        """``RowSelection`` of a split (boolean mask or index tensor), cached while the tensor (same storage, same
+        version: held here) and the graph stay the same."""
+        key = (rows.data_ptr(), rows._version, tuple(rows.shape), rows.dtype, str(rows.device), self._cache_key)
+        hit = self._rowsel.get(key)
+        if hit is None:
+            if len(self._rowsel) >= 6:
+                self._rowsel.pop(next(iter(self._rowsel)))
+            hit = self._rowsel[key] = (RowSelection(csr, rows), rows)
+        return hit[0]
 
     def norm_csr(self, edge_index, edge_weight, num_nodes):
         # (PyG 2.0.3 with cached=False renormalises at every call; same result, the graph is a constant of a training
@@ -475,11 +566,18 @@ class GCN(torch.nn.Module):
         for conv in self.layers:
             conv.reset_parameters()
 
-    def forward(self, data):
+    supports_rows = True   # forward(data, rows=...) / forward_pair(data, rows_train=..., rows_eval=...)
+
+    def forward(self, data, rows=None):
         # models/gcn.py:32-44.  The activation after a layer is computed together with the next layer's lin
         # (act_then_linear: one pass over the hidden activation where the fused kernel applies).
+        # rows (a boolean node mask or an index tensor): return the log-probabilities of those nodes only, [len, C] in
+        # index order — what ``model(data)[rows]`` holds, value for value; the last aggregation is evaluated at those
+        # rows and nowhere else.
         layers = list(self.layers)
         h = layers[0](data.x, data.edge_index, edge_weight=data.edge_attr)
+        if rows is not None and len(layers) == 1:
+            h = h[rows] if rows.dtype == torch.bool else h.index_select(0, rows)
         for conv in layers[1:]:
             csr = conv.norm_csr(data.edge_index, data.edge_attr, h.shape[0])
             if self.training:
@@ -488,16 +586,22 @@ class GCN(torch.nn.Module):
                 z = conv.lin(self.dropout(self.act_fn(h)))   # evaluation mode WITH a gradient (not on the training path)
             else:
                 _, z = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
-            h = aggregate(z, conv.bias, csr)
+            if rows is not None and conv is layers[-1]:
+                h = aggregate_rows(z, conv.bias, csr, conv.row_selection(rows, csr))
+            else:
+                h = aggregate(z, conv.bias, csr)
         return torch.nn.functional.log_softmax(h, dim=1)
 
-    def forward_pair(self, data):
+    def forward_pair(self, data, rows_train=None, rows_eval=None):
         """(training-mode log-probabilities with their autograd graph, evaluation-mode log-probabilities) of the SAME
         weights in one pass: what ``model.train(); model(data)`` and ``model.eval(); model(data)`` return, value for
         value.  The two differ only in the dropout between the layers, so the first layer's output is computed once and
         every later aggregation serves both operands in one sweep of the graph (``spmm_pair``).  The validation forward
         of one epoch and the training forward of the next see the same weights (experiment/training_loop.py:25-26:
-        train, then evaluate, then train again), which is what ``LaggedGraphedEpoch`` builds on.  Call in training mode."""
+        train, then evaluate, then train again), which is what ``LaggedGraphedEpoch`` builds on.  Call in training mode.
+        ``rows_train`` / ``rows_eval`` (both or neither): only those nodes' rows of the two outputs, as ``forward(data, rows)``."""
+        if (rows_train is None) != (rows_eval is None):
+            raise ValueError('rows_train and rows_eval go together')
         last = len(self.layers) - 1
         first = self.layers[0]
         o_tr = first(data.x, data.edge_index, edge_weight=data.edge_attr)
@@ -509,7 +613,15 @@ class GCN(torch.nn.Module):
                 z_tr, _ = act_then_linear(o_tr, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=False)
                 _, z_ev = act_then_linear(o_ev, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
             csr = conv.norm_csr(data.edge_index, data.edge_attr, o_tr.shape[0])
-            o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, conv.bias, csr)
+            if rows_train is not None and depth == last:
+                o_tr = aggregate_rows(z_tr, conv.bias, csr, conv.row_selection(rows_train, csr))
+                with torch.no_grad():
+                    o_ev = spmm_rows(csr, conv.row_selection(rows_eval, csr), z_ev, conv.bias)
+            else:
+                o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, conv.bias, csr)
+        if rows_train is not None and last == 0:
+            pick = lambda t, r: t[r] if r.dtype == torch.bool else t.index_select(0, r)
+            o_tr, o_ev = pick(o_tr, rows_train), pick(o_ev, rows_eval)
         log_softmax = torch.nn.functional.log_softmax
         return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)
 

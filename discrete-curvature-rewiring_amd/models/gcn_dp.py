@@ -18,10 +18,13 @@ After backward, the weight gradients (a few tens of kilofloats) are summed with 
 the message is latency-bound, so one call beats one per parameter.  The loss is the masked NLL summed locally and
 divided by the global number of training nodes, so the summed gradients equal the single-GPU gradients.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
-from models.gcn import GCN, act_then_linear, aggregate, gcn_norm_csr, relu_dropout, spmm, spmm_pair
+from models.gcn import (GCN, RowSelection, act_then_linear, aggregate, aggregate_rows, gcn_norm_csr, relu_dropout, spmm, spmm_pair,
+                        spmm_rows)
 
 
 def block_range(n, world, rank):
@@ -86,13 +89,17 @@ class _GatherAggregatePair(torch.autograd.Function):
     moves its half only.  See ``GCN.forward_pair``."""
 
     @staticmethod
-    def forward(ctx, z_train, z_eval, bias, csr, n_total, per, group):
+    def forward(ctx, z_train, z_eval, bias, csr, n_total, per, group, sel_train=None, sel_eval=None):
+        # sel_train / sel_eval (RowSelection of this rank's rows, both or neither): only those rows of the two outputs
         world = dist.get_world_size(group)
         f = z_train.shape[1]
         ctx.csr, ctx.group, ctx.per, ctx.rows, ctx.has_bias = csr, group, per, z_train.shape[0], bias is not None
+        ctx.sel = sel_train
         local = _pad_rows(torch.cat([z_train, z_eval], 1), per).contiguous()
         full = torch.empty((world * per, 2 * f), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(full, local, group=group)
+        if sel_train is not None:
+            return spmm_rows(csr, sel_train, full[:n_total, :f], bias), spmm_rows(csr, sel_eval, full[:n_total, f:], bias)
         out = spmm_pair(csr.rowptr, csr.col, csr.val, full[:n_total].contiguous(), csr.n_rows, f, bias=bias)
         return out[:, :f].contiguous(), out[:, f:].contiguous()
 
@@ -103,7 +110,14 @@ class _GatherAggregatePair(torch.autograd.Function):
         grad_train = grad_train.contiguous()
         gz = None
         if ctx.needs_input_grad[0]:
-            gfull = spmm(csr.rowptr_t, csr.col_t, csr.val_t, grad_train, csr.n_cols)
+            sel = ctx.sel
+            if sel is None:
+                gfull = spmm(csr.rowptr_t, csr.col_t, csr.val_t, grad_train, csr.n_cols)
+            elif sel.n == 0:
+                gfull = grad_train.new_zeros((csr.n_cols, grad_train.shape[1]))
+            else:
+                rp, ci, va = sel.transposed()
+                gfull = spmm(rp, ci, va, grad_train, csr.n_cols)
             g = torch.zeros((world * per, gfull.shape[1]), dtype=gfull.dtype, device=gfull.device)
             g[:gfull.shape[0]] = gfull
             if dist.get_backend(group) == 'nccl':
@@ -114,7 +128,7 @@ class _GatherAggregatePair(torch.autograd.Function):
                 mine = g[rank * per:(rank + 1) * per]
             gz = mine[:ctx.rows].contiguous()
         gb = grad_train.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return gz, None, gb, None, None, None, None
+        return gz, None, gb, None, None, None, None, None, None
 
 
 class ShardedGCN(torch.nn.Module):
@@ -167,25 +181,45 @@ class ShardedGCN(torch.nn.Module):
         dist.all_reduce(t, group=self.group)
         return (t / t.sum() * self.world).tolist()
 
-    def forward(self, x_local):
+    def row_selection(self, idx):
+        """``RowSelection`` of local row indices (an int64 tensor, e.g. from ``_selection``), cached per tensor."""
+        if os.environ.get('DCR_GCN_ALL_ROWS', '0') == '1':
+            return None
+        cache = getattr(self, '_rowsel', None)
+        if cache is None:
+            cache = self._rowsel = {}
+        key = (idx.data_ptr(), idx._version, tuple(idx.shape))
+        if key not in cache:
+            cache[key] = (RowSelection(self.csr, idx), idx)
+        return cache[key][0]
+
+    def forward(self, x_local, rows=None):
+        # rows (RowSelection of local rows): the log-probabilities of those rows only (models/gcn.py GCN.forward)
         h = x_local
         layers = self.gcn.layers
         for i, layer in enumerate(layers):
+            last = i + 1 == len(layers)
             if i == 0 and layer.propagate_input_first and not h.requires_grad:
                 h = layer.lin(self.propagated_input_local(h), layer.bias)   # (Â_p·X)·Wᵀ + b, no exchange
-                if i + 1 < len(layers):
+                if not last:
                     h = relu_dropout(h, self.gcn.act_fn, self.gcn.dropout)
+                elif rows is not None:
+                    h = h.index_select(0, rows.idx)
                 continue
             z_local = layer.lin(h)
             z = _GatherRows.apply(z_local, self.n, self.per, self.group)
-            h = aggregate(z, layer.bias, self.csr)
-            if i + 1 < len(layers):
+            if last and rows is not None:
+                h = aggregate_rows(z, layer.bias, self.csr, rows)
+            else:
+                h = aggregate(z, layer.bias, self.csr)
+            if not last:
                 h = relu_dropout(h, self.gcn.act_fn, self.gcn.dropout)
         return torch.nn.functional.log_softmax(h, dim=1)
 
-    def forward_pair(self, x_local):
+    def forward_pair(self, x_local, rows_train=None, rows_eval=None):
         """(training-mode, evaluation-mode) log-probabilities of this rank's nodes in one pass: one all-gather and one
-        sweep of the local rows of Â per layer for both (``GCN.forward_pair``, data-parallel).  Call in training mode."""
+        sweep of the local rows of Â per layer for both (``GCN.forward_pair``, data-parallel).  Call in training mode.
+        ``rows_train`` / ``rows_eval`` (RowSelection, both or neither): those rows of the two outputs only."""
         layers = list(self.gcn.layers)
         first = layers[0]
         if first.propagate_input_first and not x_local.requires_grad:
@@ -200,7 +234,13 @@ class ShardedGCN(torch.nn.Module):
             else:
                 z_tr, _ = act_then_linear(o_tr, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=True, want_eval=False)
                 _, z_ev = act_then_linear(o_ev, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=False, want_eval=True)
-            o_tr, o_ev = _GatherAggregatePair.apply(z_tr, z_ev, layer.bias, self.csr, self.n, self.per, self.group)
+            if rows_train is not None and layer is layers[-1]:
+                o_tr, o_ev = _GatherAggregatePair.apply(z_tr, z_ev, layer.bias, self.csr, self.n, self.per, self.group,
+                                                        rows_train, rows_eval)
+            else:
+                o_tr, o_ev = _GatherAggregatePair.apply(z_tr, z_ev, layer.bias, self.csr, self.n, self.per, self.group)
+        if rows_train is not None and len(layers) == 1:
+            o_tr, o_ev = o_tr.index_select(0, rows_train.idx), o_ev.index_select(0, rows_eval.idx)
         log_softmax = torch.nn.functional.log_softmax
         return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)
 
@@ -265,10 +305,11 @@ class ShardedGCN(torch.nn.Module):
     def train_step(self, optimizer, x_local, y_local, train_mask_local, n_train_global):
         self.train()
         self.zero_grads()
-        logp = self(x_local)
         idx, y_sel, count = self._selection(train_mask_local, y_local)
+        rows = self.row_selection(idx)
+        logp = self(x_local, rows=rows)
         if count:
-            loss = torch.nn.functional.nll_loss(logp.index_select(0, idx), y_sel, reduction='sum')
+            loss = torch.nn.functional.nll_loss(logp if rows is not None else logp.index_select(0, idx), y_sel, reduction='sum')
         else:
             loss = logp.sum() * 0.0
         loss = loss / n_train_global
@@ -282,18 +323,23 @@ class ShardedGCN(torch.nn.Module):
         STARTED from (the evaluation of the previous epoch: ``LaggedGraphedEpoch`` in experiment/training_loop.py)."""
         self.train()
         self.zero_grads()
-        lp_train, lp_eval = self.forward_pair(x_local)
         idx, y_sel, count = self._selection(train_mask_local, y_local)
+        vidx, vy, vcount = self._selection(val_mask_local, y_local)
+        rows_tr, rows_ev = self.row_selection(idx), self.row_selection(vidx)
+        lp_train, lp_eval = self.forward_pair(x_local, rows_tr, rows_ev)
+        if rows_tr is None:
+            lp_train_sel, lp_eval_sel = lp_train.index_select(0, idx), (lp_eval.index_select(0, vidx) if vcount else lp_eval)
+        else:
+            lp_train_sel, lp_eval_sel = lp_train, lp_eval
         if count:
-            loss = torch.nn.functional.nll_loss(lp_train.index_select(0, idx), y_sel, reduction='sum')
+            loss = torch.nn.functional.nll_loss(lp_train_sel, y_sel, reduction='sum')
         else:
             loss = lp_train.sum() * 0.0
         (loss / n_train_global).backward()
         self.allreduce_grads()
         optimizer.step()
         with torch.no_grad():
-            vidx, vy, vcount = self._selection(val_mask_local, y_local)
-            correct = (lp_eval.index_select(0, vidx).argmax(1) == vy).sum() if vcount else lp_eval.new_zeros((), dtype=torch.long)
+            correct = (lp_eval_sel.argmax(1) == vy).sum() if vcount else lp_eval.new_zeros((), dtype=torch.long)
             stats = torch.stack([correct.double(), torch.full((), float(vcount), dtype=torch.float64, device=lp_eval.device)])
             dist.all_reduce(stats, group=self.group)
         return stats
@@ -302,9 +348,12 @@ class ShardedGCN(torch.nn.Module):
     def eval_stats(self, x_local, y_local, mask_local):
         """{correct, count} over all ranks as a 2-element float64 device tensor (no host synchronisation)."""
         self.eval()
-        logp = self(x_local)
         idx, y_sel, count = self._selection(mask_local, y_local)
-        correct = (logp.index_select(0, idx).argmax(1) == y_sel).sum() if count else logp.new_zeros((), dtype=torch.long)
+        rows = self.row_selection(idx)
+        logp = self(x_local, rows=rows)
+        if rows is None:
+            logp = logp.index_select(0, idx)
+        correct = (logp.argmax(1) == y_sel).sum() if count else logp.new_zeros((), dtype=torch.long)
         stats = torch.stack([correct.double(), torch.full((), float(count), dtype=torch.float64, device=logp.device)])
         dist.all_reduce(stats, group=self.group)
         return stats

@@ -197,6 +197,13 @@ int dcr_spmm_csr_f32_pair_dev(const int64_t *rowptr_dev, const int32_t *col_dev,
 int dcr_spmm_csr_f32_pair_split_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const float *B_dev,
                                     float *C0_dev, float *C1_dev, int64_t n_rows, int64_t n_feat, int64_t ldb, int64_t ldc,
                                     const float *bias_dev, int relu, void *hip_stream);
+/* Only the rows rows_dev[0..n_sel) of the product: C[k,:] = row rows_dev[k] of Â·B (+ bias), each accumulated exactly as
+ * dcr_spmm_csr_f32_dev accumulates it.  The reference indexes the model's output with the split masks and reads nothing else
+ * (experiment/training_loop.py:50-51 log_probs[train_mask]; :64-71 log_probs[mask] of the evaluated split): the last layer's
+ * aggregation (models/gcn.py:36) is evaluated at those rows. */
+int dcr_spmm_csr_rows_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const int64_t *rows_dev,
+                              int64_t n_sel, const float *B_dev, float *C_dev, int64_t n_feat, int64_t ldb, int64_t ldc,
+                              const float *bias_dev, int relu, void *hip_stream);
 
 /* ---- GCN weight gradient on the matrix cores (device pointers, caller's stream)
  * C[M x N] = A^T * B with A [K x M] and B [K x N] row-major fp32 (lda/ldb/ldc in

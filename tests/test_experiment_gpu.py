@@ -229,3 +229,76 @@ def test_one_graph_per_epoch_training_loop_equals_the_plain_loop(epochs, patienc
     for (k1, v1), (k2, v2) in zip(best_w.items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2), k1
     assert tl.evaluate(m2, data, test=False)['val_acc'] == best
+
+
+def test_row_selected_forward_is_the_indexed_full_forward():
+    """``model(data, rows=mask)`` against ``model(data)[mask]`` (what experiment/training_loop.py:50-51,64-71 read): the same
+    bits forward — every selected row is accumulated as the full aggregation accumulates it — in both modes, for masks and
+    index tensors, and through ``forward_pair``; the gradients agree to rounding (the backward pass leaves out terms that
+    are exactly zero, which changes the summation grouping of rows above 96 non-zeros only)."""
+    from models.gcn import RowSelection, gcn_norm_csr, spmm, spmm_rows
+    model, _, data = _gcn_case(0.0)
+    n = data.num_nodes
+    csr = gcn_norm_csr(data.edge_index, None, n)
+    assert int((csr.rowptr[1:] - csr.rowptr[:-1]).max()) > 96          # both row paths of the kernel are exercised
+    g = torch.Generator(device='cuda').manual_seed(7)
+    sel = RowSelection(csr, data.train_mask)
+    hubs_first = torch.argsort(csr.rowptr[1:] - csr.rowptr[:-1], descending=True)[:200].contiguous()
+    for f in (5, 16, 32, 6):
+        wide = torch.randn(n, 2 * f, device='cuda', generator=g)
+        bias = torch.randn(f, device='cuda', generator=g)
+        for B in (wide[:, :f], wide[:, f:], wide[:, f:].contiguous()):
+            full = spmm(csr.rowptr, csr.col, csr.val, B.contiguous(), csr.n_rows, bias=bias)
+            assert torch.equal(spmm_rows(csr, sel, B, bias), full[data.train_mask])
+            assert torch.equal(spmm_rows(csr, RowSelection(csr, hubs_first), B, bias), full.index_select(0, hubs_first))
+    assert spmm_rows(csr, RowSelection(csr, torch.zeros(n, dtype=torch.bool, device='cuda')), wide[:, :f]).shape == (0, f)
+    # the transposed, column-restricted matrix against the full transposed product of a gradient that is zero elsewhere
+    grad = torch.zeros(n, 16, device='cuda')
+    compact = torch.randn(sel.n, 16, device='cuda', generator=g)
+    grad[data.train_mask] = compact
+    want = spmm(csr.rowptr_t, csr.col_t, csr.val_t, grad, csr.n_cols)
+    rp, ci, va = sel.transposed()
+    got = spmm(rp, ci, va, compact, csr.n_cols)
+    short = (csr.rowptr_t[1:] - csr.rowptr_t[:-1]) <= 96
+    assert torch.equal(got[short], want[short])                         # rows accumulated in order: zero terms change nothing
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    val_idx = data.val_mask.nonzero().squeeze(1)
+    for mode in ('train', 'eval'):
+        model.train(mode == 'train')
+        with torch.no_grad():
+            full = model(data)
+            assert torch.equal(model(data, rows=data.train_mask), full[data.train_mask])
+            assert torch.equal(model(data, rows=val_idx), full.index_select(0, val_idx))
+    model.train()
+    lp_tr, lp_ev = model.forward_pair(data, rows_train=data.train_mask, rows_eval=val_idx)
+    f_tr, f_ev = model.forward_pair(data)
+    assert torch.equal(lp_tr, f_tr[data.train_mask]) and torch.equal(lp_ev, f_ev.index_select(0, val_idx))
+    y = data.y[data.train_mask]
+    model.zero_grad()
+    torch.nn.functional.nll_loss(lp_tr, y).backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    torch.nn.functional.nll_loss(f_tr[data.train_mask], y).backward()
+    for a, p in zip(got, model.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-4, atol=1e-7), (a - p.grad).abs().max()
+
+
+def test_epochs_on_selected_rows_follow_the_full_output_epochs(monkeypatch):
+    """Twelve epochs with the last aggregation evaluated at the split rows against twelve epochs on the full output
+    (DCR_GCN_ALL_ROWS=1): the same accuracies, weights equal to rounding."""
+    import experiment.training_loop as tl
+    runs = {}
+    for all_rows in ('1', '0'):
+        monkeypatch.setenv('DCR_GCN_ALL_ROWS', all_rows)
+        model, opt, data = _gcn_case(0.0)
+        accs = []
+        for _ in range(12):
+            tl.train(model, opt, data)
+            accs.append(tl.evaluate(model, data, test=False)['val_acc'])
+        data.test_mask = ~(data.train_mask | data.val_mask)
+        both = tl.evaluate(model, data, test=True)          # (two splits: the full output, indexed twice)
+        assert both['val_acc'] == accs[-1] and 0 <= both['test_acc'] <= 1
+        runs[all_rows] = (accs, [p.detach().clone() for p in model.parameters()])
+    assert runs['0'][0] == runs['1'][0]
+    for a, b in zip(runs['0'][1], runs['1'][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
