@@ -479,9 +479,12 @@ __global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict_
 template <int LPR>
 __global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict__ dz, const float *__restrict__ w,
                                                          const unsigned long long *__restrict__ bits, float *__restrict__ dx,
-                                                         int64_t n_rows, int C, float scale) {
+                                                         int64_t n_rows, int C, float scale, float *__restrict__ colpart) {
+    // colpart (nullable): [gridDim.x][H] column sums of the rows this workgroup wrote — the bias gradient of the layer that
+    // produced x is the column sum of dx, and dx is in registers here (k_colsum_finish adds the workgroups' parts in order)
     constexpr int H = 4 * LPR, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     float wr[16][4];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -503,9 +506,39 @@ __global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict_
             for (int j = 0; j < 16; ++j) acc = fmaf(g[j], wr[j][q], acc);
             const bool keep = (bits[wv * 4 + q] >> lane) & 1ull;
             o[q] = keep ? acc * scale : 0.f;
+            cs[q] += o[q];
         }
         *reinterpret_cast<float4 *>(dx + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    if (colpart) {  // uniform
+        __shared__ float red[4][H];
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[q] += __shfl_xor(cs[q], m, 64);
+        if (sub == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[threadIdx.x >> 6][4 * sl + q] = cs[q];
+        __syncthreads();
+        if (threadIdx.x < H)
+            colpart[(int64_t)blockIdx.x * H + threadIdx.x] =
+                (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// out[c] = sum over the parts of column c, in a fixed order (one workgroup per column)
+__global__ void __launch_bounds__(256) k_colsum_finish(const float *__restrict__ part, int64_t n_parts, int H, float *__restrict__ out) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float a = 0.f;
+    for (int64_t i = threadIdx.x; i < n_parts; i += 256) a += part[i * H + c];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
 }
 
 template <int LPR>
@@ -552,23 +585,55 @@ extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float 
     return DCR_OK;
 }
 
-extern "C" int dcr_act_linear_bwd_f32_dev(const float *dz, const float *w, const uint64_t *bits, float *dx, int64_t n_rows, int hidden,
-                                          int classes, double p, void *hip_stream) {
-    if (!dz || !w || !bits || !dx || n_rows < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd arguments");
-    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: unsupported shape");
-    if ((uintptr_t)dx & 15) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: 16-byte aligned tensors expected");
-    if (n_rows == 0) return DCR_OK;
+static int64_t act_linear_bwd_blocks(int64_t n_rows, int hidden) {
     const int lpr = hidden / 4;
     const int64_t n_waves = (n_rows + 64 / lpr - 1) / (64 / lpr);
     int64_t blocks = (n_waves + 3) / 4;
     if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+    return blocks < 1 ? 1 : blocks;
+}
+
+extern "C" int dcr_act_linear_bwd_workspace(int64_t n_rows, int hidden, int64_t *floats) {
+    if (!floats || n_rows < 0 || (hidden != 64 && hidden != 128)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd_workspace arguments");
+    *floats = act_linear_bwd_blocks(n_rows, hidden) * hidden;
+    return DCR_OK;
+}
+
+static int act_linear_bwd(const float *dz, const float *w, const uint64_t *bits, float *dx, float *colsum, float *ws, int64_t ws_floats,
+                          int64_t n_rows, int hidden, int classes, double p, void *hip_stream);
+
+extern "C" int dcr_act_linear_bwd_f32_dev(const float *dz, const float *w, const uint64_t *bits, float *dx, int64_t n_rows, int hidden,
+                                          int classes, double p, void *hip_stream) {
+    return act_linear_bwd(dz, w, bits, dx, nullptr, nullptr, 0, n_rows, hidden, classes, p, hip_stream);
+}
+
+extern "C" int dcr_act_linear_bwd_colsum_f32_dev(const float *dz, const float *w, const uint64_t *bits, float *dx, float *colsum,
+                                                 float *ws, int64_t ws_floats, int64_t n_rows, int hidden, int classes, double p,
+                                                 void *hip_stream) {
+    if (!colsum || !ws) DCR_FAIL(DCR_EINVAL, "act_linear_bwd_colsum: colsum and workspace expected");
+    return act_linear_bwd(dz, w, bits, dx, colsum, ws, ws_floats, n_rows, hidden, classes, p, hip_stream);
+}
+
+static int act_linear_bwd(const float *dz, const float *w, const uint64_t *bits, float *dx, float *colsum, float *ws, int64_t ws_floats,
+                          int64_t n_rows, int hidden, int classes, double p, void *hip_stream) {
+    if (!dz || !w || !bits || !dx || n_rows < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd arguments");
+    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: unsupported shape");
+    if ((uintptr_t)dx & 15) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: 16-byte aligned tensors expected");
+    const int64_t blocks = act_linear_bwd_blocks(n_rows, hidden);
+    if (colsum && ws_floats < blocks * hidden) DCR_FAIL(DCR_EINVAL, "act_linear_bwd_colsum: workspace too small (dcr_act_linear_bwd_workspace)");
+    if (n_rows == 0) {
+        if (colsum) DCR_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * hidden, (hipStream_t)hip_stream));
+        return DCR_OK;
+    }
     const float scale = (float)(1.0 / (1.0 - p));
     if (hidden == 128)
         hipLaunchKernelGGL((dcr::k_act_linear_bwd<32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, dz, w,
-                           (const unsigned long long *)bits, dx, n_rows, classes, scale);
+                           (const unsigned long long *)bits, dx, n_rows, classes, scale, colsum ? ws : nullptr);
     else
         hipLaunchKernelGGL((dcr::k_act_linear_bwd<16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, dz, w,
-                           (const unsigned long long *)bits, dx, n_rows, classes, scale);
+                           (const unsigned long long *)bits, dx, n_rows, classes, scale, colsum ? ws : nullptr);
+    if (colsum)
+        hipLaunchKernelGGL(dcr::k_colsum_finish, dim3((unsigned)hidden), dim3(256), 0, (hipStream_t)hip_stream, ws, blocks, hidden, colsum);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }

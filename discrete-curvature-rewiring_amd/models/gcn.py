@@ -295,6 +295,8 @@ class _LinearFn(torch.autograd.Function):
     """y = x·Wᵀ (+ b) through the GEMM library; dW = dyᵀ·x (a reduction over all nodes) on the hand-written MFMA
     kernel."""
 
+    colsum_handoffs = 0   # bias gradients taken from the kernel that produced grad_out (read by the tests)
+
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
@@ -311,7 +313,14 @@ class _LinearFn(torch.autograd.Function):
             # and 3.9x slower at 1M nodes); for wide layers on small graphs the library is as fast
             tall = x.shape[0] >= 64 * max(x.shape[1], grad_out.shape[1])
             gw = atb_hip(grad_out, x) if tall else grad_out.t() @ x
-        gb = grad_out.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            ready = getattr(grad_out, '_dcr_colsum', None)   # left there by the kernel that produced this gradient
+            if ready is not None and ready[:2] == (grad_out.data_ptr(), grad_out._version):
+                gb = ready[2]
+                _LinearFn.colsum_handoffs += 1
+            else:
+                gb = grad_out.sum(0)
         return gx, gw, gb
 
 
@@ -416,9 +425,17 @@ class _ActLinearFn(torch.autograd.Function):
         gx = gw = None
         stream = torch.cuda.current_stream(g_tr.device).cuda_stream
         if ctx.needs_input_grad[0]:
+            # dx and, from the same registers, its column sums: the bias gradient of the layer that produced x, which
+            # _LinearFn.backward picks up instead of reading the N x H gradient once more
             gx = torch.empty_like(h)
-            _lib.check(_lib.lib().dcr_act_linear_bwd_f32_dev(g_tr.data_ptr(), w.data_ptr(), ctx.bits.data_ptr(), gx.data_ptr(),
-                                                             h.shape[0], h.shape[1], w.shape[0], ctx.p, ctypes.c_void_p(stream)))
+            need = ctypes.c_int64()
+            _lib.check(_lib.lib().dcr_act_linear_bwd_workspace(h.shape[0], h.shape[1], ctypes.byref(need)))
+            ws = torch.empty(max(need.value, 1), dtype=torch.float32, device=h.device)
+            colsum = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
+            _lib.check(_lib.lib().dcr_act_linear_bwd_colsum_f32_dev(g_tr.data_ptr(), w.data_ptr(), ctx.bits.data_ptr(), gx.data_ptr(),
+                                                                    colsum.data_ptr(), ws.data_ptr(), need.value, h.shape[0], h.shape[1],
+                                                                    w.shape[0], ctx.p, ctypes.c_void_p(stream)))
+            gx._dcr_colsum = (gx.data_ptr(), gx._version, colsum)
         if ctx.needs_input_grad[1]:
             gw = atb_hip(g_tr, h) if h.shape[0] >= 64 * max(h.shape[1], g_tr.shape[1]) else g_tr.t() @ h
         return gx, gw, None, None, None

@@ -241,6 +241,13 @@ int dcr_act_linear_fwd_f32_dev(const float *x_dev, const float *w_dev, float *h_
                                uint64_t offset, const uint64_t *offset_dev, void *hip_stream);  /* ldz: row stride of both z */
 int dcr_act_linear_bwd_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, float *dx_dev, int64_t n_rows,
                                int hidden, int classes, double p, void *hip_stream);
+/* The same pass, also returning colsum_dev[hidden] = the column sums of dx: the bias gradient of the layer that produced x
+ * (models/gcn.py:36, `bias` of the previous GCNConv) without reading dx again.  ws_dev: dcr_act_linear_bwd_workspace floats;
+ * the parts are added in a fixed order (deterministic). */
+int dcr_act_linear_bwd_workspace(int64_t n_rows, int hidden, int64_t *floats);
+int dcr_act_linear_bwd_colsum_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, float *dx_dev,
+                                      float *colsum_dev, float *ws_dev, int64_t ws_floats, int64_t n_rows, int hidden, int classes,
+                                      double p, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -530,3 +530,19 @@ def test_activation_fused_into_the_next_contraction(hidden, classes, n):
     only_tr = _ActLinearFn.apply(x, w, p, True, False)[0]
     only_ev = _ActLinearFn.apply(x, w, 0.0, False, True)[1]
     assert torch.equal(only_tr, z_tr.detach()) and torch.equal(only_ev, z_ev)
+    # behind a layer with a bias: its bias gradient comes out of the same backward pass (column sums of dx)
+    from models.gcn import _LinearFn
+    a = torch.randn(n, 24, device=dev, generator=g)
+    w1 = (torch.randn(hidden, 24, device=dev, generator=g) * 0.2).requires_grad_(True)
+    b1 = torch.zeros(hidden, device=dev, requires_grad=True)
+    before = _LinearFn.colsum_handoffs
+    ctr.copy_(c0)
+    pre = _LinearFn.apply(a, w1, b1)
+    z, _ = _ActLinearFn.apply(pre, wr.detach(), p, True, False)
+    z.backward(gz)
+    assert _LinearFn.colsum_handoffs == before + 1
+    ctr.copy_(c0)
+    keep1 = _ReluDropoutFn.apply(pre.detach(), p) != 0          # the separate kernel again: the mask of call number c0
+    want_gpre = torch.where(keep1, (gz.double() @ w.double()).float() / (1 - p), torch.zeros_like(pre)).double()
+    assert (b1.grad.double() - want_gpre.sum(0)).abs().max().item() < 1e-3 * max(1.0, float(n) ** 0.5)
+    assert (w1.grad.double() - want_gpre.t() @ a.double()).abs().max().item() < 1e-2 * max(1.0, float(n) ** 0.5)
