@@ -1488,15 +1488,16 @@ __global__ void __launch_bounds__(256) k_h2_weight(View g, int32_t *weight) {
     const int lane = threadIdx.x & 63;
     int u = -1, val = 0;
     if (s < g.cap_total) {
-        u = g.slot_row[s];
-        if (u >= 0 && u < g.n) {
-            const int2 ru = g.rowinfo[u];
-            if ((int)(s - ru.x) < ru.y && s >= ru.x) {
-                const int v = g.col[s];
-                if (v >= 0 && v < g.n) val = g.rowinfo[v].y;
-            }
-        } else {
-            u = -1;
+        // two rounds of loads, not four: the slot's row and neighbour first (both in bounds for every slot), then the two
+        // row headers; what the slot holds is validated afterwards (slack behind a row holds -1)
+        const int us = g.slot_row[s];
+        const int v = g.col[s];
+        const bool uok = us >= 0 && us < g.n, vok = v >= 0 && v < g.n;
+        const int2 ru = g.rowinfo[uok ? us : 0];
+        const int dv = g.rowinfo[vok ? v : 0].y;
+        if (uok) {
+            u = us;
+            if (vok && s >= ru.x && (int)(s - ru.x) < ru.y) val = dv;
         }
     }
 #pragma unroll
@@ -1586,7 +1587,7 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
         const int c = (int)threadIdx.x - 64;
         int64_t tot = 0;
         for (int b = c * H2_WB; b < (c + 1) * H2_WB; ++b) tot += res->h2_bucket[b];
-        if (tot > L.cap[c]) {  // the list cannot hold them: nothing of this class runs, the pass is redone elsewhere
+        if (tot > (c == 0 ? L.cap[0] : c == 1 ? L.cap[1] : c == 2 ? L.cap[2] : c == 3 ? L.cap[3] : L.cap[4])) {  // the list cannot hold them: nothing of this class runs, the pass is redone elsewhere
             res->h2_status = 1;
             tot = 0;
         }
@@ -1595,8 +1596,12 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
     __syncthreads();
     if (bkt >= 0) {
         const int64_t first = (int64_t)blk_base[bkt] + my_off;
-        if (nparts <= 65535 && first >= 0 && first + nunits <= L.cap[cls]) {
-            for (int j = 0; j < nunits; ++j) L.units[cls][first + j] = make_int4(u, (nparts << 16) | j, ru.x, ru.y);
+        // (selects, not L.units[cls]: indexing a kernel argument with a run-time value puts the whole struct into scratch)
+        int4 *dst = cls == 0 ? L.units[0] : cls == 1 ? L.units[1] : cls == 2 ? L.units[2] : cls == 3 ? L.units[3] : L.units[4];
+        const int64_t cap = cls == 0 ? L.cap[0] : cls == 1 ? L.cap[1] : cls == 2 ? L.cap[2] : cls == 3 ? L.cap[3] : L.cap[4];
+        static_assert(H2_CLASSES == 5, "the selects above list the classes");
+        if (nparts <= 65535 && first >= 0 && first + nunits <= cap) {
+            for (int j = 0; j < nunits; ++j) dst[first + j] = make_int4(u, (nparts << 16) | j, ru.x, ru.y);
         } else if (nparts > 65535) {
             res->h2_status = 1;
         }  // (else: reported through h2_count / h2_status above)
