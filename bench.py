@@ -113,7 +113,7 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=train_mask, val_mask=val_mask)
     model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
     opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                            {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True)
+                            {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True, fused=True)
 
     def sync():
         if dist is not None:
@@ -264,7 +264,7 @@ def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, ep
     torch.manual_seed(0)
     model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=dropout).to(dev)
     opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                            {'params': model.reg_params, 'weight_decay': wd}], lr=lr, capturable=True)
+                            {'params': model.reg_params, 'weight_decay': wd}], lr=lr, capturable=True, fused=True)
     # the epoch as experiment/training_loop.py runs it: eager for the first calls, then two captured HIP graphs
     epoch = make_epoch(model, opt, data, lagged=True)
     for _ in range(10):

@@ -390,125 +390,161 @@ extern "C" int dcr_relu_dropout_bwd_f32_dev(const float *grad_out, float *grad_i
 // every lane with 32 / LPR finished outputs.  Memory-bound: N·H·4 read + N·H·4 written + 2·N·C·4.
 namespace dcr {
 
-template <int LPR, bool TRAIN, bool EVAL>
+// MFMA form.  A wave takes 16 rows at a time; lane (i = lane & 15, g = lane >> 4) loads, for m = 0 .. H/16 - 1, the four
+// floats x[row i][16m + 4g ..] — exactly the A-operand shape of v_mfma_f32_16x16x4_f32 (lane l supplies A[l & 15][k = l >> 4])
+// when step (m, q) takes the k index g to be hidden column 16m + 4g + q; the matching B operand W[class i][16m + 4g + q] sits
+// in 4·H/16 registers per lane for the whole kernel.  Two accumulator tiles (training, evaluation) of 4 registers each hold
+// z[row 4g + r][class i]: no cross-lane reduction at all (the VALU version spent more on its reduce-scatter than on the
+// products, and both on top of Philox made it ALU-bound at 0.36 ms for 1.2 GB).  The float4 a lane holds is element
+// t = row·H/4 + 4m + g of k_relu_dropout_fwd's numbering: same Philox counter, same place in the bit words
+// (word 4·(t >> 6) + q, bit t & 63), assembled here with two OR-exchanges across g and one or two across neighbouring rows.
+template <int HM, bool TRAIN, bool EVAL>
 __global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ h_train,
                                                          float *__restrict__ z_train, float *__restrict__ z_eval, int64_t ldz,
                                                          unsigned long long *__restrict__ bits, int64_t n_rows, int C, float scale,
                                                          uint32_t threshold, uint64_t seed, uint64_t offset,
                                                          const uint64_t *__restrict__ offset_dev) {
-    constexpr int H = 4 * LPR, RPW = 64 / LPR;  // rows per wave
+    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR;  // RPW rows share one set of four bit words
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (TRAIN && offset_dev) offset += *offset_dev;
-    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
-    float wr[16][4];
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    float wb[HM][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int m = 0; m < HM; ++m) {
+        const float4 t = i < C ? *reinterpret_cast<const float4 *>(w + (int64_t)i * H + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wb[m][0] = t.x; wb[m][1] = t.y; wb[m][2] = t.z; wb[m][3] = t.w;
+    }
+    const int64_t n_tiles = (n_rows + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 16 + i;
+        const bool live = row < n_rows;
+        float v[HM][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wr[j][q] = j < C ? w[(int64_t)j * H + 4 * sl + q] : 0.f;
-    const int64_t n_waves = (n_rows + RPW - 1) / RPW;
-    for (int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wv < n_waves; wv += (int64_t)gridDim.x * 4) {
-        const int64_t row = wv * RPW + sub;
-        const int64_t t = row * LPR + sl;  // the thread of k_relu_dropout_fwd that owns these four elements (= 64 wv + lane)
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < n_rows) {
-            const float4 q = *reinterpret_cast<const float4 *>(x + t * 4);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        for (int m = 0; m < HM; ++m) {
+            const float4 t = live ? *reinterpret_cast<const float4 *>(x + row * H + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[m][0] = t.x; v[m][1] = t.y; v[m][2] = t.z; v[m][3] = t.w;
         }
-        float vals[32];
+        f32x4 acc_tr = {0.f, 0.f, 0.f, 0.f}, acc_ev = {0.f, 0.f, 0.f, 0.f};
         if (TRAIN) {
-            uint32_t r[4];
-            philox4x32_10((uint64_t)t, offset, seed, r);
-            bool keep[4];
-            float o[4];
+            uint32_t part[4] = {0u, 0u, 0u, 0u};  // keep bits of this lane's elements, bit 4m + g of column q's word
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                keep[j] = v[j] > 0.f && r[j] >= threshold;
-                o[j] = keep[j] ? v[j] * scale : 0.f;
+            for (int m = 0; m < HM; ++m) {
+                const int64_t t = row * LPR + 4 * m + g;
+                uint32_t r[4];
+                philox4x32_10((uint64_t)t, offset, seed, r);
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool keep = v[m][q] > 0.f && r[q] >= threshold;
+                    o[q] = keep ? v[m][q] * scale : 0.f;
+                    part[q] |= keep ? (1u << (4 * m + g)) : 0u;
+                }
+                if (live) *reinterpret_cast<float4 *>(h_train + row * H + 16 * m + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc_tr = __builtin_amdgcn_mfma_f32_16x16x4f32(o[q], wb[m][q], acc_tr, 0, 0, 0);
             }
-            if (row < n_rows) *reinterpret_cast<float4 *>(h_train + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            // bit words: OR over the four g of a row, then over the RPW rows of a word (row s of them shifted by s·LPR)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned long long m = __ballot(keep[j]);
-                if (lane == 0) bits[wv * 4 + j] = m;
+            for (int q = 0; q < 4; ++q) {
+                uint32_t p = part[q];
+                p |= (uint32_t)__shfl_xor((int)p, 16);
+                p |= (uint32_t)__shfl_xor((int)p, 32);
+                unsigned long long word = (unsigned long long)p << ((i % RPW) * LPR);
+                uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+#pragma unroll
+                for (int d = 1; d < RPW; d <<= 1) {
+                    lo |= (uint32_t)__shfl_xor((int)lo, d);
+                    hi |= (uint32_t)__shfl_xor((int)hi, d);
+                }
+                if (g == 0 && (i % RPW) == 0 && live) bits[(row / RPW) * 4 + q] = ((unsigned long long)hi << 32) | lo;
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) vals[j] = fmaf(o[3], wr[j][3], fmaf(o[2], wr[j][2], fmaf(o[1], wr[j][1], o[0] * wr[j][0])));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) vals[j] = 0.f;
         }
         if (EVAL) {
-            float e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = v[j] > 0.f ? v[j] : 0.f;
+            for (int m = 0; m < HM; ++m)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) vals[16 + j] = fmaf(e[3], wr[j][3], fmaf(e[2], wr[j][2], fmaf(e[1], wr[j][1], e[0] * wr[j][0])));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) vals[16 + j] = 0.f;
+                for (int q = 0; q < 4; ++q)
+                    acc_ev = __builtin_amdgcn_mfma_f32_16x16x4f32(v[m][q] > 0.f ? v[m][q] : 0.f, wb[m][q], acc_ev, 0, 0, 0);
         }
-        // reduce-scatter over the LPR lanes of the row: after the step with distance s a lane keeps the half of its
-        // values selected by that bit of its index, so lane sl ends with values (32 / LPR) * sl ... + 32 / LPR - 1
+        // accumulator register r of lane (i, g) is z[row 4g + r of the tile][class i]
+        if (i < C) {
 #pragma unroll
-        // (the two-way choice is written as a bit select — one v_bfi_b32 — on purpose: as `up ? vals[a] : vals[b]` the
-        //  compiler turned it into a dynamically indexed register array, i.e. a chain of 32 compare-and-selects per
-        //  value: 1,700 of them per row pair, 3.7 ms for the kernel)
-        for (int s = LPR / 2, n = 32; s >= 1; s >>= 1, n >>= 1) {
-            const unsigned um = (sl & s) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i >= n / 2) continue;  // (compile-time after unrolling)
-                const unsigned lo = __float_as_uint(vals[i]), hi = __float_as_uint(vals[i + n / 2]);
-                const float mine = __uint_as_float((hi & um) | (lo & ~um)), other = __uint_as_float((lo & um) | (hi & ~um));
-                vals[i] = mine + __shfl_xor(other, s);
-            }
-        }
-        if (row < n_rows) {
-            constexpr int PER = 32 / LPR;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int idx = PER * sl + i;  // 0..15: training output idx; 16..31: evaluation output idx - 16
-                if (TRAIN && idx < 16 && idx < C) z_train[row * ldz + idx] = vals[i];
-                if (EVAL && idx >= 16 && idx - 16 < C) z_eval[row * ldz + idx - 16] = vals[i];
+            for (int r = 0; r < 4; ++r) {
+                const int64_t orow = tile * 16 + 4 * g + r;
+                if (orow < n_rows) {
+                    if (TRAIN) z_train[orow * ldz + i] = acc_tr[r];
+                    if (EVAL) z_eval[orow * ldz + i] = acc_ev[r];
+                }
             }
         }
     }
 }
 
 // dx = keep ? (dz · W) / (1 - p) : 0 — the backward of the training operand above in one pass (it was a GEMM writing
-// N x H floats and the ReLU/dropout backward reading and writing them again)
+// N x H floats and the ReLU/dropout backward reading and writing them again).  A workgroup takes 256 rows: their dz rows
+// (256·C floats, contiguous) and bit words go through LDS in one coalesced sweep, then every wave walks its 64 rows with
+// LPR lanes per row (4 columns each, their block of W in registers), reading dz as LDS broadcasts: the first version
+// loaded the 16 gradients of a row with 16 dependent global loads per two rows and ran at 2.1 TB/s.
 template <int LPR>
 __global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict__ dz, const float *__restrict__ w,
                                                          const unsigned long long *__restrict__ bits, float *__restrict__ dx,
                                                          int64_t n_rows, int C, float scale, float *__restrict__ colpart) {
     // colpart (nullable): [gridDim.x][H] column sums of the rows this workgroup wrote — the bias gradient of the layer that
     // produced x is the column sum of dx, and dx is in registers here (k_colsum_finish adds the workgroups' parts in order)
-    constexpr int H = 4 * LPR, RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
+    constexpr int H = 4 * LPR, RPW = 64 / LPR, TR = 256, WORDS = TR / RPW * 4;
+    __shared__ float tile[TR * 16];
+    __shared__ unsigned long long tbits[WORDS];
+    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR, wave = threadIdx.x >> 6;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     float wr[16][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wr[j][q] = j < C ? w[(int64_t)j * H + 4 * sl + q] : 0.f;
-    const int64_t n_waves = (n_rows + RPW - 1) / RPW;
-    for (int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); wv < n_waves; wv += (int64_t)gridDim.x * 4) {
-        const int64_t row = wv * RPW + sub;
-        if (row >= n_rows) continue;
-        const int64_t t = row * LPR + sl;
-        float g[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) g[j] = j < C ? dz[row * C + j] : 0.f;
-        float o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc = fmaf(g[j], wr[j][q], acc);
-            const bool keep = (bits[wv * 4 + q] >> lane) & 1ull;
-            o[q] = keep ? acc * scale : 0.f;
-            cs[q] += o[q];
+    for (int j = 0; j < 16; ++j) {
+        const float4 t = j < C ? *reinterpret_cast<const float4 *>(w + (int64_t)j * H + 4 * sl) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wr[j][0] = t.x; wr[j][1] = t.y; wr[j][2] = t.z; wr[j][3] = t.w;
+    }
+    const int64_t n_tiles = (n_rows + TR - 1) / TR;
+    const bool vec = (C & 3) == 0 && ((uintptr_t)dz & 15) == 0;
+    for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int64_t row0 = tl * TR;
+        const int nrow = (int)(n_rows - row0 < TR ? n_rows - row0 : TR);
+        const int nfl = nrow * C;
+        const float *src = dz + row0 * C;
+        if (vec) {
+            for (int k = threadIdx.x; k < nfl / 4; k += 256) reinterpret_cast<float4 *>(tile)[k] = reinterpret_cast<const float4 *>(src)[k];
+        } else {
+            for (int k = threadIdx.x; k < nfl; k += 256) tile[k] = src[k];
         }
-        *reinterpret_cast<float4 *>(dx + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        const int nwords = (nrow + RPW - 1) / RPW * 4;
+        for (int k = threadIdx.x; k < nwords; k += 256) tbits[k] = bits[row0 / RPW * 4 + k];
+        __syncthreads();
+#pragma unroll 4
+        for (int st = 0; st < 64 / RPW; ++st) {
+            const int r = wave * 64 + st * RPW + sub;
+            if (r >= nrow) continue;
+            float g[16];
+            if (C == 16) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    const float4 t = reinterpret_cast<const float4 *>(tile)[r * 4 + j4];
+                    g[4 * j4] = t.x; g[4 * j4 + 1] = t.y; g[4 * j4 + 2] = t.z; g[4 * j4 + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) g[j] = j < C ? tile[r * C + j] : 0.f;
+            }
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc = fmaf(g[j], wr[j][q], acc);
+                const bool keep = (tbits[(wave * (64 / RPW) + st) * 4 + q] >> lane) & 1ull;
+                o[q] = keep ? acc * scale : 0.f;
+                cs[q] += o[q];
+            }
+            *reinterpret_cast<float4 *>(dx + ((row0 + r) * LPR + sl) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
     }
     if (colpart) {  // uniform
         __shared__ float red[4][H];
@@ -541,22 +577,22 @@ __global__ void __launch_bounds__(256) k_colsum_finish(const float *__restrict__
     if (threadIdx.x == 0) out[c] = red[0];
 }
 
-template <int LPR>
+template <int HM>
 static void launch_act_linear_fwd(bool train, bool eval, const float *x, const float *w, float *h_train, float *z_train, float *z_eval,
                                   int64_t ldz, unsigned long long *bits, int64_t n_rows, int C, float scale, uint32_t threshold, uint64_t seed,
                                   uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
-    const int64_t n_waves = (n_rows + 64 / LPR - 1) / (64 / LPR);
+    const int64_t n_waves = (n_rows + 15) / 16;        // a wave per 16-row tile
     int64_t blocks = (n_waves + 3) / 4;
-    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;  // grid-stride: the weights are loaded into registers once per wave
+    if (blocks > 256 * 8) blocks = 256 * 8;            // grid-stride: the weights are loaded into registers once per wave
     if (blocks < 1) blocks = 1;
     if (train && eval)
-        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
+        hipLaunchKernelGGL((k_act_linear_fwd<HM, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
                            n_rows, C, scale, threshold, seed, offset, offset_dev);
     else if (train)
-        hipLaunchKernelGGL((k_act_linear_fwd<LPR, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
+        hipLaunchKernelGGL((k_act_linear_fwd<HM, true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
                            n_rows, C, scale, threshold, seed, offset, offset_dev);
     else
-        hipLaunchKernelGGL((k_act_linear_fwd<LPR, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
+        hipLaunchKernelGGL((k_act_linear_fwd<HM, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, h_train, z_train, z_eval, ldz, bits,
                            n_rows, C, scale, threshold, seed, offset, offset_dev);
 }
 
@@ -570,26 +606,26 @@ extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float 
     if (train && (!h_train || !bits || !(p >= 0.0 && p < 1.0))) DCR_FAIL(DCR_EINVAL, "act_linear: training output needs h_train, bits and 0 <= p < 1");
     if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16 || ldz < classes)
         DCR_FAIL(DCR_EINVAL, "act_linear: hidden width 64 or 128, at most 16 classes, ldz >= classes (other shapes take the separate kernels)");
-    if (((uintptr_t)x & 15) || (h_train && ((uintptr_t)h_train & 15))) DCR_FAIL(DCR_EINVAL, "act_linear: 16-byte aligned tensors expected");
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (h_train && ((uintptr_t)h_train & 15)))
+        DCR_FAIL(DCR_EINVAL, "act_linear: 16-byte aligned tensors expected");
     if (n_rows == 0) return DCR_OK;
     const double th = p * 4294967296.0;
     const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
     const float scale = (float)(1.0 / (1.0 - p));
     if (hidden == 128)
-        dcr::launch_act_linear_fwd<32>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,
+        dcr::launch_act_linear_fwd<8>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,
                                        seed, offset, offset_dev, (hipStream_t)hip_stream);
     else
-        dcr::launch_act_linear_fwd<16>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,
+        dcr::launch_act_linear_fwd<4>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,
                                        seed, offset, offset_dev, (hipStream_t)hip_stream);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
 
 static int64_t act_linear_bwd_blocks(int64_t n_rows, int hidden) {
-    const int lpr = hidden / 4;
-    const int64_t n_waves = (n_rows + 64 / lpr - 1) / (64 / lpr);
-    int64_t blocks = (n_waves + 3) / 4;
-    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+    (void)hidden;
+    int64_t blocks = (n_rows + 255) / 256;  // a workgroup per 256-row tile
+    if (blocks > 256 * 64) blocks = 256 * 64;
     return blocks < 1 ? 1 : blocks;
 }
 
@@ -618,7 +654,7 @@ static int act_linear_bwd(const float *dz, const float *w, const uint64_t *bits,
                           int64_t n_rows, int hidden, int classes, double p, void *hip_stream) {
     if (!dz || !w || !bits || !dx || n_rows < 0 || !(p >= 0.0 && p < 1.0)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd arguments");
     if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: unsupported shape");
-    if ((uintptr_t)dx & 15) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: 16-byte aligned tensors expected");
+    if (((uintptr_t)dx & 15) || ((uintptr_t)w & 15)) DCR_FAIL(DCR_EINVAL, "act_linear_bwd: 16-byte aligned tensors expected");
     const int64_t blocks = act_linear_bwd_blocks(n_rows, hidden);
     if (colsum && ws_floats < blocks * hidden) DCR_FAIL(DCR_EINVAL, "act_linear_bwd_colsum: workspace too small (dcr_act_linear_bwd_workspace)");
     if (n_rows == 0) {

@@ -20,7 +20,7 @@ data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=r < 0.1, val_mask=(
 torch.manual_seed(0)
 model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
 opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                        {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True)
+                        {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True, fused=os.environ.get('ADAM_FUSED', '1') == '1')
 if os.environ.get('EAGER') == '1':
     os.environ['DCR_EPOCH_GRAPH'] = '0'
 epoch = make_epoch(model, opt, data, lagged=True)
