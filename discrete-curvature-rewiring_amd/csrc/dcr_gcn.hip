@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict_
                     o[q] = keep ? v[m][q] * scale : 0.f;
                     part[q] |= keep ? (1u << (4 * m + g)) : 0u;
                 }
-                if (live) *reinterpret_cast<float4 *>(h_train + row * H + 16 * m + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+                if (live && h_train) *reinterpret_cast<float4 *>(h_train + row * H + 16 * m + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc_tr = __builtin_amdgcn_mfma_f32_16x16x4f32(o[q], wb[m][q], acc_tr, 0, 0, 0);
             }
@@ -562,6 +562,171 @@ __global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict_
     }
 }
 
+// The whole backward of the fused activation + contraction in ONE pass, on the matrix cores: dx = keep ? (dz·W)/(1-p) : 0,
+// its column sums (bias gradient of the previous layer) and dW = dzᵀ·h with h = keep ? x/(1-p) : 0 rebuilt from x and the
+// keep bits — the forward pass then need not store h (N x H floats written and read back), and the separate weight-gradient
+// reduction over all rows (0.26 ms at 1M x 128 x 16) goes away.  A workgroup stages 256 rows of dz and their bit words in LDS
+// (k_act_linear_bwd); a wave takes 16 rows at a time with v_mfma_f32_16x16x4_f32, lane (i = lane & 15, g = lane >> 4):
+//   dx tile:  A[row i][k = g] = dz[row i][class 4s + g] (LDS), B[k = g][n = i] = W[class 4s + g][col(i)] (registers),
+//             D register r = dx[row 4g + r][col(i)], with col(i) = 64b + 4i + q for MFMA (b, q): the four q of one b are four
+//             consecutive columns, so every lane stores float4s and a wave writes 256 contiguous bytes of each of 4 rows;
+//   dW tile:  A[class i][k = g] = dz[row 4s + g][class i] (LDS), B[k = g][n = i] = h[row 4s + g][col(i)] from a float4 load
+//             of x[row 4s + g][64b + 4i ..] (a wave reads 256 contiguous bytes of each of 4 rows), D register r =
+//             dW[class 4g + r][col(i)], accumulated in registers over all tiles of the wave.
+// Element (row, column 4·sl + q) keeps bit (row % RPW)·LPR + sl of word 4·(row / RPW) + q, as everywhere else.
+template <int HB>  // H = 64 * HB
+__global__ void __launch_bounds__(256) k_act_linear_bwd_fused(const float *__restrict__ dz, const float *__restrict__ w,
+                                                               const unsigned long long *__restrict__ bits, const float *__restrict__ x,
+                                                               float *__restrict__ dx, int64_t n_rows, int C, float scale,
+                                                               float *__restrict__ part) {
+    // part: [gridDim.x][H + 16 * H]: column sums of dx, then the workgroup's dW (class-major, 16 rows)
+    constexpr int H = 64 * HB, LPR = H / 4, RPW = 64 / LPR, TR = 256, WORDS = TR / RPW * 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float tile[TR * 16];
+    __shared__ unsigned long long tbits[WORDS];
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    float wb[4][HB][4];  // W[class 4s + g][64b + 4i + q]
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int b = 0; b < HB; ++b) {
+            const int cls = 4 * s4 + g;
+            const float4 t = cls < C ? *reinterpret_cast<const float4 *>(w + (int64_t)cls * H + 64 * b + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wb[s4][b][0] = t.x; wb[s4][b][1] = t.y; wb[s4][b][2] = t.z; wb[s4][b][3] = t.w;
+        }
+    f32x4 dw[HB][4];
+    float cs[HB][4];
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dw[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            cs[b][q] = 0.f;
+        }
+    const int64_t n_tiles = (n_rows + TR - 1) / TR;
+    const bool vec = (C & 3) == 0 && ((uintptr_t)dz & 15) == 0;
+    for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int64_t row0 = tl * TR;
+        const int nrow = (int)(n_rows - row0 < TR ? n_rows - row0 : TR);
+        const int nfl = nrow * C;
+        const float *src = dz + row0 * C;
+        if (vec) {
+            for (int k = threadIdx.x; k < TR * C / 4; k += 256)
+                reinterpret_cast<float4 *>(tile)[k] = k < nfl / 4 ? reinterpret_cast<const float4 *>(src)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int k = threadIdx.x; k < TR * C; k += 256) tile[k] = k < nfl ? src[k] : 0.f;
+        }
+        const int nwords = (nrow + RPW - 1) / RPW * 4;
+        for (int k = threadIdx.x; k < WORDS; k += 256) tbits[k] = k < nwords ? bits[row0 / RPW * 4 + k] : 0ull;
+        __syncthreads();
+        for (int st = 0; st < 4; ++st) {  // the wave's four 16-row tiles
+            const int r0 = wave * 64 + st * 16;
+            if (r0 >= nrow) break;  // uniform
+            // ---- x for the weight gradient: rows 4s + g, columns 64b + 4i .. + 3 ----
+            float xv[4][HB][4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int64_t row = row0 + r0 + 4 * s4 + g;
+#pragma unroll
+                for (int b = 0; b < HB; ++b) {
+                    const float4 t = row < n_rows ? *reinterpret_cast<const float4 *>(x + row * H + 64 * b + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xv[s4][b][0] = t.x; xv[s4][b][1] = t.y; xv[s4][b][2] = t.z; xv[s4][b][3] = t.w;
+                }
+            }
+            // ---- dx = mask · scale · (dz · W) ----
+            f32x4 acc[HB][4];
+#pragma unroll
+            for (int b = 0; b < HB; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int cls = 4 * s4 + g;
+                const float a = cls < C ? tile[(r0 + i) * C + cls] : 0.f;
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[s4][b][q], acc[b][q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = r0 + 4 * g + r;  // row of accumulator register r
+                const int wbase = rl / RPW * 4, sh = (rl % RPW) * LPR + i;
+                unsigned long long kw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kw[q] = tbits[wbase + q];
+#pragma unroll
+                for (int b = 0; b < HB; ++b) {
+                    float o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool keep = (kw[q] >> (sh + 16 * b)) & 1ull;
+                        o[q] = keep ? acc[b][q][r] * scale : 0.f;
+                        cs[b][q] += o[q];
+                    }
+                    if (rl < nrow) *reinterpret_cast<float4 *>(dx + (row0 + rl) * H + 64 * b + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            // ---- dW += dzᵀ · h ----
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int rl = r0 + 4 * s4 + g;
+                const float a = i < C ? tile[rl * C + i] : 0.f;
+                const int wbase = rl / RPW * 4, sh = (rl % RPW) * LPR + i;
+                unsigned long long kw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kw[q] = tbits[wbase + q];
+#pragma unroll
+                for (int b = 0; b < HB; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool keep = (kw[q] >> (sh + 16 * b)) & 1ull;
+                        const float hv = keep ? xv[s4][b][q] * scale : 0.f;
+                        dw[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, hv, dw[b][q], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the workgroup's parts: waves added in wave order through LDS (reusing the dz tile: 4 x (H + 16 H) floats > 16 KB
+    //      for H = 128, so two rounds) ----
+    float *out = part + (int64_t)blockIdx.x * (H + 16 * H);
+    // column sums: over g inside the wave, then over the waves
+#pragma unroll
+    for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cs[b][q] += __shfl_xor(cs[b][q], 16, 64);
+            cs[b][q] += __shfl_xor(cs[b][q], 32, 64);
+        }
+    __syncthreads();
+    if (g == 0)
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile[wave * H + 64 * b + 4 * i + q] = cs[b][q];
+    __syncthreads();
+    if (threadIdx.x < H) out[threadIdx.x] = (tile[threadIdx.x] + tile[H + threadIdx.x]) + (tile[2 * H + threadIdx.x] + tile[3 * H + threadIdx.x]);
+    __syncthreads();
+    // dW: register r of (b, q) is dW[class 4g + r][64b + 4i + q]; waves 0,1 then 2,3 through the 16 KB tile
+    for (int round = 0; round < 2; ++round) {
+        if ((wave >> 1) == round) {
+#pragma unroll
+            for (int b = 0; b < HB; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile[(wave & 1) * 16 * H + (4 * g + r) * H + 64 * b + 4 * i + q] = dw[b][q][r];
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 16 * H; k += 256) {
+            const float v = tile[k] + tile[16 * H + k];
+            out[H + k] = round == 0 ? v : out[H + k] + v;
+        }
+        __syncthreads();
+    }
+}
+
 // out[c] = sum over the parts of column c, in a fixed order (one workgroup per column)
 __global__ void __launch_bounds__(256) k_colsum_finish(const float *__restrict__ part, int64_t n_parts, int H, float *__restrict__ out) {
     __shared__ float red[256];
@@ -575,6 +740,25 @@ __global__ void __launch_bounds__(256) k_colsum_finish(const float *__restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) out[c] = red[0];
+}
+
+// out0[c] (c < split) and out1[c - split] = sum over the parts of column c of a [n_parts][stride] array, in a fixed order
+__global__ void __launch_bounds__(256) k_parts_finish(const float *__restrict__ part, int64_t n_parts, int stride, int split,
+                                                       float *__restrict__ out0, float *__restrict__ out1) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float a = 0.f;
+    for (int64_t k = threadIdx.x; k < n_parts; k += 256) a += part[k * stride + c];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (c < split) out0[c] = red[0];
+        else out1[c - split] = red[0];
+    }
 }
 
 template <int HM>
@@ -603,7 +787,7 @@ extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float 
                                           uint64_t offset, const uint64_t *offset_dev, void *hip_stream) {
     const bool train = z_train != nullptr, eval = z_eval != nullptr;
     if (!x || !w || n_rows < 0 || (!train && !eval)) DCR_FAIL(DCR_EINVAL, "bad act_linear arguments");
-    if (train && (!h_train || !bits || !(p >= 0.0 && p < 1.0))) DCR_FAIL(DCR_EINVAL, "act_linear: training output needs h_train, bits and 0 <= p < 1");
+    if (train && (!bits || !(p >= 0.0 && p < 1.0))) DCR_FAIL(DCR_EINVAL, "act_linear: training output needs bits and 0 <= p < 1");
     if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16 || ldz < classes)
         DCR_FAIL(DCR_EINVAL, "act_linear: hidden width 64 or 128, at most 16 classes, ldz >= classes (other shapes take the separate kernels)");
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (h_train && ((uintptr_t)h_train & 15)))
@@ -632,6 +816,46 @@ static int64_t act_linear_bwd_blocks(int64_t n_rows, int hidden) {
 extern "C" int dcr_act_linear_bwd_workspace(int64_t n_rows, int hidden, int64_t *floats) {
     if (!floats || n_rows < 0 || (hidden != 64 && hidden != 128)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd_workspace arguments");
     *floats = act_linear_bwd_blocks(n_rows, hidden) * hidden;
+    return DCR_OK;
+}
+
+static int64_t act_linear_bwd_fused_blocks(int64_t n_rows) {
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;  // grid-stride: a part of H + 16 H floats per workgroup
+    return blocks < 1 ? 1 : blocks;
+}
+
+extern "C" int dcr_act_linear_bwd_fused_workspace(int64_t n_rows, int hidden, int64_t *floats) {
+    if (!floats || n_rows < 0 || (hidden != 64 && hidden != 128)) DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd_fused_workspace arguments");
+    *floats = act_linear_bwd_fused_blocks(n_rows) * 17 * hidden;
+    return DCR_OK;
+}
+
+extern "C" int dcr_act_linear_bwd_fused_f32_dev(const float *dz, const float *w, const uint64_t *bits, const float *x, float *dx,
+                                                float *dw, float *colsum, float *ws, int64_t ws_floats, int64_t n_rows, int hidden,
+                                                int classes, double p, void *hip_stream) {
+    if (!dz || !w || !bits || !x || !dx || !dw || !colsum || !ws || n_rows < 0 || !(p >= 0.0 && p < 1.0))
+        DCR_FAIL(DCR_EINVAL, "bad act_linear_bwd_fused arguments");
+    if ((hidden != 64 && hidden != 128) || classes < 1 || classes > 16) DCR_FAIL(DCR_EINVAL, "act_linear_bwd_fused: unsupported shape");
+    if (((uintptr_t)dx & 15) || ((uintptr_t)w & 15) || ((uintptr_t)x & 15)) DCR_FAIL(DCR_EINVAL, "act_linear_bwd_fused: 16-byte aligned tensors expected");
+    const int64_t blocks = act_linear_bwd_fused_blocks(n_rows);
+    if (ws_floats < blocks * 17 * hidden) DCR_FAIL(DCR_EINVAL, "act_linear_bwd_fused: workspace too small (dcr_act_linear_bwd_fused_workspace)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (n_rows == 0) {
+        DCR_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * hidden, st));
+        DCR_HIP(hipMemsetAsync(dw, 0, sizeof(float) * hidden * classes, st));
+        return DCR_OK;
+    }
+    const float scale = (float)(1.0 / (1.0 - p));
+    if (hidden == 128)
+        hipLaunchKernelGGL((dcr::k_act_linear_bwd_fused<2>), dim3((unsigned)blocks), dim3(256), 0, st, dz, w, (const unsigned long long *)bits, x,
+                           dx, n_rows, classes, scale, ws);
+    else
+        hipLaunchKernelGGL((dcr::k_act_linear_bwd_fused<1>), dim3((unsigned)blocks), dim3(256), 0, st, dz, w, (const unsigned long long *)bits, x,
+                           dx, n_rows, classes, scale, ws);
+    // parts -> colsum[hidden] and dw[classes][hidden]: the first hidden * (1 + classes) columns of the [blocks][17 * hidden] parts
+    hipLaunchKernelGGL(dcr::k_parts_finish, dim3((unsigned)(hidden * (1 + classes))), dim3(256), 0, st, ws, blocks, 17 * hidden, hidden, colsum, dw);
+    DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
 

@@ -398,20 +398,20 @@ class _ActLinearFn(torch.autograd.Function):
             z_tr = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_train else None
             z_ev = torch.empty((n, classes), dtype=x.dtype, device=x.device) if want_eval else None
         ldz = 2 * classes if (want_train and want_eval) else classes
-        h = bits = ctr = None
+        bits = ctr = None
         if want_train:
             words = ctypes.c_int64()
             _lib.check(_lib.lib().dcr_relu_dropout_bits_words(x.numel(), ctypes.byref(words)))
             bits = torch.empty(max(words.value, 1), dtype=torch.int64, device=x.device)
-            h = torch.empty_like(x)
             ctr = _dropout_counter(x.device)
+        # (no training activation is stored: the backward kernel rebuilds it from x and the keep bits)
         _lib.check(_lib.lib().dcr_act_linear_fwd_f32_dev(
-            x.data_ptr(), w.data_ptr(), h.data_ptr() if want_train else None, z_tr.data_ptr() if want_train else None,
+            x.data_ptr(), w.data_ptr(), None, z_tr.data_ptr() if want_train else None,
             z_ev.data_ptr() if want_eval else None, ldz, bits.data_ptr() if want_train else None, n, hidden, classes, float(p),
             torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None, ctypes.c_void_p(stream)))
         if want_train:
             ctr.add_(1)
-            ctx.save_for_backward(h, w)
+            ctx.save_for_backward(x, w)
             ctx.bits, ctx.p = bits, float(p)
         if want_eval:
             ctx.mark_non_differentiable(z_ev)
@@ -420,25 +420,25 @@ class _ActLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_tr, g_ev):
         from dcr import _lib
-        h, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors
         g_tr = g_tr.contiguous()
-        gx = gw = None
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None, None
+        # one pass over x (dcr_act_linear_bwd_fused_f32_dev): dx, its column sums — the bias gradient of the layer that
+        # produced x, which _LinearFn.backward picks up instead of reading the N x H gradient once more — and dW
         stream = torch.cuda.current_stream(g_tr.device).cuda_stream
-        if ctx.needs_input_grad[0]:
-            # dx and, from the same registers, its column sums: the bias gradient of the layer that produced x, which
-            # _LinearFn.backward picks up instead of reading the N x H gradient once more
-            gx = torch.empty_like(h)
-            need = ctypes.c_int64()
-            _lib.check(_lib.lib().dcr_act_linear_bwd_workspace(h.shape[0], h.shape[1], ctypes.byref(need)))
-            ws = torch.empty(max(need.value, 1), dtype=torch.float32, device=h.device)
-            colsum = torch.empty(h.shape[1], dtype=torch.float32, device=h.device)
-            _lib.check(_lib.lib().dcr_act_linear_bwd_colsum_f32_dev(g_tr.data_ptr(), w.data_ptr(), ctx.bits.data_ptr(), gx.data_ptr(),
-                                                                    colsum.data_ptr(), ws.data_ptr(), need.value, h.shape[0], h.shape[1],
-                                                                    w.shape[0], ctx.p, ctypes.c_void_p(stream)))
-            gx._dcr_colsum = (gx.data_ptr(), gx._version, colsum)
-        if ctx.needs_input_grad[1]:
-            gw = atb_hip(g_tr, h) if h.shape[0] >= 64 * max(h.shape[1], g_tr.shape[1]) else g_tr.t() @ h
-        return gx, gw, None, None, None
+        n, hidden = x.shape
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(w)
+        colsum = torch.empty(hidden, dtype=torch.float32, device=x.device)
+        need = ctypes.c_int64()
+        _lib.check(_lib.lib().dcr_act_linear_bwd_fused_workspace(n, hidden, ctypes.byref(need)))
+        ws = torch.empty(max(need.value, 1), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().dcr_act_linear_bwd_fused_f32_dev(g_tr.data_ptr(), w.data_ptr(), ctx.bits.data_ptr(), x.data_ptr(),
+                                                               gx.data_ptr(), gw.data_ptr(), colsum.data_ptr(), ws.data_ptr(),
+                                                               need.value, n, hidden, w.shape[0], ctx.p, ctypes.c_void_p(stream)))
+        gx._dcr_colsum = (gx.data_ptr(), gx._version, colsum)
+        return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), None, None, None
 
 
 def act_then_linear(x, act_fn, dropout, lin, want_train=True, want_eval=False):

@@ -234,7 +234,7 @@ int dcr_relu_dropout_bwd_f32_dev(const float *grad_out_dev, float *grad_in_dev, 
  * models/gcn.py:36-42 between two layers (x = relu(x); x = dropout(x); next GCNConv's lin: x·W^T, W = [classes, hidden]) in
  * ONE pass over the hidden activation: z_train = dropout(relu(x))·W^T (with h_train = dropout(relu(x)) stored for the weight
  * gradient and the keep bits as above, same Philox stream as dcr_relu_dropout_fwd_f32_ctr_dev) and / or z_eval = relu(x)·W^T.
- * A null z_train (z_eval) skips that operand.  hidden 64 or 128, classes <= 16 (other shapes: the separate entry points).
+ * A null z_train (z_eval) skips that operand; a null h_train skips the stored training activation.  hidden 64 or 128, classes <= 16 (other shapes: the separate entry points).
  * Backward of the training operand: dx = keep ? (dz·W) / (1 - p) : 0. */
 int dcr_act_linear_fwd_f32_dev(const float *x_dev, const float *w_dev, float *h_train_dev, float *z_train_dev, float *z_eval_dev,
                                int64_t ldz, uint64_t *bits_dev, int64_t n_rows, int hidden, int classes, double p, uint64_t seed,
@@ -248,6 +248,14 @@ int dcr_act_linear_bwd_workspace(int64_t n_rows, int hidden, int64_t *floats);
 int dcr_act_linear_bwd_colsum_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, float *dx_dev,
                                       float *colsum_dev, float *ws_dev, int64_t ws_floats, int64_t n_rows, int hidden, int classes,
                                       double p, void *hip_stream);
+/* The whole backward of dcr_act_linear_fwd_f32_dev's training operand in one pass over x, on the matrix cores: dx as above,
+ * colsum_dev[hidden] = its column sums, dw_dev[classes x hidden] = dz^T · h with h = keep ? x / (1 - p) : 0 rebuilt from x and
+ * the keep bits (the forward call may then pass h_train_dev = NULL and store no activation).  Replaces the weight-gradient
+ * reduction of the next layer's Linear (models/gcn.py:36, dW = dz^T · h) as well.  Deterministic (fixed-order sums). */
+int dcr_act_linear_bwd_fused_workspace(int64_t n_rows, int hidden, int64_t *floats);
+int dcr_act_linear_bwd_fused_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, const float *x_dev,
+                                     float *dx_dev, float *dw_dev, float *colsum_dev, float *ws_dev, int64_t ws_floats,
+                                     int64_t n_rows, int hidden, int classes, double p, void *hip_stream);
 
 #ifdef __cplusplus
 }
