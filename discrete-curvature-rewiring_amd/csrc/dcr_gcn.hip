@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) k_act_linear_bwd(const float *__restrict_
 //             dW[class 4g + r][col(i)], accumulated in registers over all tiles of the wave.
 // Element (row, column 4·sl + q) keeps bit (row % RPW)·LPR + sl of word 4·(row / RPW) + q, as everywhere else.
 template <int HB>  // H = 64 * HB
-__global__ void __launch_bounds__(256) k_act_linear_bwd_fused(const float *__restrict__ dz, const float *__restrict__ w,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_act_linear_bwd_fused(const float *__restrict__ dz, const float *__restrict__ w,
                                                                const unsigned long long *__restrict__ bits, const float *__restrict__ x,
                                                                float *__restrict__ dx, int64_t n_rows, int C, float scale,
                                                                float *__restrict__ part) {
@@ -622,68 +622,56 @@ __global__ void __launch_bounds__(256) k_act_linear_bwd_fused(const float *__res
         for (int st = 0; st < 4; ++st) {  // the wave's four 16-row tiles
             const int r0 = wave * 64 + st * 16;
             if (r0 >= nrow) break;  // uniform
-            // ---- x for the weight gradient: rows 4s + g, columns 64b + 4i .. + 3 ----
-            float xv[4][HB][4];
+            // one 64-column block at a time: its x rows are requested first, the dx block is formed and stored while they
+            // travel, then the block's part of dW (register budget: two waves per SIMD need the kernel under 256 per lane,
+            // 72 of them persistent: W, dW, column sums)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int64_t row = row0 + r0 + 4 * s4 + g;
+            for (int b = 0; b < HB; ++b) {
+                float xv[4][4];  // x[row 4s + g][64b + 4i + q]
 #pragma unroll
-                for (int b = 0; b < HB; ++b) {
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int64_t row = row0 + r0 + 4 * s4 + g;
                     const float4 t = row < n_rows ? *reinterpret_cast<const float4 *>(x + row * H + 64 * b + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    xv[s4][b][0] = t.x; xv[s4][b][1] = t.y; xv[s4][b][2] = t.z; xv[s4][b][3] = t.w;
+                    xv[s4][0] = t.x; xv[s4][1] = t.y; xv[s4][2] = t.z; xv[s4][3] = t.w;
                 }
-            }
-            // ---- dx = mask · scale · (dz · W) ----
-            f32x4 acc[HB][4];
+                // ---- dx = mask · scale · (dz · W) ----
+                f32x4 acc[4];
 #pragma unroll
-            for (int b = 0; b < HB; ++b)
+                for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int cls = 4 * s4 + g;
+                    const float a = cls < C ? tile[(r0 + i) * C + cls] : 0.f;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int cls = 4 * s4 + g;
-                const float a = cls < C ? tile[(r0 + i) * C + cls] : 0.f;
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[s4][b][q], acc[q], 0, 0, 0);
+                }
 #pragma unroll
-                for (int b = 0; b < HB; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[s4][b][q], acc[b][q], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = r0 + 4 * g + r;  // row of accumulator register r
-                const int wbase = rl / RPW * 4, sh = (rl % RPW) * LPR + i;
-                unsigned long long kw[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) kw[q] = tbits[wbase + q];
-#pragma unroll
-                for (int b = 0; b < HB; ++b) {
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = r0 + 4 * g + r;  // row of accumulator register r
+                    const int wbase = rl / RPW * 4, sh = (rl % RPW) * LPR + i + 16 * b;
                     float o[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const bool keep = (kw[q] >> (sh + 16 * b)) & 1ull;
-                        o[q] = keep ? acc[b][q][r] * scale : 0.f;
+                        const bool keep = (tbits[wbase + q] >> sh) & 1ull;
+                        o[q] = keep ? acc[q][r] * scale : 0.f;
                         cs[b][q] += o[q];
                     }
                     if (rl < nrow) *reinterpret_cast<float4 *>(dx + (row0 + rl) * H + 64 * b + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
                 }
-            }
-            // ---- dW += dzᵀ · h ----
+                // ---- dW += dzᵀ · h ----
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int rl = r0 + 4 * s4 + g;
-                const float a = i < C ? tile[rl * C + i] : 0.f;
-                const int wbase = rl / RPW * 4, sh = (rl % RPW) * LPR + i;
-                unsigned long long kw[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) kw[q] = tbits[wbase + q];
-#pragma unroll
-                for (int b = 0; b < HB; ++b)
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int rl = r0 + 4 * s4 + g;
+                    const float a = i < C ? tile[rl * C + i] : 0.f;
+                    const int wbase = rl / RPW * 4, sh = (rl % RPW) * LPR + i + 16 * b;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const bool keep = (kw[q] >> (sh + 16 * b)) & 1ull;
-                        const float hv = keep ? xv[s4][b][q] * scale : 0.f;
+                        const bool keep = (tbits[wbase + q] >> sh) & 1ull;
+                        const float hv = keep ? xv[s4][q] * scale : 0.f;
                         dw[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, hv, dw[b][q], 0, 0, 0);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
