@@ -85,6 +85,10 @@ __global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *r
                                                  int32_t v, DevResult *res) {
     int lane = threadIdx.x;
     if (u == -2) {  // the pair picked on the device (dcr_sdrf_tail_at)
+        if (res->draw_status != 0) {  // the device-side draw did not decide: nothing is edited, the host takes over
+            if (lane == 0) res->add_status = 3;
+            return;
+        }
         u = res->cand_i;
         v = res->cand_j;
     }
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(64) k_remove_edge(int2 *rowinfo, int32_t *col,
 // tail of an SDRF iteration: remove the arg-max edge iff its (stale) curvature exceeds the bound
 __global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *col, double *curv, DevResult *res,
                                                         double bound) {
-    if (res->add_status == 1) return;  // add overflowed: host re-lays out and replays the tail
+    if (res->add_status == 1 || res->add_status == 3) return;  // add overflowed (host re-lays out and replays the tail) / no draw
     int lane = threadIdx.x;
     int32_t u = res->ext_u, v = res->ext_v;
     bool doit = (res->ext_slot >= 0) && (res->ext_val > bound);
@@ -164,6 +168,7 @@ __device__ inline void dev_mark_dirty(const int2 *rowinfo, const int32_t *col, u
 __global__ void __launch_bounds__(256) k_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u,
                                                      int32_t v, int edit, const DevResult *res) {
     if (u == -2) {
+        if (res->draw_status != 0) return;
         u = res->cand_i;
         v = res->cand_j;
     }
@@ -173,7 +178,7 @@ __global__ void __launch_bounds__(256) k_mark_dirty(const int2 *rowinfo, const i
 // the edge the tail is about to remove (it is only known on the device)
 __global__ void __launch_bounds__(256) k_mark_dirty_ext(const int2 *rowinfo, const int32_t *col, uint8_t *dirty,
                                                          const DevResult *res, double bound, int edit) {
-    if (res->add_status == 1) return;
+    if (res->add_status == 1 || res->add_status == 3) return;
     if (res->ext_slot >= 0 && res->ext_val > bound)
         dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit, threadIdx.x, blockDim.x);
 }
@@ -398,6 +403,7 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_TRY(alloc_layout(g, tot));
     DCR_TRY(dev_alloc(&g->dres, 1));
     DCR_TRY(dev_alloc(&g->imp_stats, 1));
+    DCR_TRY(dev_alloc(&g->draw_bsum, 256));
     DCR_TRY(dev_alloc(&g->dirty, n + 4));  // OR-ed through 32-bit words
     DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(n > 0 ? n : 1), g->stream));
     DCR_HIP(hipHostMalloc((void **)&g->hres, sizeof(DevResult), hipHostMallocDefault));
@@ -424,7 +430,7 @@ int dcr_graph_destroy(dcr_graph *g) {
     void *dev_ptrs[] = {g->rowinfo, g->rowcap, g->col, g->slot_row, g->curv, g->red_scratch, g->scan_a, g->scan_b,
                         g->imp_table, g->imp_posx, g->imp_posy, g->imp_c1, g->imp_c2, g->imp_b, g->imp_c,
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
-                        g->imp_stats, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
+                        g->imp_stats, g->draw_bsum, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
                         g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
                         g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
                         g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_units[3], g->h2_units[4], g->h2_retry, g->h2_task, g->h2_cand, g->h2_part, g->h2_bloom,

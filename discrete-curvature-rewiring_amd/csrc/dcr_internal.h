@@ -48,7 +48,7 @@ struct DevResult {
     int32_t ext_slot;     // argext slot (-1: none)
     int32_t ext_u, ext_v;
     int32_t ext_du, ext_dv;  // their degrees (saves dcr_improvements a round trip)
-    int32_t add_status;   // 0 ok, 1 row overflow (nothing changed), 2 already present
+    int32_t add_status;   // 0 ok, 1 row overflow (nothing changed), 2 already present, 3 no edge drawn on the device (nothing changed)
     int32_t removed_u, removed_v;
     int32_t overflow_row;
     int32_t max_keys;     // largest du+dv+2 seen by classify
@@ -64,6 +64,11 @@ struct DevResult {
     int64_t n_cand;
     int64_t imp_argmax;
     int32_t cand_i, cand_j;
+    // device-side draw (dcr_sdrf_iteration_device_draw): the index np.random.choice would return, and whether the margins
+    // that make it certain held (0 ok; 1 undecided / not finite: the host draws; 2 no candidates)
+    int64_t draw_idx;
+    double draw_total, draw_gap;
+    int32_t draw_status, draw_pad;
     int32_t misc[8];  // scratch: has_edge/remove status, and the kernels' invariant guard record
     // two-hop pass (dcr_bfc_h2.hip): units per (class, weight bucket), placement cursors, units per class
     int32_t h2_bucket[24];
@@ -199,6 +204,7 @@ struct dcr_graph {
     int64_t imp_out_h_cap = 0, imp_cand_h_cap = 0;
     int64_t imp_n = 0;
     dcr::ImpStats *imp_stats = nullptr;
+    double *draw_bsum = nullptr;  // device-side draw: partial sums of exp(tau * improvement)
 
     dcr::DevResult *dres = nullptr;  // device
     dcr::DevResult *hres = nullptr;  // pinned host

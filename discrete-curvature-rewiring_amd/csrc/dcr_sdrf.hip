@@ -10,6 +10,7 @@
 //   * i == x, j in DY: deg(x)+1, T+1, j leaves DY: c1[k] drops by [k ~ j]; needs one scan of row j.
 //   * j == y, i in DX: mirrored.
 //   * every other admissible pair leaves all ingredients unchanged: improvement = +0.0.
+#include <cstdlib>
 #include "dcr_internal.h"
 #include <chrono>
 #include <cstdio>
@@ -697,43 +698,134 @@ __global__ void k_pick_candidate(const int32_t *ci, const int32_t *cj, int64_t i
     const int32_t a = ci[index], b = cj[index];
     res->cand_i = a < b ? a : b;
     res->cand_j = a < b ? b : a;
+    res->draw_status = 0;
+}
+
+// ---- the draw of sdrf_no_cuda.py:49-50 on the device -------------------------------------------------------------------
+// np.random.choice(n, p = softmax(improvements, tau)) is: cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right') with
+// ONE uniform u from the global stream (the host draws it: it does not depend on anything computed here).  The index is the
+// first i with cdf_i / t > u, i.e. with P_i > u · P_n for the exact prefix sums P of e_i = exp(tau · improvement_i): numpy's
+// floating-point chain (its exp, the pairwise sum S, e / S, the sequential cumsum, the division by t) and the sums formed
+// here each stay within (n + 64) · 2^-53 · P_n of those exact values, so when u · P_n is further than a margin of
+// (n + 1024) · 2^-51 · P_n from both P_{i-1} and P_i the comparison numpy makes at i - 1 and at i has the outcome found here
+// and i IS the index numpy returns.  When it is closer (probability ~ 1e-10 per draw), or anything is not finite, or there is
+// no candidate, nothing is decided here: draw_status says so, the tail kernels leave the graph alone, and the host runs the
+// exact path (numpy's own exp and sums) for this iteration.
+constexpr int DRAW_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__ imp, const DevResult *res, double tau,
+                                                       double *__restrict__ bsum) {
+    __shared__ double red[256];
+    const int64_t n = res->n_cand;
+    const int64_t L = (n + DRAW_BLOCKS - 1) / DRAW_BLOCKS, l = (L + 255) / 256;
+    const int64_t b0 = (int64_t)blockIdx.x * L, t0 = b0 + (int64_t)threadIdx.x * l;
+    const int64_t bend = b0 + L < n ? b0 + L : n;
+    const int64_t t1 = t0 + l < bend ? t0 + l : bend;
+    double s = 0.0;
+    for (int64_t k = t0; k < t1; ++k) s += exp(imp[k] * tau);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_draw_pick(const double *__restrict__ imp, const int32_t *__restrict__ ci,
+                                                    const int32_t *__restrict__ cj, DevResult *res, double tau, double u,
+                                                    const double *__restrict__ bsum, double margin_scale) {
+    __shared__ double pre[256];
+    __shared__ int found;
+    const int t = threadIdx.x;
+    const int64_t n = res->n_cand;
+    if (n <= 0) {
+        if (t == 0) {
+            res->draw_status = 2;
+            res->draw_idx = -1;
+        }
+        return;
+    }
+    // inclusive prefix of the block sums (256 values: one thread adds them in order)
+    pre[t] = bsum[t];
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0;
+        for (int k = 0; k < DRAW_BLOCKS; ++k) {
+            a += pre[k];
+            pre[k] = a;
+        }
+        found = DRAW_BLOCKS;
+    }
+    __syncthreads();
+    const double total = pre[DRAW_BLOCKS - 1];
+    const double T = u * total;
+    // (false for NaN too; far from the subnormal range, where the relative error bounds behind the margin do not hold)
+    const bool fine = total > 1e-250 && total < 1e300;
+    if (fine && pre[t] > T) atomicMin(&found, t);
+    __syncthreads();
+    const int bs = found;
+    if (!fine || bs >= DRAW_BLOCKS) {
+        if (t == 0) {
+            res->draw_status = 1;
+            res->draw_idx = -1;
+            res->draw_total = total;
+        }
+        return;
+    }
+    const double base = bs == 0 ? 0.0 : pre[bs - 1];
+    __syncthreads();
+    // inside block bs: the threads' segment sums, then the segment that crosses T is walked element by element
+    const int64_t L = (n + DRAW_BLOCKS - 1) / DRAW_BLOCKS, l = (L + 255) / 256;
+    const int64_t b0 = (int64_t)bs * L, t0 = b0 + (int64_t)t * l;
+    const int64_t bend = b0 + L < n ? b0 + L : n;
+    const int64_t t1 = t0 + l < bend ? t0 + l : bend;
+    double s = 0.0;
+    for (int64_t k = t0; k < t1; ++k) s += exp(imp[k] * tau);
+    pre[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        const double margin = (double)(n + 1024) * 0x1p-51 * total * margin_scale;
+        double run = base;
+        int64_t idx = -1;
+        double below = 0.0, above = 0.0;
+        for (int k = 0; k < 256 && idx < 0; ++k) {
+            if (run + pre[k] > T) {
+                const int64_t s0 = b0 + (int64_t)k * l, s1 = s0 + l < bend ? s0 + l : bend;
+                for (int64_t q = s0; q < s1; ++q) {
+                    const double prev = run;
+                    run += exp(imp[q] * tau);
+                    if (run > T) {
+                        idx = q;
+                        below = T - prev;
+                        above = run - T;
+                        break;
+                    }
+                }
+                break;  // (not found inside a segment whose sum crosses: rounding; left undecided)
+            }
+            run += pre[k];
+        }
+        const bool ok = idx >= 0 && above > margin && (idx == 0 || below > margin);
+        res->draw_total = total;
+        res->draw_gap = idx >= 0 ? (above < below || idx == 0 ? above : below) / total : 0.0;
+        res->draw_idx = ok ? idx : -1;
+        res->draw_status = ok ? 0 : 1;
+        if (ok) {
+            const int32_t a = ci[idx], b = cj[idx];
+            res->cand_i = a < b ? a : b;
+            res->cand_j = a < b ? b : a;
+        }
+    }
 }
 
 }  // namespace dcr
 
 using namespace dcr;
 
-extern "C" {
-
-int dcr_argext(dcr_graph *g, int want_max, int32_t excl_u, int32_t excl_v, int32_t *out_u, int32_t *out_v,
-               double *out_val) {
-    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
-    if (!g->curv_valid) DCR_FAIL(DCR_ESTATE, "dcr_argext needs a curvature pass first");
-    DCR_HIP(hipSetDevice(g->device));
-    if (excl_u > excl_v) {
-        int32_t t = excl_u;
-        excl_u = excl_v;
-        excl_v = t;
-    }
-    DCR_TRY(launch_argext(g, want_max, excl_u, excl_v));
-    DCR_TRY(sync_result(g));
-    if (g->hres->ext_slot < 0) DCR_FAIL(DCR_ENOTFOUND, "graph has no (eligible) edges");
-    if (out_u) *out_u = g->hres->ext_u;
-    if (out_v) *out_v = g->hres->ext_v;
-    if (out_val) *out_val = g->hres->ext_val;
-    return DCR_OK;
-}
-
-int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want_candidates, int64_t *n_out,
-                     const double **out_improvement, const int32_t **out_ci, const int32_t **out_cj) {
-    if (!g || !n_out) DCR_FAIL(DCR_EINVAL, "null argument");
-    if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
-    if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
-    DCR_HIP(hipSetDevice(g->device));
-#ifdef DCR_IMP_TIMING
-    static double t_enq = 0, t_sync = 0; static long t_n = 0;
-    const auto T0 = std::chrono::steady_clock::now();
-#endif
+// the improvement pipeline of one edge (x, y), enqueued on the library stream: candidates and their improvements end up in
+// g->imp_out / imp_ci / imp_cj, their number in the result block (n_cand); *upper_out = the bound (dx + 1)(dy + 1) on it
+static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_t *upper_out) {
     int dx, dy;
     if (g->am_valid && g->am_x == x && g->am_y == y) {  // the arg-min step already brought the degrees over
         dx = g->am_dx;
@@ -828,6 +920,43 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     hipLaunchKernelGGL(k_imp_emit, dim3(rows), dim3(256), 0, g->stream, vw, B, x, y, words, curv_type, g->imp_out,
                        g->imp_ci, g->imp_cj);
     DCR_HIP(hipGetLastError());
+    *upper_out = upper;
+    return DCR_OK;
+}
+
+extern "C" {
+
+int dcr_argext(dcr_graph *g, int want_max, int32_t excl_u, int32_t excl_v, int32_t *out_u, int32_t *out_v,
+               double *out_val) {
+    if (!g) DCR_FAIL(DCR_EINVAL, "null graph");
+    if (!g->curv_valid) DCR_FAIL(DCR_ESTATE, "dcr_argext needs a curvature pass first");
+    DCR_HIP(hipSetDevice(g->device));
+    if (excl_u > excl_v) {
+        int32_t t = excl_u;
+        excl_u = excl_v;
+        excl_v = t;
+    }
+    DCR_TRY(launch_argext(g, want_max, excl_u, excl_v));
+    DCR_TRY(sync_result(g));
+    if (g->hres->ext_slot < 0) DCR_FAIL(DCR_ENOTFOUND, "graph has no (eligible) edges");
+    if (out_u) *out_u = g->hres->ext_u;
+    if (out_v) *out_v = g->hres->ext_v;
+    if (out_val) *out_val = g->hres->ext_val;
+    return DCR_OK;
+}
+
+int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want_candidates, int64_t *n_out,
+                     const double **out_improvement, const int32_t **out_ci, const int32_t **out_cj) {
+    if (!g || !n_out) DCR_FAIL(DCR_EINVAL, "null argument");
+    if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
+    if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
+    DCR_HIP(hipSetDevice(g->device));
+#ifdef DCR_IMP_TIMING
+    static double t_enq = 0, t_sync = 0; static long t_n = 0;
+    const auto T0 = std::chrono::steady_clock::now();
+#endif
+    int64_t upper = 0;
+    DCR_TRY(imp_enqueue(g, x, y, curv_type, &upper));
     // one host sync: the result block and the values go out together; the candidate count is not known yet, so the
     // copy is sized by its upper bound (dx+1)(dy+1), which the real count nearly reaches on a sparse graph
     if (upper > 0 && out_improvement) {
@@ -1037,6 +1166,67 @@ int dcr_sdrf_tail_at_pass_argmin(dcr_graph *g, int64_t cand_index, int do_remove
         }
         if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
         DCR_TRY(relayout(g));  // nothing was edited (the removal is skipped when the add overflows): lay out, replay
+    }
+    tail_finish(g, tc, out_removed, nullptr, false);
+    if (out_added) {
+        out_added[0] = g->hres->cand_i;
+        out_added[1] = g->hres->cand_j;
+    }
+    return DCR_OK;
+}
+
+// One whole iteration of the loop body for finite tau with ONE host synchronisation: the improvement pipeline of the edge
+// (x, y) found by the previous call, the draw on the device (k_draw_*: the host supplies the uniform it has taken from numpy's
+// stream), the tail (add, conditional removal) and the NEXT iteration's curvature pass and first minimum
+// (sdrf_no_cuda.py:29-66, then :24,:27).  *out_status: 0 done; 1 the draw was left undecided, 2 there was no candidate — in
+// both cases NOTHING was edited and the caller runs the iteration through dcr_improvements / dcr_sdrf_tail* instead.
+int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_type, double tau, double uniform, int do_remove,
+                                   double removal_bound, int incremental, int *out_status, int64_t *out_n_cand,
+                                   int32_t out_added[2], int32_t out_removed[2], int32_t *out_u, int32_t *out_v, double *out_val) {
+    if (!g || !out_status || !out_n_cand) DCR_FAIL(DCR_EINVAL, "null argument");
+    if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
+    if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
+    if (!(tau == tau) || tau > 1.7e308 || tau < -1.7e308 || !(uniform >= 0.0 && uniform < 1.0))
+        DCR_FAIL(DCR_EINVAL, "device draw: finite tau and a uniform in [0, 1) expected");
+    if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
+    DCR_HIP(hipSetDevice(g->device));
+    int64_t upper = 0;
+    DCR_TRY(imp_enqueue(g, x, y, curv_type, &upper));
+    // the stale arg-max of the removal step does not depend on the edge about to be drawn (see dcr_improvements)
+    if (g->curv_valid && do_remove) {
+        DCR_TRY(launch_argext(g, 1, -1, -1));
+        g->amax_valid = true;
+    }
+    hipLaunchKernelGGL(k_draw_partial, dim3(DRAW_BLOCKS), dim3(256), 0, g->stream, g->imp_out, g->dres, tau, g->draw_bsum);
+    // (DCR_DRAW_MARGIN_SCALE widens the margin: the tests use it to send draws down the undecided path)
+    const double margin_scale = getenv("DCR_DRAW_MARGIN_SCALE") ? atof(getenv("DCR_DRAW_MARGIN_SCALE")) : 1.0;
+    hipLaunchKernelGGL(k_draw_pick, dim3(1), dim3(256), 0, g->stream, g->imp_out, g->imp_ci, g->imp_cj, g->dres, tau, uniform,
+                       g->draw_bsum, margin_scale >= 1.0 ? margin_scale : 1.0);
+    TailCall tc;
+    DCR_TRY(tail_prepare(g, -2, -2, do_remove, removal_bound, &tc));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        DCR_TRY(tail_enqueue(g, tc, attempt == 0));
+        g->max_deg_bound++;  // (see dcr_sdrf_tail_at_pass_argmin)
+        const int rc = dcr_curvature_pass_argmin(g, curv_type, incremental, out_u, out_v, out_val);  // synchronises
+        g->max_deg_bound--;
+        if (g->hres->add_status != 1) {
+            if (rc != DCR_OK) {
+                if (rc != DCR_EHIP && g->hres->add_status != 3) tail_finish(g, tc, out_removed, nullptr, false);
+                return rc;
+            }
+            break;
+        }
+        if (attempt == 1) DCR_FAIL(DCR_ECAPACITY, "row still full after relayout");
+        DCR_TRY(relayout(g));
+    }
+    g->imp_n = g->hres->n_cand;
+    *out_n_cand = g->hres->n_cand;
+    *out_status = g->hres->draw_status;
+    if (g->hres->draw_status != 0 || g->hres->add_status == 3) {  // nothing was edited; the pass ran on the same graph
+        if (g->hres->draw_status == 0) DCR_FAIL(DCR_ESTATE, "device draw: edit skipped without a draw status");
+        if (out_removed) out_removed[0] = out_removed[1] = -1;
+        if (out_added) out_added[0] = out_added[1] = -1;
+        return DCR_OK;
     }
     tail_finish(g, tc, out_removed, nullptr, false);
     if (out_added) {

@@ -48,6 +48,8 @@ SIGNATURES = {
     'dcr_candidate_at': (ctypes.c_int, [_vp, _i64, _i32p, _i32p]),
     'dcr_sdrf_tail': (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_int, _f64, _i32p, _f64p]),
     'dcr_sdrf_tail_at': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _f64, _i32p, _i32p, _f64p]),
+    'dcr_sdrf_iteration_device_draw': (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_int, _f64, _f64, ctypes.c_int, _f64, ctypes.c_int,
+                                                     ctypes.POINTER(ctypes.c_int), _i64p, _i32p, _i32p, _i32p, _i32p, _f64p]),
     'dcr_sdrf_tail_at_pass_argmin': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _f64, ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p, _i32p, _f64p]),
     'dcr_profile_reset': (ctypes.c_int, [_vp]),
     'dcr_profile_read': (ctypes.c_int, [_vp, _f64p, _i64p]),

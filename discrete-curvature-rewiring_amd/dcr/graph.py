@@ -239,6 +239,21 @@ class DcrGraph:
         rem = None if removed[0] < 0 else (removed[0], removed[1])
         return (added[0], added[1]), rem, (u.value, v.value, val.value)
 
+    def sdrf_iteration_device_draw(self, x, y, curv_type, tau, uniform, do_remove, removal_bound, incremental=False):
+        """One loop iteration for the edge (x, y) with the draw on the device and one host synchronisation
+        (``dcr_sdrf_iteration_device_draw``); returns (status, candidates, added pair, removed pair or None, (u, v, value) of the
+        next first minimum).  status != 0: nothing was edited (1: the draw was left undecided, 2: no candidates)."""
+        status, n_cand = ctypes.c_int(), ctypes.c_int64()
+        added = (ctypes.c_int32 * 2)(-1, -1)
+        removed = (ctypes.c_int32 * 2)(-1, -1)
+        u, v, val = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        check(lib().dcr_sdrf_iteration_device_draw(self._h, int(x), int(y), curv_code(curv_type), float(tau), float(uniform),
+                                                   int(bool(do_remove)), float(removal_bound), int(bool(incremental)),
+                                                   ctypes.byref(status), ctypes.byref(n_cand), added, removed,
+                                                   ctypes.byref(u), ctypes.byref(v), ctypes.byref(val)))
+        rem = None if removed[0] < 0 else (removed[0], removed[1])
+        return status.value, n_cand.value, (added[0], added[1]), rem, (u.value, v.value, val.value)
+
     # ---- measurement hooks ------------------------------------------------------------
     def profile_reset(self):
         check(lib().dcr_profile_reset(self._h))

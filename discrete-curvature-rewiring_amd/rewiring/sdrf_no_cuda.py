@@ -127,6 +127,9 @@ class SdrfRun:
         self.tau = tau
         self.trace = trace
         self.G = DcrGraph.from_data(data, device=device)
+        # DCR_DEVICE_DRAW=0: always draw on the host (numpy's exp / sum / cumsum on the downloaded improvements)
+        self.device_draw = os.environ.get('DCR_DEVICE_DRAW', '1') != '0'
+        self.device_draws = self.host_draws = 0
         self._next_argmin = None  # (x, y) of the pass already run for the coming iteration (see step)
         self.last = (None, None, None)  # (x, y, candidates) of the last iteration (bench.py: bytes of the improvement step)
 
@@ -147,6 +150,23 @@ class SdrfRun:
             except KeyError:
                 raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
         rec = {'argmin': [x, y]} if want_trace else None
+
+        if self.device_draw and more and not want_trace and np.isfinite(tau):
+            # The whole iteration with one host synchronisation: the uniform np.random.choice would take is taken here and
+            # the draw itself runs on the device (dcr_sdrf_iteration_device_draw), accepted only when it is certain to be
+            # numpy's index.  Otherwise nothing was edited: the uniform goes back into the stream and the iteration runs
+            # the long way below (numpy's own exp, sum and cumsum on the host).
+            state = np.random.get_state()
+            uniform = np.random.random_sample()
+            status, n_cand, _, _, nxt = G.sdrf_iteration_device_draw(x, y, curv_type, tau, uniform, self.remove_edges,
+                                                                    self.removal_bound, incremental=self.incremental)
+            if status == 0:
+                self._next_argmin = nxt[:2]
+                self.last = (x, y, int(n_cand))
+                self.device_draws += 1
+                return True
+            np.random.set_state(state)
+            self.host_draws += 1
 
         k = l = idx = None
         if tau == float('inf') and not want_trace:

@@ -815,3 +815,43 @@ def test_fused_tail_replay_when_the_add_crosses_a_degree_class(dcr, oracle, monk
     ou, ov, oc = C.curv_all('bfc', nthreads=4)
     ru, rv, rc = G.curvature_read()
     assert np.array_equal(ru, ou) and np.array_equal(rv, ov) and np.array_equal(rc, oc)
+
+
+@pytest.mark.parametrize('incremental', [False, True])
+def test_device_side_draw_is_numpys_draw(dcr, oracle, monkeypatch, incremental):
+    """The one-synchronisation iteration (dcr_sdrf_iteration_device_draw: np.random.choice's index found on the device from the
+    uniform the host took from numpy's stream, sdrf_no_cuda.py:49-50) against the oracle's loop, which calls numpy itself:
+    the same edge list after 120 iterations at the bench's temperature and at a flat one — with every draw on the device,
+    with every draw sent down the undecided path (margin widened: nothing edited, uniform put back, host draw), and with the
+    device draw switched off; the three also leave numpy's stream in the same state."""
+    from dcr import synthetic
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import SdrfRun
+    import torch
+    ei, n = synthetic.powerlaw_graph(400, 4, seed=21)
+    loops = 120
+    for tau in (163.0, 0.7):
+        np.random.seed(11)
+        want = oracle.sdrf(ei, n, 'bfc', loops, True, 0.8, tau, nthreads=4)
+        want_next = np.random.random_sample()
+        for mode in ('device', 'undecided', 'host'):
+            monkeypatch.setenv('DCR_DEVICE_DRAW', '0' if mode == 'host' else '1')
+            if mode == 'undecided':
+                monkeypatch.setenv('DCR_DRAW_MARGIN_SCALE', '1e30')
+            else:
+                monkeypatch.delenv('DCR_DRAW_MARGIN_SCALE', raising=False)
+            np.random.seed(11)
+            run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.8, tau, incremental=incremental)
+            done = 0
+            for i in range(loops):
+                if not run.step(more=i + 1 < loops):
+                    break
+                done += 1
+            assert np.array_equal(run.result().edge_index.numpy(), want), (tau, mode)
+            assert np.random.random_sample() == want_next, (tau, mode)
+            if mode == 'device':
+                assert run.device_draws >= done - 1 and run.host_draws == 0
+            elif mode == 'undecided':
+                assert run.device_draws == 0 and run.host_draws >= done - 1
+            else:
+                assert run.device_draws == run.host_draws == 0
