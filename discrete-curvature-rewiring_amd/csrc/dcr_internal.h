@@ -68,7 +68,8 @@ struct DevResult {
     // that make it certain held (0 ok; 1 undecided / not finite: the host draws; 2 no candidates)
     int64_t draw_idx;
     double draw_total, draw_gap;
-    int32_t draw_status, draw_pad;
+    int32_t draw_status;
+    int32_t draw_pad;
     int32_t misc[8];  // scratch: has_edge/remove status, and the kernels' invariant guard record
     // two-hop pass (dcr_bfc_h2.hip): units per (class, weight bucket), placement cursors, units per class
     int32_t h2_bucket[24];

@@ -152,10 +152,10 @@ class SdrfRun:
         rec = {'argmin': [x, y]} if want_trace else None
 
         if self.device_draw and more and not want_trace and np.isfinite(tau):
-            # The whole iteration with one host synchronisation: the uniform np.random.choice would take is taken here and
-            # the draw itself runs on the device (dcr_sdrf_iteration_device_draw), accepted only when it is certain to be
-            # numpy's index.  Otherwise nothing was edited: the uniform goes back into the stream and the iteration runs
-            # the long way below (numpy's own exp, sum and cumsum on the host).
+            # The whole iteration without bringing the improvements to the host: the uniform np.random.choice would take is
+            # taken here and the draw itself runs on the device (dcr_sdrf_iteration_device_draw), accepted only when it is
+            # certain to be numpy's index.  Otherwise nothing was edited: the uniform goes back into the stream and the
+            # iteration runs the long way below (numpy's own exp, sum and cumsum on the host).
             state = np.random.get_state()
             uniform = np.random.random_sample()
             status, n_cand, _, _, nxt = G.sdrf_iteration_device_draw(x, y, curv_type, tau, uniform, self.remove_edges,

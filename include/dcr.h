@@ -136,13 +136,14 @@ int dcr_sdrf_tail_at_pass_argmin(dcr_graph *g, int64_t cand_index, int do_remove
                                  double *out_val);
 
 /* One whole loop iteration for finite tau (sdrf_no_cuda.py:29-66 for the edge (x, y) the previous call returned, then :24,:27 of
- * the next iteration) with ONE host synchronisation.  The draw np.random.choice(n, p=softmax(improvements, tau)) (:49-50) runs
+ * the next iteration) with the improvements staying on the device (two host round trips of the 1 KB result block; no
+ * transfer of the improvements, no host arithmetic).  The draw np.random.choice(n, p=softmax(improvements, tau)) (:49-50) runs
  * on the device from `uniform`, the one double the caller has taken from numpy's global stream: the index is the first i whose
  * prefix sum of exp(tau * improvement) exceeds uniform * total, accepted only when that comparison is decided by a margin wider
  * than every rounding difference between numpy's arithmetic and the device's.  *out_status: 0 done (outputs as
- * dcr_sdrf_tail_at_pass_argmin); 1 undecided or not finite, 2 no candidates: nothing was edited, the arg-min returned is that
- * of the unchanged graph, and the caller runs this iteration through dcr_improvements + the host draw instead (after putting
- * the uniform back into the stream). */
+ * dcr_sdrf_tail_at_pass_argmin); 1 undecided or not finite, 2 no candidates: nothing was edited, no pass was run (out_u /
+ * out_v / out_val untouched), and the caller runs this iteration through dcr_improvements + the host draw instead (after
+ * putting the uniform back into the stream). */
 int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_type, double tau, double uniform, int do_remove,
                                    double removal_bound, int incremental, int *out_status, int64_t *out_n_cand,
                                    int32_t out_added[2], int32_t out_removed[2], int32_t *out_u, int32_t *out_v, double *out_val);
