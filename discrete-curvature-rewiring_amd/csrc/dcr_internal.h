@@ -239,7 +239,7 @@ void launch_remove_if_above(dcr_graph *g, double bound, int edit);  // acts on t
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit);  // flag the edges edit number `edit` can change (>= 3: coarse)
 
 // dcr_sdrf.hip
-int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v);
+int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_t st = nullptr);  // st: default the library stream
 int process_giant_edges(dcr_graph *g, int curv_type);  // dcr_bfc_giant.hip; syncs once
 int process_hub_edges(dcr_graph *g, int curv_type, bool incremental);  // dcr_bfc_giant.hip; syncs once
 int giant_edge(dcr_graph *g, int u, int v, int du, int dv, int64_t slot, int curv_type, bool need_cycles, int64_t *d_out6);  // result in DevResult after the next sync

@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int np
 
 constexpr int ARGEXT_BLOCKS = 1024;  // (8192 blocks: 92 us instead of 33 on S100k, the per-block reduction dominates)
 
-int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
+int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_t st) {
+    if (!st) st = g->stream;
     g->amax_valid = false;  // the ext fields of the result block are about to be overwritten
     if (!g->red_scratch) {
         Ext *p = nullptr;
@@ -189,9 +190,9 @@ int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v) {
     int64_t blocks = (g->cap_total + 255) / 256;
     if (blocks > ARGEXT_BLOCKS) blocks = ARGEXT_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_argext_edges, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->cap_total, g->curv,
+    hipLaunchKernelGGL(k_argext_edges, dim3((unsigned)blocks), dim3(256), 0, st, vw, g->cap_total, g->curv,
                        want_max, excl_u, excl_v, g->dres, (Ext *)g->red_scratch);
-    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, g->stream, vw, (const Ext *)g->red_scratch, (int)blocks,
+    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, st, vw, (const Ext *)g->red_scratch, (int)blocks,
                        want_max, g->dres);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
@@ -1191,11 +1192,19 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
         DCR_FAIL(DCR_EINVAL, "device draw: finite tau and a uniform in [0, 1) expected");
     if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
     DCR_HIP(hipSetDevice(g->device));
+    // the stale arg-max of the removal step does not depend on the edge about to be drawn (see dcr_improvements), nor on the
+    // improvement pipeline: beside it, on a stream of its own (it writes other fields of the result block)
+    const bool amax = g->curv_valid && do_remove;
+    if (amax) {
+        DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
+        DCR_HIP(hipStreamWaitEvent(g->side[0], g->ev_fork, 0));
+        DCR_TRY(launch_argext(g, 1, -1, -1, g->side[0]));
+        DCR_HIP(hipEventRecord(g->ev_join[0], g->side[0]));
+    }
     int64_t upper = 0;
     DCR_TRY(imp_enqueue(g, x, y, curv_type, &upper));
-    // the stale arg-max of the removal step does not depend on the edge about to be drawn (see dcr_improvements)
-    if (g->curv_valid && do_remove) {
-        DCR_TRY(launch_argext(g, 1, -1, -1));
+    if (amax) {
+        DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[0], 0));
         g->amax_valid = true;
     }
     hipLaunchKernelGGL(k_draw_partial, dim3(DRAW_BLOCKS), dim3(256), 0, g->stream, g->imp_out, g->dres, tau, g->draw_bsum);
