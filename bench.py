@@ -27,6 +27,7 @@ for p in (REPO, PKG):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F32_MATRIX_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (MI355X_MICROARCH.md)
 PMC_PROFILE = 'r03_pmc_traffic.json'  # written by tools/pmc_traffic.sh on the GPU box, copied into profiles/
 KERNEL_TIMES = 'r03_kernel_times.json'  # rocprofv3 --kernel-trace --stats of this bench (tools/kernel_times.sh), same hash rule
 
@@ -155,6 +156,40 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
            'config': {'workload': f'synthetic preferential-attachment graph N={n} E={ei_np.shape[1] // 2}, F={F}, '
                                   f'hidden={H}, classes={C}, dropout 0.5, Adam; epoch = train step + val forward',
                       'parallelism': f'row-partitioned dp{world}' if world > 1 else 'single GPU'}}
+    # what an epoch cannot go below on this chip, kernel by kernel: the two 65.5 GFLOP contractions of layer 1 (forward
+    # and weight gradient) at the dense f32 matrix peak, everything else at the HBM roof on the bytes it has to move
+    # (fused activation forward: read N*H, write 2 N*C + bits; backward: read N*H + N*C + bits, write N*H; the three
+    # class-width aggregations on the rows and non-zeros an epoch reads; the layer-1 output written once)
+    n_tr, n_va = int(train_mask.sum()), int(val_mask.sum())
+    flops = 2.0 * 2.0 * n * F * H / world
+    nnz_sel = 2.0 * (n_tr + n_va) / n * (ei_np.shape[1] + n)   # non-zeros of the selected rows (forward) and columns (backward)
+    byts = (n * H * 4 * (1 + 1 + 2) + n * C * 4 * 3 + 2 * n * H / 8 + nnz_sel * (C * 4 + 8)) / world
+    floor_ms = (flops / (F32_MATRIX_PEAK_TFLOPS * 1e12) + byts / (HBM_PEAK_GBPS * 1e9)) * 1e3
+    res['epoch_floor_ms'] = floor_ms
+    res['epoch_floor_frac'] = floor_ms / res['ms_per_epoch']
+    res['epoch_floor_definition'] = ('layer-1 forward + weight-gradient contractions (2 x 2 N F H flop) at 157.3 TFLOP/s f32 MFMA, plus '
+                                     'the bytes of the fused activation kernels and of the row-selected aggregations at 8 TB/s')
+    res['last_aggregation'] = ('evaluated at the rows the epoch reads (training rows for the loss, validation rows for the accuracy: '
+                               f'{n_tr} + {n_va} of {n}); DCR_GCN_ALL_ROWS=1 computes every row')
+    if dist is None and not args.no_cpu_baseline:   # the same epoch with every row of the last aggregation, for comparison
+        os.environ['DCR_GCN_ALL_ROWS'] = '1'
+        try:
+            torch.manual_seed(0)
+            model2 = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
+            opt2 = torch.optim.Adam([{'params': model2.non_reg_params, 'weight_decay': 0},
+                                     {'params': model2.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True, fused=True)
+            epoch2 = make_epoch(model2, opt2, data, lagged=True)
+            for _ in range(6):
+                epoch2()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                epoch2()
+            sync()
+            res['ms_per_epoch_all_rows'] = (time.perf_counter() - t0) / 10 * 1e3
+            del model2, opt2, epoch2
+        finally:
+            os.environ.pop('DCR_GCN_ALL_ROWS', None)
     if dist is not None:
         res['rccl_ranks'] = dist.get_world_size()
         res['backend'] = dist.get_backend()
@@ -187,7 +222,8 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
                     'gathered_GBps': gathered / (ms * 1e-3) / 1e9,
                     'gathered_rows_per_ns': nnz / (ms * 1e-3) / 1e9}
         res['spmm_roofline'] = spmm_point(C)
-        res['spmm_roofline']['kernel'] = 'k_spmm_csr at the class width: the three aggregations of an epoch'
+        res['spmm_roofline']['kernel'] = ('k_spmm_csr at the class width over ALL rows (model(data) outside an epoch); an epoch runs '
+                                           'it on the rows it reads')
         res['spmm_roofline']['note'] = ('B (N x classes floats) sits in the Infinity Cache; rows are 64 bytes, so the kernel is '
                                         'bound by the rate of row requests, not by bytes (MI355X_MICROARCH.md, indexed rows)')
         res['spmm_roofline_hidden_width'] = spmm_point(H)
@@ -418,6 +454,32 @@ def main():
                'bfc_pass_ms': ms_i / max(cnt_i, 1), 'steps': n_i,
                'note': 'dcr_curvature_pass_incremental: bit-identical results (tests), not the headline metric'}
         run_i = None
+    # the same iterations with the draw on the host (improvements downloaded, numpy's exp / sum, exact cumsum): reported for
+    # comparison, never `value`
+    hostdraw = None
+    if rank == 0 and not args.no_incremental:
+        os.environ['DCR_DEVICE_DRAW'] = '0'
+        try:
+            run_h = SdrfRun(data, 'bfc', True, args.removal_bound, args.tau, device=local_rank)
+        finally:
+            os.environ.pop('DCR_DEVICE_DRAW', None)
+        np.random.seed(0)
+        for _ in range(args.warmup + 1):
+            run_h.step()
+        run_h.G.profile_reset()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        n_h = 0
+        for _ in range(args.steps):
+            n_h += 1
+            if not run_h.step():
+                break
+        torch.cuda.synchronize()
+        th = time.perf_counter() - th
+        ms_h, cnt_h = run_h.G.profile_read()
+        hostdraw = {'value': n_h / th, 'unit': 'iterations/sec', 'ms_per_step': th / n_h * 1e3, 'bfc_pass_ms': ms_h / max(cnt_h, 1),
+                    'steps': n_h, 'note': 'DCR_DEVICE_DRAW=0: the draw on the host, as in rounds 1-2'}
+        run_h = None
     # BASELINE.json configs[2] as written: a full pass + 500 SDRF iterations, one run timed end to end (graph upload and
     # row build excluded, everything else included); reported next to the K-step figure, never instead of it
     cfg2 = None
@@ -526,6 +588,10 @@ def main():
             'backend': (dist.get_backend() if dist is not None else None),
             'bfc_edges_per_sec': E / (pass_ms * 1e-3),
             'bfc_pass_ms': pass_ms,
+            'outside_pass_ms': elapsed / max(steps_done, 1) * 1e3 - pass_ms,
+            'draws': {'device': int(getattr(run, 'device_draws', 0)), 'host': int(getattr(run, 'host_draws', 0)),
+                      'note': 'np.random.choice index found on the device from the uniform taken from numpy on the host '
+                              '(dcr_sdrf_iteration_device_draw); host: draws left undecided by the margin test, redone with numpy'},
             'pass_engine': pass_engine,
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
@@ -577,6 +643,8 @@ def main():
                         'same graph (tools/make_golden.py); the Python reference cannot travel to the GPU box'}
         if inc is not None:
             out['incremental_mode'] = inc
+        if hostdraw is not None:
+            out['host_draw_mode'] = hostdraw
         if tinf is not None:
             out['tau_inf'] = tinf
         if s1m is not None:

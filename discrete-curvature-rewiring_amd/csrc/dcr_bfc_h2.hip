@@ -1786,7 +1786,7 @@ int launch_curvature_pass_h2(dcr_graph *g) {
                            g->dres);
     }
     // records of split nodes are accumulated with atomics: start from zero
-    hipLaunchKernelGGL(k_h2_retry_zero, dim3(64), dim3(256), 0, g->stream, vw, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4],
+    hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4],
                        g->h2_rec);
     // Streams: the block classes (long units; the triangle step waits for them only) on two high-priority streams, the
     // wave classes on three low-priority ones, the edge set on a stream of its own, the triangle step on a fourth
@@ -1802,15 +1802,21 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         sS0 = g->side[2];
         sa = g->aux;
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        for (hipStream_t st : {sM, sS2, sS1, sS0, sa}) DCR_HIP(hipStreamWaitEvent(st, g->ev_fork, 0));
     }
+    // (each stream's wait is enqueued right before its kernel: the GPU is through the preamble before the host is through
+    //  these calls, so every call ahead of a launch is time the chip waits)
     const int64_t hint4 = g->h2_last_count[4] >= 0 ? (int64_t)g->h2_last_count[4] + 8 : g->num_cu;
     const int64_t hint3 = g->h2_last_count[3] >= 0 ? (int64_t)g->h2_last_count[3] + 8 : 3 * (int64_t)g->num_cu;
     launch_h2_block<4, true>(g, vw, tk, rt, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4], hint4, 0, sL);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sM, g->ev_fork, 0));
     launch_h2_block<3, false>(g, vw, tk, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, sM);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sS2, g->ev_fork, 0));
     launch_h2_small<2>(g, vw, rt, sS2);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sS1, g->ev_fork, 0));
     launch_h2_small<1>(g, vw, rt, sS1);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sS0, g->ev_fork, 0));
     launch_h2_small<0>(g, vw, rt, sS0);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sa, g->ev_fork, 0));
     // the edge set (probed by k_h2_triangles only).  (Beside weights and plan, which are short and on the critical path,
     // its 32 MB memset and 1 M atomics tripled their time.)
     // (Built ahead of the pass instead — beside the improvement pipeline of the SDRF loop, patched after the tail's edits —
@@ -1836,7 +1842,7 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         for (hipEvent_t ev : {g->ev_join[3], g->ev_join[2], g->ev_aux2, g->ev_fork}) DCR_HIP(hipStreamWaitEvent(g->stream, ev, 0));
     }
     // nodes whose tables filled up in their class: zero their records, redo them with worst-case partitions
-    hipLaunchKernelGGL(k_h2_retry_zero, dim3(64), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
+    hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
                        g->h2_rec);
     tk.retry_flag = 0x80000000u;
     launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
