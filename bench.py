@@ -567,6 +567,7 @@ def main():
             s1m = {'error': f'{type(ex).__name__}: {ex}'[:300]}
     elif not args.no_gcn and world > 1:
         pass  # every rank generates the graph itself in gcn_bench (no broadcast of a 160 MB edge list)
+    draws = {'device': int(getattr(run, 'device_draws', 0)), 'host': int(getattr(run, 'host_draws', 0))}
     run = G = None  # release the SDRF graph before the GCN leg
     out = None
     if rank == 0:
@@ -589,7 +590,7 @@ def main():
             'bfc_edges_per_sec': E / (pass_ms * 1e-3),
             'bfc_pass_ms': pass_ms,
             'outside_pass_ms': elapsed / max(steps_done, 1) * 1e3 - pass_ms,
-            'draws': {'device': int(getattr(run, 'device_draws', 0)), 'host': int(getattr(run, 'host_draws', 0)),
+            'draws': {**draws,
                       'note': 'np.random.choice index found on the device from the uniform taken from numpy on the host '
                               '(dcr_sdrf_iteration_device_draw); host: draws left undecided by the margin test, redone with numpy'},
             'pass_engine': pass_engine,
