@@ -5,6 +5,7 @@
 // each lane holding VEC consecutive features, so one wave-instruction reads (64/LPR) rows of B in 16-byte
 // pieces (full 128-B lines for n_feat >= 32) and a wave covers 64/LPR output rows.  MFMA has nothing to do here:
 // the dense contraction (X·Wᵀ) is done before this kernel on the matrix cores by the GEMM library.
+#include <cstdint>
 #include "dcr_internal.h"
 
 namespace dcr {
@@ -73,8 +74,9 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
                                                    const float *__restrict__ val, const float *__restrict__ B,
                                                    float *__restrict__ C, int64_t n_rows, int n_feat, int64_t ldb,
                                                    int64_t ldc, const float *__restrict__ bias, int relu, int blk, int64_t blk_c,
-                                                   const int64_t *__restrict__ rows) {
-    // rows: nullptr, or the n_rows rows of the matrix to compute (output row k = row rows[k] of the product)
+                                                   const int64_t *__restrict__ rows, int64_t split, int64_t b_off2) {
+    // rows: nullptr, or the n_rows rows of the matrix to compute (output row k = row rows[k] of the product); output rows
+    // from `split` on take their operand b_off2 floats further into B (two row lists over two column blocks in one launch)
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     constexpr int G = ROWS_PER_BLOCK;        // lane groups per workgroup
     constexpr int U = LPR <= 8 ? 8 : 4;      // narrow rows of B: more gathers in flight per group
@@ -89,6 +91,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
     __syncthreads();
     if (row < n_rows) {
         const int64_t mrow = rows ? rows[row] : row;
+        const float *Bk = row >= split ? B + b_off2 : B;
         const int64_t e0 = rowptr[mrow], e1 = rowptr[mrow + 1];
         if (e1 - e0 > SPMM_LONG) {
             if (sl == 0) long_rows[atomicAdd(&n_long, 1)] = sub;
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
                 for (int k = 0; k < NBLK; ++k)
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) acc[k][q] = 0.f;
-                spmm_accumulate<VEC, U, NBLK>(col, val, B, ldb, f0, e0, e1, 1, blk, acc);
+                spmm_accumulate<VEC, U, NBLK>(col, val, Bk, ldb, f0, e0, e1, 1, blk, acc);
 #pragma unroll
                 for (int k = 0; k < NBLK; ++k) {
                     float *dst = C + row * ldc + f0 + k * blk_c;
@@ -119,6 +122,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
     for (int li = 0; li < nl; ++li) {
         const int64_t lrow = (int64_t)long_rows[li] * gridDim.x + blockIdx.x;
         const int64_t lmrow = rows ? rows[lrow] : lrow;
+        const float *Bk = lrow >= split ? B + b_off2 : B;
         const int64_t e0 = rowptr[lmrow], e1 = rowptr[lmrow + 1];
         for (int fb = 0; fb < n_feat; fb += LPR * VEC) {  // uniform trip count
             const int f0 = fb + sl * VEC;
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
             for (int k = 0; k < NBLK; ++k)
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[k][q] = 0.f;
-            if (f0 < n_feat) spmm_accumulate<VEC, U, NBLK>(col, val, B, ldb, f0, e0 + sub, e1, G, blk, acc);
+            if (f0 < n_feat) spmm_accumulate<VEC, U, NBLK>(col, val, Bk, ldb, f0, e0 + sub, e1, G, blk, acc);
 #pragma unroll
             for (int k = 0; k < NBLK; ++k) {
 #pragma unroll
@@ -153,15 +157,15 @@ __global__ void __launch_bounds__(256) k_spmm_csr(const int64_t *__restrict__ ro
 template <int LPR, int VEC>
 static void launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
                         int64_t n_rows, int n_feat, int64_t ldb, int64_t ldc, const float *bias, int relu, int n_blocks,
-                        int64_t blk_c, hipStream_t st, const int64_t *rows) {
+                        int64_t blk_c, hipStream_t st, const int64_t *rows, int64_t split, int64_t b_off2) {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
     const int64_t blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     if (n_blocks == 2)
         hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 2>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                           n_feat, ldb, ldc, bias, relu, n_feat, blk_c, rows);
+                           n_feat, ldb, ldc, bias, relu, n_feat, blk_c, rows, split, b_off2);
     else
         hipLaunchKernelGGL((k_spmm_csr<LPR, VEC, 1>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, B, C, n_rows,
-                           n_feat, ldb, ldc, bias, relu, 0, (int64_t)0, rows);
+                           n_feat, ldb, ldc, bias, relu, 0, (int64_t)0, rows, split, b_off2);
 }
 
 }  // namespace dcr
@@ -170,7 +174,8 @@ using namespace dcr;
 
 static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const float *B, float *C,
                          int64_t n_rows, int64_t n_feat, int64_t n_blocks, int64_t ldb, int64_t ldc, const float *bias, int relu,
-                         void *hip_stream, int64_t blk_c = -1, const int64_t *rows = nullptr) {
+                         void *hip_stream, int64_t blk_c = -1, const int64_t *rows = nullptr, int64_t split = INT64_MAX,
+                         int64_t b_off2 = 0) {
     // blk_c: where the second block of the output starts relative to the first (floats); -1: next to it (n_feat)
     if (!rowptr || !B || !C || n_rows < 0 || n_feat <= 0 || n_blocks < 1 || n_blocks > 2 || ldb < n_feat * n_blocks ||
         ldc < (blk_c < 0 ? n_feat * n_blocks : n_feat))
@@ -183,7 +188,7 @@ static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float 
     // (the template is chosen by the width of ONE block: a block of a two-block call is accumulated exactly like a call of its own)
     const bool v4 = (F % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)B & 15) == 0);
     const bool v2 = (F % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) && (((uintptr_t)B & 7) == 0);
-#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, blk_c, st, rows)
+#define GO(L, V) launch_spmm<L, V>(rowptr, col, val, B, C, n_rows, F, ldb, ldc, bias, relu, (int)n_blocks, blk_c, st, rows, split, b_off2)
     if (v4) {
         const int lanes = F / 4;
         if (lanes <= 4) GO(4, 4);
@@ -237,6 +242,19 @@ extern "C" int dcr_spmm_csr_rows_f32_dev(const int64_t *rowptr, const int32_t *c
                                          const float *bias, int relu, void *hip_stream) {
     if (!rows && n_sel > 0) DCR_FAIL(DCR_EINVAL, "bad SpMM arguments (no row list)");
     return spmm_dispatch(rowptr, col, val, B, C, n_sel, n_feat, 1, ldb, ldc, bias, relu, hip_stream, -1, rows);
+}
+
+// Two row lists over two column blocks of one operand in ONE launch: output rows [0, n_first) are rows rows_dev[k] of Â·B0,
+// rows [n_first, n_sel) those of Â·B1 with B1 = B0 + b_off2 floats (the training rows of Â·Z_train and the validation rows of
+// Â·Z_eval of an epoch, Z = [Z_train | Z_eval]).  Each row as dcr_spmm_csr_rows_f32_dev computes it.
+extern "C" int dcr_spmm_csr_rows2_f32_dev(const int64_t *rowptr, const int32_t *col, const float *val, const int64_t *rows,
+                                          int64_t n_first, int64_t n_sel, const float *B, int64_t b_off2, float *C, int64_t n_feat,
+                                          int64_t ldb, int64_t ldc, const float *bias, int relu, void *hip_stream) {
+    if ((!rows && n_sel > 0) || n_first < 0 || n_first > n_sel || b_off2 < 0 || b_off2 + n_feat > ldb)
+        DCR_FAIL(DCR_EINVAL, "bad SpMM arguments (row lists)");
+    // (the 16-byte path needs both operands aligned: decided on B0, so B1 must keep its alignment)
+    if ((b_off2 % 4) != 0 && (n_feat % 4) == 0) DCR_FAIL(DCR_EINVAL, "bad SpMM arguments (second operand not 16 bytes apart)");
+    return spmm_dispatch(rowptr, col, val, B, C, n_sel, n_feat, 1, ldb, ldc, bias, relu, hip_stream, -1, rows, n_first, b_off2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ SIGNATURES = {
     'dcr_host_cdf_from_exp_plain': (ctypes.c_int, [_f64p, _i64, _f64, _f64p, _f64p]),
     'dcr_spmm_csr_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),
     'dcr_spmm_csr_f32_pair_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),
+    'dcr_spmm_csr_rows2_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),
     'dcr_spmm_csr_rows_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),
     'dcr_spmm_csr_f32_pair_split_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_int, _vp]),
     'dcr_relu_dropout_bits_words': (ctypes.c_int, [_i64, _i64p]),

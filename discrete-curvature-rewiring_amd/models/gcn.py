@@ -205,6 +205,14 @@ class RowSelection:
         self._csr = csr
         self._t = None
 
+    def joined_with(self, other):
+        """[idx | other.idx] as one tensor (the row list of ``dcr_spmm_csr_rows2_f32_dev``); built once per pair."""
+        cache = self.__dict__.setdefault('_joined', {})
+        hit = cache.get(id(other))
+        if hit is None or hit[0] is not other:
+            hit = cache[id(other)] = (other, torch.cat([self.idx, other.idx]).contiguous())
+        return hit[1]
+
     def transposed(self):
         """(rowptr, col, val) of Âᵀ[:, idx] with the columns renumbered 0..n-1 (positions in ``idx``); built once."""
         if self._t is None:
@@ -269,6 +277,51 @@ class _AggregateRows(torch.autograd.Function):
 
 def aggregate_rows(z, bias, csr, sel):
     return _AggregateRows.apply(z, bias, csr, sel)
+
+
+class _AggregateRowsPair(torch.autograd.Function):
+    """((Â·Z_train + b)[rows_train], (Â·Z_eval + b)[rows_eval]) in ONE launch when the two operands are the halves of one
+    buffer (act_then_linear writes them that way): ``dcr_spmm_csr_rows2_f32_dev``, every row as ``spmm_rows`` computes it.
+    Only the training operand carries a gradient (as ``_AggregateRows``)."""
+
+    @staticmethod
+    def forward(ctx, z_train, z_eval, bias, csr, sel_train, sel_eval):
+        ctx.csr, ctx.sel = csr, sel_train
+        ctx.has_bias = bias is not None
+        ctx.z_shape = z_train.shape
+        f = z_train.shape[1]
+        joined = (_AGG_BACKEND == 'hip' and z_train.is_cuda and z_train.dtype == torch.float32 and f % 4 == 0
+                  and z_train.stride() == (2 * f, 1) and z_eval.stride() == (2 * f, 1)
+                  and z_eval.data_ptr() == z_train.data_ptr() + 4 * f and sel_train.n > 0 and sel_eval.n > 0)
+        if not joined:
+            out_ev = spmm_rows(csr, sel_eval, z_eval, bias)
+            ctx.mark_non_differentiable(out_ev)
+            return spmm_rows(csr, sel_train, z_train, bias), out_ev
+        from dcr import _lib
+        both = sel_train.joined_with(sel_eval)
+        C = torch.empty((sel_train.n + sel_eval.n, f), dtype=torch.float32, device=z_train.device)
+        stream = torch.cuda.current_stream(z_train.device).cuda_stream
+        _lib.check(_lib.lib().dcr_spmm_csr_rows2_f32_dev(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(), both.data_ptr(),
+                                                         sel_train.n, sel_train.n + sel_eval.n, z_train.data_ptr(), f, C.data_ptr(), f,
+                                                         2 * f, f, bias.data_ptr() if bias is not None else None, 0,
+                                                         ctypes.c_void_p(stream)))
+        out_tr, out_ev = C[:sel_train.n], C[sel_train.n:]
+        ctx.mark_non_differentiable(out_ev)
+        return out_tr, out_ev
+
+    @staticmethod
+    def backward(ctx, grad_train, grad_eval):
+        csr, sel = ctx.csr, ctx.sel
+        grad_train = grad_train.contiguous()
+        gz = None
+        if ctx.needs_input_grad[0]:
+            if sel.n == 0:
+                gz = grad_train.new_zeros(ctx.z_shape)
+            else:
+                rp, ci, va = sel.transposed()
+                gz = spmm(rp, ci, va, grad_train, csr.n_cols)
+        gb = grad_train.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gz, None, gb, None, None, None
 
 
 def atb_hip(a, b):
@@ -631,9 +684,8 @@ class GCN(torch.nn.Module):
                 _, z_ev = act_then_linear(o_ev, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
             csr = conv.norm_csr(data.edge_index, data.edge_attr, o_tr.shape[0])
             if rows_train is not None and depth == last:
-                o_tr = aggregate_rows(z_tr, conv.bias, csr, conv.row_selection(rows_train, csr))
-                with torch.no_grad():
-                    o_ev = spmm_rows(csr, conv.row_selection(rows_eval, csr), z_ev, conv.bias)
+                o_tr, o_ev = _AggregateRowsPair.apply(z_tr, z_ev, conv.bias, csr, conv.row_selection(rows_train, csr),
+                                                      conv.row_selection(rows_eval, csr))
             else:
                 o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, conv.bias, csr)
         if rows_train is not None and last == 0:

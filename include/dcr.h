@@ -217,6 +217,12 @@ int dcr_spmm_csr_f32_pair_split_dev(const int64_t *rowptr_dev, const int32_t *co
 int dcr_spmm_csr_rows_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const int64_t *rows_dev,
                               int64_t n_sel, const float *B_dev, float *C_dev, int64_t n_feat, int64_t ldb, int64_t ldc,
                               const float *bias_dev, int relu, void *hip_stream);
+/* Two row lists over two column blocks of one operand in one launch: output rows [0, n_first) = rows rows_dev[k] of Â·B0,
+ * rows [n_first, n_sel) = rows rows_dev[k] of Â·B1, B1 = B0 + b_off2 floats (the training rows of Â·Z_train and the validation
+ * rows of Â·Z_eval of one epoch, Z = [Z_train | Z_eval]: experiment/training_loop.py:50-51 and :64-71 on the same weights). */
+int dcr_spmm_csr_rows2_f32_dev(const int64_t *rowptr_dev, const int32_t *col_dev, const float *val_dev, const int64_t *rows_dev,
+                               int64_t n_first, int64_t n_sel, const float *B_dev, int64_t b_off2, float *C_dev, int64_t n_feat,
+                               int64_t ldb, int64_t ldc, const float *bias_dev, int relu, void *hip_stream);
 
 /* ---- GCN weight gradient on the matrix cores (device pointers, caller's stream)
  * C[M x N] = A^T * B with A [K x M] and B [K x N] row-major fp32 (lda/ldb/ldc in
