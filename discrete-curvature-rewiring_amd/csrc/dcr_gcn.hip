@@ -815,6 +815,94 @@ static void launch_act_linear_fwd(bool train, bool eval, const float *x, const f
 
 }  // namespace dcr
 
+// ---- loss and accuracy on the selected rows (experiment/training_loop.py:51 F.nll_loss(log_probs[mask], y[mask]); :64-71
+// log_probs[mask].max(1)[1].eq(y[mask]).sum()) — a dozen stock element-wise / reduction launches of a few microseconds each per
+// epoch, as three kernels.  The gradient is -g / m at the picked entries and zero elsewhere, as the stock kernels give it.
+namespace dcr {
+
+__global__ void __launch_bounds__(1024) k_picked_mean_fwd(const float *__restrict__ lp, int64_t ld, const int64_t *__restrict__ y,
+                                                           int64_t m, int C, float *__restrict__ out) {
+    __shared__ double red[1024];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) {
+        const int64_t t = y[i];
+        if (t >= 0 && t < C) a += (double)lp[i * ld + t];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(-red[0] / (double)m);
+}
+
+__global__ void __launch_bounds__(256) k_picked_mean_bwd(const int64_t *__restrict__ y, int64_t m, int C, const float *__restrict__ g,
+                                                          float *__restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one element of the [m, C] gradient
+    if (i >= m * C) return;
+    const int64_t row = i / C;
+    const int c = (int)(i - row * C);
+    grad[i] = y[row] == c ? -(g[0] / (float)m) : 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_count_argmax_equal(const float *__restrict__ lp, int64_t ld, const int64_t *__restrict__ y,
+                                                             int64_t m, int C, unsigned long long *__restrict__ out) {
+    __shared__ int red[256];
+    int hits = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const float *r = lp + i * ld;
+        float best = r[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {  // first maximum; a NaN counts as the maximum (torch.max)
+            const float v = r[c];
+            if (!(best != best) && (v > best || v != v)) {
+                best = v;
+                arg = c;
+            }
+        }
+        hits += (int64_t)arg == y[i] ? 1 : 0;
+    }
+    red[threadIdx.x] = hits;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0]) atomicAdd(out, (unsigned long long)red[0]);
+}
+
+}  // namespace dcr
+
+extern "C" int dcr_nll_picked_mean_fwd_f32_dev(const float *lp, int64_t ld, const int64_t *y, int64_t m, int classes, float *out_loss,
+                                               void *hip_stream) {
+    if (!lp || !y || !out_loss || m <= 0 || classes < 1 || ld < classes) DCR_FAIL(DCR_EINVAL, "bad nll arguments");
+    hipLaunchKernelGGL(dcr::k_picked_mean_fwd, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, lp, ld, y, m, classes, out_loss);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_nll_picked_mean_bwd_f32_dev(const int64_t *y, int64_t m, int classes, const float *g, float *grad, void *hip_stream) {
+    if (!y || !g || !grad || m <= 0 || classes < 1) DCR_FAIL(DCR_EINVAL, "bad nll arguments");
+    const int64_t blocks = (m * classes + 255) / 256;
+    hipLaunchKernelGGL(dcr::k_picked_mean_bwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, y, m, classes, g, grad);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_count_argmax_equal_f32_dev(const float *lp, int64_t ld, const int64_t *y, int64_t m, int classes, int64_t *out_count,
+                                              void *hip_stream) {
+    if (!out_count || m < 0 || classes < 1 || ld < classes || (m > 0 && (!lp || !y))) DCR_FAIL(DCR_EINVAL, "bad accuracy arguments");
+    DCR_HIP(hipMemsetAsync(out_count, 0, sizeof(int64_t), (hipStream_t)hip_stream));
+    if (m == 0) return DCR_OK;
+    int64_t blocks = (m + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dcr::k_count_argmax_equal, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, lp, ld, y, m, classes,
+                       (unsigned long long *)out_count);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
 extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float *h_train, float *z_train, float *z_eval, int64_t ldz,
                                           uint64_t *bits, int64_t n_rows, int hidden, int classes, double p, uint64_t seed,
                                           uint64_t offset, const uint64_t *offset_dev, void *hip_stream) {

@@ -24,6 +24,50 @@ import torch
 import torch.nn.functional as F
 
 
+class _PickedMean(torch.autograd.Function):
+    """``-log_probs.gather(1, y[:, None]).mean()`` and its backward as one kernel each (csrc/dcr_gcn.hip): the gradient is
+    ``-g / m`` at the picked entries and zero elsewhere, bit for bit what ``F.nll_loss`` (training_loop.py:51) gives."""
+
+    @staticmethod
+    def forward(ctx, log_probs, y):
+        import ctypes
+        from dcr import _lib
+        lp = log_probs.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=lp.device)
+        stream = torch.cuda.current_stream(lp.device).cuda_stream
+        _lib.check(_lib.lib().dcr_nll_picked_mean_fwd_f32_dev(lp.data_ptr(), lp.shape[1], y.data_ptr(), lp.shape[0], lp.shape[1],
+                                                              out.data_ptr(), ctypes.c_void_p(stream)))
+        ctx.y, ctx.shape = y, tuple(lp.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from dcr import _lib
+        g = g.contiguous().float()
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        stream = torch.cuda.current_stream(g.device).cuda_stream
+        _lib.check(_lib.lib().dcr_nll_picked_mean_bwd_f32_dev(ctx.y.data_ptr(), ctx.shape[0], ctx.shape[1], g.data_ptr(), grad.data_ptr(),
+                                                              ctypes.c_void_p(stream)))
+        return grad, None
+
+
+def _count_correct(log_probs, y):
+    """``log_probs.max(1)[1].eq(y).sum()`` (training_loop.py:64-71) as one kernel: int64 0-dim tensor."""
+    import ctypes
+    from dcr import _lib
+    lp = log_probs.contiguous()
+    out = torch.empty((), dtype=torch.int64, device=lp.device)
+    stream = torch.cuda.current_stream(lp.device).cuda_stream
+    _lib.check(_lib.lib().dcr_count_argmax_equal_f32_dev(lp.data_ptr(), lp.shape[1] if lp.dim() == 2 else 1, y.data_ptr(), lp.shape[0],
+                                                         lp.shape[1], out.data_ptr(), ctypes.c_void_p(stream)))
+    return out
+
+
+def _fused_ok(t):
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] > 0
+
+
 def _takes_rows(model):
     """Models of this package compute ``model(data)[mask]`` as ``model(data, rows=mask)``: the last aggregation evaluated at
     the rows the caller reads (models/gcn.py).  ``DCR_GCN_ALL_ROWS=1``: always the full output, indexed afterwards."""
@@ -102,6 +146,8 @@ class GraphedEpoch:
         backward at the bench shape), a gather and a mean are a few small multi-workgroup kernels."""
         if not self.rows:
             log_probs = log_probs.index_select(0, self.train_idx)
+        if self.rows and _fused_ok(log_probs):
+            return _PickedMean.apply(log_probs, self.y_train)
         return -log_probs.gather(1, self.y_train.unsqueeze(1)).mean()
 
     def _train_step(self):
@@ -114,7 +160,8 @@ class GraphedEpoch:
     def _val_correct(self):
         with torch.no_grad():
             if self.rows:
-                return self.model(self.data, rows=self.val_idx).max(1)[1].eq(self.y_val).sum()
+                lp = self.model(self.data, rows=self.val_idx)
+                return _count_correct(lp, self.y_val) if _fused_ok(lp) else lp.max(1)[1].eq(self.y_val).sum()
             log_probs = self.model(self.data)
         return log_probs.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
 
@@ -173,11 +220,10 @@ class LaggedGraphedEpoch(GraphedEpoch):
                 and GraphedEpoch.supported(model, optimizer, data))
 
     def _fused_step(self):
-        for dst, src in zip(self.prev, self.model.state_dict().values()):
-            dst.copy_(src)
+        torch._foreach_copy_(self.prev, list(self.model.state_dict().values()))   # (one launch for the snapshot)
         if self.rows:
             lp_train, lp_eval = self.model.forward_pair(self.data, rows_train=self.train_idx, rows_eval=self.val_idx)
-            correct_prev = lp_eval.max(1)[1].eq(self.y_val).sum()
+            correct_prev = _count_correct(lp_eval, self.y_val) if _fused_ok(lp_eval) else lp_eval.max(1)[1].eq(self.y_val).sum()
         else:
             lp_train, lp_eval = self.model.forward_pair(self.data)
             correct_prev = lp_eval.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()

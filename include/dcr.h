@@ -276,6 +276,17 @@ int dcr_act_linear_bwd_fused_f32_dev(const float *dz_dev, const float *w_dev, co
                                      float *dx_dev, float *dw_dev, float *colsum_dev, float *ws_dev, int64_t ws_floats,
                                      int64_t n_rows, int hidden, int classes, double p, void *hip_stream);
 
+/* ---- loss and accuracy on the rows an epoch reads (device pointers, caller's stream) ----
+ * experiment/training_loop.py:51 F.nll_loss(log_probs[mask], y[mask]) as out_loss[0] = -mean_i lp[i, y_i] over m rows of
+ * log-probabilities (row stride ld), and its backward grad[i, c] = (c == y_i) ? -g[0] / m : 0 over the contiguous [m, classes]
+ * gradient (what the stock kernels produce); :64-71 log_probs[mask].max(1)[1].eq(y[mask]).sum() as out_count[0] (first maximum
+ * per row). */
+int dcr_nll_picked_mean_fwd_f32_dev(const float *lp_dev, int64_t ld, const int64_t *y_dev, int64_t m, int classes, float *out_loss_dev,
+                                    void *hip_stream);
+int dcr_nll_picked_mean_bwd_f32_dev(const int64_t *y_dev, int64_t m, int classes, const float *g_dev, float *grad_dev, void *hip_stream);
+int dcr_count_argmax_equal_f32_dev(const float *lp_dev, int64_t ld, const int64_t *y_dev, int64_t m, int classes, int64_t *out_count_dev,
+                                   void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
