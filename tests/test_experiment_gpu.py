@@ -302,3 +302,50 @@ def test_epochs_on_selected_rows_follow_the_full_output_epochs(monkeypatch):
     assert runs['0'][0] == runs['1'][0]
     for a, b in zip(runs['0'][1], runs['1'][1]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_loss_and_accuracy_kernels_against_the_stock_ops():
+    """dcr_nll_picked_mean_* and dcr_count_argmax_equal_f32_dev (the masked NLL and the arg-max accuracy of
+    experiment/training_loop.py:51,64-71 on the selected rows): the gradient bit for bit what F.nll_loss gives, the loss to
+    rounding, the count exactly — ties resolved to the first maximum and a NaN counted as the maximum, as torch.max does."""
+    import torch.nn.functional as F
+    from experiment.training_loop import _PickedMean, _count_correct
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for m, c in ((1, 3), (1000, 16), (99703, 16), (4097, 7)):
+        logits = torch.randn(m, c, device='cuda', generator=g)
+        y = torch.randint(0, c, (m,), device='cuda', generator=g)
+        a = logits.clone().requires_grad_(True)
+        b = logits.clone().requires_grad_(True)
+        la = _PickedMean.apply(F.log_softmax(a, dim=1), y)
+        lb = F.nll_loss(F.log_softmax(b, dim=1), y)
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+        (la * 1.0).backward()
+        lb.backward()
+        assert torch.equal(a.grad, b.grad), (m, c)
+        lp = F.log_softmax(logits, dim=1)
+        assert int(_count_correct(lp, y)) == int(lp.max(1)[1].eq(y).sum())
+    # ties and NaNs
+    lp = torch.tensor([[0.5, 0.5, 0.1], [0.1, 0.7, 0.7], [float('nan'), 1.0, 2.0], [1.0, float('nan'), float('nan')], [0.0, 0.0, 0.0]],
+                      device='cuda')
+    for y in ([0, 1, 0, 1, 0], [1, 2, 2, 2, 2], [0, 1, 2, 0, 1]):
+        yt = torch.tensor(y, device='cuda')
+        assert int(_count_correct(lp, yt)) == int(lp.max(1)[1].eq(yt).sum()), y
+
+
+def test_two_row_lists_in_one_launch():
+    """dcr_spmm_csr_rows2_f32_dev (training rows of the first column block, validation rows of the second) against two
+    dcr_spmm_csr_rows_f32_dev calls: the same bits, with and without a bias, including empty lists on either side."""
+    from models.gcn import RowSelection, _AggregateRowsPair, gcn_norm_csr, spmm_rows
+    model, _, data = _gcn_case(0.0)
+    n = data.num_nodes
+    csr = gcn_norm_csr(data.edge_index, None, n)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    empty = torch.zeros(n, dtype=torch.bool, device='cuda')
+    for f in (16, 8, 4):
+        both = torch.randn(n, 2 * f, device='cuda', generator=g)
+        bias = torch.randn(f, device='cuda', generator=g)
+        for m_tr, m_ev in ((data.train_mask, data.val_mask), (data.val_mask, data.train_mask), (empty, data.val_mask), (data.train_mask, empty)):
+            s_tr, s_ev = RowSelection(csr, m_tr), RowSelection(csr, m_ev)
+            for b in (bias, None):
+                o_tr, o_ev = _AggregateRowsPair.apply(both[:, :f], both[:, f:], b, csr, s_tr, s_ev)
+                assert torch.equal(o_tr, spmm_rows(csr, s_tr, both[:, :f], b)) and torch.equal(o_ev, spmm_rows(csr, s_ev, both[:, f:], b))
