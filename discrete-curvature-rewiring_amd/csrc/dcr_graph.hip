@@ -81,9 +81,8 @@ __device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32
     }
 }
 
-__global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *rowcap, int32_t *col, int32_t u,
-                                                 int32_t v, DevResult *res) {
-    int lane = threadIdx.x;
+__device__ inline void dev_add_edge(int2 *rowinfo, const int32_t *rowcap, int32_t *col, int32_t u, int32_t v, DevResult *res,
+                                    int lane) {  // one wave; lane = its lane
     if (u == -2) {  // the pair picked on the device (dcr_sdrf_tail_at)
         if (res->draw_status != 0) {  // the device-side draw did not decide: nothing is edited, the host takes over
             if (lane == 0) res->add_status = 3;
@@ -113,6 +112,11 @@ __global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *r
     rowinfo[u] = make_int2(ru.x, ru.y + 1);
     rowinfo[v] = make_int2(rv.x, rv.y + 1);
     res->add_status = 0;
+}
+
+__global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *rowcap, int32_t *col, int32_t u,
+                                                 int32_t v, DevResult *res) {
+    dev_add_edge(rowinfo, rowcap, col, u, v, res, threadIdx.x);
 }
 
 __global__ void __launch_bounds__(64) k_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32_t u, int32_t v,
@@ -183,6 +187,47 @@ __global__ void __launch_bounds__(256) k_mark_dirty_ext(const int2 *rowinfo, con
         dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit, threadIdx.x, blockDim.x);
 }
 
+// The whole tail of an SDRF iteration as ONE launch when the stale arg-max is already in the result block (sdrf_no_cuda.py:51,
+// 56-66): add (u, v), flag what the add can change, flag what the removal can change while the edge is still there, remove the
+// arg-max edge iff above the bound.  Four launches of one or four waves each cost their launch gaps, not their work.
+__global__ void __launch_bounds__(256) k_sdrf_tail(int2 *rowinfo, const int32_t *rowcap, int32_t *col, double *curv, uint8_t *dirty,
+                                                    DevResult *res, int32_t u, int32_t v, int edit_add, int do_remove, double bound,
+                                                    int edit_rem) {
+    const int tid = threadIdx.x;
+    if (tid < 64) dev_add_edge(rowinfo, rowcap, col, u, v, res, tid);
+    __threadfence();
+    __syncthreads();
+    int32_t au = u, av = v;
+    bool mark = true;
+    if (u == -2) {
+        mark = res->draw_status == 0;
+        au = res->cand_i;
+        av = res->cand_j;
+    }
+    if (mark) dev_mark_dirty(rowinfo, col, dirty, au, av, edit_add, tid, 256);
+    if (!do_remove) return;
+    const int st_add = res->add_status;
+    if (st_add == 1 || st_add == 3) return;  // (uniform) add overflowed: replayed after a re-layout / no draw
+    const bool doit = res->ext_slot >= 0 && res->ext_val > bound;
+    if (doit) dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit_rem, tid, 256);
+    __threadfence();
+    __syncthreads();
+    if (tid >= 64) return;
+    if (!doit) {
+        if (tid == 0) {
+            res->removed_u = -1;
+            res->removed_v = -1;
+        }
+        return;
+    }
+    int st = 0;
+    dev_remove_edge(rowinfo, col, curv, res->ext_u, res->ext_v, tid, &st);
+    if (tid == 0) {
+        res->removed_u = res->ext_u;
+        res->removed_v = res->ext_v;
+    }
+}
+
 __global__ void __launch_bounds__(64) k_has_edge(const int2 *rowinfo, const int32_t *col, int32_t u, int32_t v,
                                                  DevResult *res) {
     int2 ru = rowinfo[u], rv = rowinfo[v];
@@ -219,6 +264,11 @@ __global__ void k_relayout(const int2 *old_info, const int32_t *old_col, const d
 // ---------------------------------------------------------------------------------------------
 void launch_add_edge(dcr_graph *g, int32_t u, int32_t v) {
     hipLaunchKernelGGL(k_add_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->rowcap, g->col, u, v, g->dres);
+}
+
+void launch_sdrf_tail(dcr_graph *g, int32_t u, int32_t v, int edit_add, int do_remove, double bound, int edit_rem) {
+    hipLaunchKernelGGL(k_sdrf_tail, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->rowcap, g->col, g->curv, g->dirty, g->dres, u, v,
+                       edit_add, do_remove, bound, edit_rem);
 }
 
 void launch_remove_if_above(dcr_graph *g, double bound, int edit) {

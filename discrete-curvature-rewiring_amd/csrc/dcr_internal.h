@@ -236,6 +236,8 @@ int relayout(dcr_graph *g);
 int sync_result(dcr_graph *g);  // D2H of DevResult + stream sync
 void launch_add_edge(dcr_graph *g, int32_t u, int32_t v);          // u < 0: no-op that clears add_status
 void launch_remove_if_above(dcr_graph *g, double bound, int edit);  // acts on the last argext result
+// add + dirty flags + conditional removal of the arg-max already in the result block, one launch (dcr_graph.hip: k_sdrf_tail)
+void launch_sdrf_tail(dcr_graph *g, int32_t u, int32_t v, int edit_add, int do_remove, double bound, int edit_rem);
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit);  // flag the edges edit number `edit` can change (>= 3: coarse)
 
 // dcr_sdrf.hip

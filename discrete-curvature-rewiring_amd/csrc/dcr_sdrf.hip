@@ -1071,6 +1071,11 @@ static int tail_prepare(dcr_graph *g, int32_t add_k, int32_t add_l, int do_remov
 }
 
 static int tail_enqueue(dcr_graph *g, const TailCall &tc, bool first_attempt) {
+    if (tc.adding && (!tc.do_remove || (tc.have_amax && first_attempt))) {  // nothing to compute in between: one launch
+        launch_sdrf_tail(g, tc.add_k, tc.add_l, tc.edit_add, tc.do_remove, tc.bound, tc.edit_rem);
+        DCR_HIP(hipGetLastError());
+        return DCR_OK;
+    }
     launch_add_edge(g, tc.add_k, tc.add_l);
     launch_mark_dirty(g, tc.add_k, tc.add_l, tc.edit_add);  // after the append: the new neighbours are flagged too
     if (tc.do_remove) {
