@@ -993,15 +993,18 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
     hipStream_t s1 = g->stream, s2 = g->stream, s3 = g->stream;
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
-        for (int b = 0; b < 3; ++b) DCR_HIP(hipStreamWaitEvent(g->side[b], g->ev_fork, 0));
         s1 = g->side[0]; s2 = g->side[1]; s3 = g->side[2];
     }
     // a class whose smallest degree exceeds the (host-tracked upper bound of the) largest degree has no units: on
-    // small graphs that saves the dispatch of up to four full persistent grids
+    // small graphs that saves the dispatch of up to four full persistent grids.  (Each side stream's wait is enqueued
+    // right before its kernel: the chip is through the plan before the host is through these calls.)
     if (g->max_deg_bound > nc_maxdeg(3)) launch_nc_block_big<MODE>(g, vw, curv_type, g->stream);  // classes 4 and 3
     else if (g->max_deg_bound > nc_maxdeg(2)) launch_nc_block<3, MODE>(g, vw, curv_type, g->stream);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(s1, g->ev_fork, 0));
     if (g->max_deg_bound > nc_maxdeg(1)) launch_nc_block<2, MODE>(g, vw, curv_type, s1);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(s2, g->ev_fork, 0));
     if (g->max_deg_bound > nc_maxdeg(0)) launch_nc_wave<1, MODE>(g, vw, curv_type, s2);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(s3, g->ev_fork, 0));
     launch_nc_wave<0, MODE>(g, vw, curv_type, s3);
     if (!serial) {
         for (int b = 0; b < 3; ++b) {

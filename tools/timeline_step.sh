@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl_step
-K=12 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_step -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_step.py > /dev/null 2>&1
+K=12 INC=${INC:-0} timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_step -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_step.py > /dev/null 2>&1
 python3 - > $OUT/${TAG}_step_timeline.txt <<'PY'
 import csv
 rows = list(csv.DictReader(open('/tmp/tl_step/p_kernel_trace.csv')))
