@@ -109,6 +109,73 @@ def draw_index(improvements, tau):
     return lo
 
 
+class _StreamMark:
+    """Put ONE uniform back into numpy's global stream (the device-side draw takes it before it knows whether numpy would
+    have).  ``np.random.get_state()`` / ``set_state()`` cost 34 us each — more than the whole draw on the device; the global
+    ``RandomState`` sits on an ``MT19937`` bit generator whose state struct (624 key words + position: 2,500 bytes) numpy
+    exposes by address for exactly this kind of interop (``BitGenerator.ctypes.state_address``), so the mark is a 2.5 KB
+    ``memmove`` (0.3 us).  Checked once against ``get_state`` / ``set_state`` themselves; anything unexpected (another bit
+    generator installed, the check failing) falls back to those two calls."""
+
+    _SIZE = 624 * 4 + 4
+    _checked = None  # None: not yet; True / False: the fast way is / is not usable
+
+    def __init__(self):
+        import ctypes
+        self._ctypes = ctypes
+        self._buf = ctypes.create_string_buffer(self._SIZE)
+        self._slow = None
+        self._addr = 0
+
+    @staticmethod
+    def _address():
+        try:
+            from numpy.random import MT19937
+            bg = np.random.mtrand._rand._bit_generator
+            return int(bg.ctypes.state_address) if type(bg) is MT19937 else 0
+        except Exception:  # noqa: BLE001  (private attribute layout of another numpy)
+            return 0
+
+    @classmethod
+    def _self_check(cls):
+        addr = cls._address()
+        if not addr:
+            return False
+        import ctypes
+        before = np.random.get_state()
+        try:
+            buf = ctypes.create_string_buffer(cls._SIZE)
+            ctypes.memmove(buf, addr, cls._SIZE)
+            first = np.random.random_sample(3)
+            moved = np.random.get_state()
+            ctypes.memmove(addr, buf, cls._SIZE)
+            back = np.random.get_state()
+            again = np.random.random_sample(3)
+            same = lambda a, b: np.array_equal(a[1], b[1]) and a[2] == b[2]   # (key words, position)
+            ok = same(back, before) and not same(moved, before)
+            return bool(ok and np.array_equal(first, again))
+        finally:
+            np.random.set_state(before)
+
+    def mark(self):
+        if _StreamMark._checked is None:
+            _StreamMark._checked = self._self_check()
+        self._addr = self._address() if _StreamMark._checked else 0
+        if self._addr:
+            self._ctypes.memmove(self._buf, self._addr, self._SIZE)
+            self._slow = None
+        else:
+            self._slow = np.random.get_state()
+
+    def rewind(self):
+        if self._slow is not None:
+            np.random.set_state(self._slow)
+        elif self._addr and self._addr == self._address():
+            self._ctypes.memmove(self._addr, self._buf, self._SIZE)
+        else:
+            raise RuntimeError('numpy global bit generator was replaced between mark() and rewind()')
+
+
 class SdrfRun:
     """One SDRF rewiring run, steppable: ``step()`` is one iteration of the loop body
     sdrf_no_cuda.py:22-66 and returns False when the reference loop would ``break``."""
@@ -130,6 +197,7 @@ class SdrfRun:
         # DCR_DEVICE_DRAW=0: always draw on the host (numpy's exp / sum / cumsum on the downloaded improvements)
         self.device_draw = os.environ.get('DCR_DEVICE_DRAW', '1') != '0'
         self.device_draws = self.host_draws = 0
+        self._mark = _StreamMark()
         self._next_argmin = None  # (x, y) of the pass already run for the coming iteration (see step)
         self.last = (None, None, None)  # (x, y, candidates) of the last iteration (bench.py: bytes of the improvement step)
 
@@ -156,7 +224,7 @@ class SdrfRun:
             # taken here and the draw itself runs on the device (dcr_sdrf_iteration_device_draw), accepted only when it is
             # certain to be numpy's index.  Otherwise nothing was edited: the uniform goes back into the stream and the
             # iteration runs the long way below (numpy's own exp, sum and cumsum on the host).
-            state = np.random.get_state()
+            self._mark.mark()
             uniform = np.random.random_sample()
             status, n_cand, _, _, nxt = G.sdrf_iteration_device_draw(x, y, curv_type, tau, uniform, self.remove_edges,
                                                                     self.removal_bound, incremental=self.incremental)
@@ -165,7 +233,7 @@ class SdrfRun:
                 self.last = (x, y, int(n_cand))
                 self.device_draws += 1
                 return True
-            np.random.set_state(state)
+            self._mark.rewind()
             self.host_draws += 1
 
         k = l = idx = None

@@ -239,3 +239,34 @@ def test_ordered_graph_follows_networkx():
         H = nx.convert_node_labels_to_integers(U).to_directed()      # what from_networkx lists for an undirected graph
         assert [list(e) for e in H.edges] == OU.to_edge_index().T.tolist()
         assert OU.number_of_edges() == U.number_of_edges()
+
+
+def test_stream_mark_puts_one_uniform_back():
+    """rewiring/sdrf_no_cuda.py::_StreamMark (the device-side draw takes the uniform of np.random.choice before it knows
+    whether numpy would have taken one): mark / draw / rewind leaves numpy's global stream exactly where get_state /
+    set_state would, at every position of the Mersenne Twister's block including the one where a draw regenerates it, and
+    the self-check it runs first leaves the stream untouched."""
+    from rewiring.sdrf_no_cuda import _StreamMark
+    np.random.seed(12345)
+    before = np.random.get_state()
+    assert _StreamMark._self_check() is True
+    after = np.random.get_state()
+    assert np.array_equal(before[1], after[1]) and before[2] == after[2]
+    m = _StreamMark()
+    for start in (0, 1, 310, 311, 312, 623, 1000):
+        np.random.seed(7)
+        np.random.random_sample(start)
+        want_state = np.random.get_state()
+        m.mark()
+        u = np.random.random_sample()
+        m.rewind()
+        got_state = np.random.get_state()
+        assert np.array_equal(want_state[1], got_state[1]) and want_state[2:] == got_state[2:], start
+        assert np.random.random_sample() == u
+    # a gaussian cached by the legacy stream survives (it lives outside the bit generator's state)
+    np.random.seed(3)
+    np.random.standard_normal()
+    st = np.random.get_state()
+    m.mark(); np.random.random_sample(); m.rewind()
+    st2 = np.random.get_state()
+    assert st[3:] == st2[3:] and np.array_equal(st[1], st2[1]) and st[2] == st2[2]
