@@ -1644,24 +1644,30 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= g.cap_total) return;
     if (*status != 0) return;  // some records are missing: the whole pass is redone by the node-centric kernels
+    // Two rounds of loads, not six behind one another: everything addressed by the slot itself first (its row, its
+    // neighbour, its record — all in bounds for every slot, slack included), then everything addressed by those (the two row
+    // headers, the partner slot's neighbour, row and record, from clamped indices); validity is decided afterwards.
     const int u = g.slot_row[s];
-    if (u < 0 || u >= g.n) return;
-    const int2 ru = g.rowinfo[u];
-    if (s < ru.x || (int)(s - ru.x) >= ru.y) return;
     const int v = g.col[s];
-    if (v <= u || v >= g.n) return;  // the value lives at the slot whose neighbour id exceeds the row id
-    const int dv = g.rowinfo[v].y;
+    const uint4 a = rec[s];  // from u's side: statistics over N(v) \ N(u) \ {u}
+    const bool uok = u >= 0 && u < g.n, vok = v >= 0 && v < g.n;
+    const int64_t r = (int64_t)a.w;
+    const bool rok = r >= 0 && r < g.cap_total;
+    const int2 ru = g.rowinfo[uok ? u : 0];
+    const int dv = g.rowinfo[vok ? v : 0].y;
+    const int rcol = g.col[rok ? r : 0], rrow = g.slot_row[rok ? r : 0];
+    const uint4 b = rec[rok ? r : 0];  // from v's side: statistics over N(u) \ N(v) \ {v}
+    if (!uok) return;
+    if (s < ru.x || (int)(s - ru.x) >= ru.y) return;
+    if (v <= u || !vok) return;  // the value lives at the slot whose neighbour id exceeds the row id
     if ((ru.y < dv ? ru.y : dv) == 1) {  // bfc_naive.py:18-19
         curv[s] = 0.0;
         return;
     }
-    const uint4 a = rec[s];  // from u's side: statistics over N(v) \ N(u) \ {u}
-    const int64_t r = (int64_t)a.w;
-    if (r < 0 || r >= g.cap_total || g.col[r] != u || g.slot_row[r] != v) {
+    if (!rok || rcol != u || rrow != v) {
         row_ok(g, make_int2(-1, (int)a.w), 39, u, v);
         return;
     }
-    const uint4 b = rec[r];  // from v's side: statistics over N(u) \ N(v) \ {v}
     if (a.z != b.z) {        // both sides count the same triangles
         row_ok(g, make_int2(-1, (int)a.z), 40, u, v);
         return;
