@@ -1,5 +1,6 @@
 """GPU-box checker: a long SDRF run on the north-star graph, full recompute against the incremental pass, final edge lists
-compared; then the final graph's full pass against the C oracle on sampled edges.  tests/test_checkers_gpu.py runs it with
+compared, and compared again with the list of a run whose draws are all made on the host; then the final graph's full pass
+against the C oracle on sampled edges.  tests/test_checkers_gpu.py runs it with
 200 iterations; the long version: ITERS=3000 python tests/check_soak.py"""
 import os, sys, time
 import numpy as np
@@ -30,6 +31,21 @@ def run(iters=3000, samples=20000):
             run.G.curvature_pass('bfc')
             eu, ev, cv = run.G.curvature_read()
     assert np.array_equal(out[False], out[True]), 'edge lists differ'
+    # the same run once more with every draw on the host (numpy's own exp, sum and cumsum on the downloaded improvements):
+    # the device-side draw must have picked numpy's index in every one of the iterations above, at ~190k candidates each
+    os.environ['DCR_DEVICE_DRAW'] = '0'
+    try:
+        np.random.seed(0)
+        run_h = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0)
+    finally:
+        os.environ.pop('DCR_DEVICE_DRAW', None)
+    t = time.time()
+    for _ in range(done):
+        if not run_h.step():
+            break
+    print(f'host draws: {done} iterations in {time.time() - t:.1f} s; device draws of the first run: {run.device_draws} '
+          f'(undecided, redone on the host: {run.host_draws})', flush=True)
+    assert np.array_equal(run_h.result().edge_index.numpy(), out[True]), 'device-side draws and host draws diverge'
     C = c_oracle.CGraph(out[True], n)
     rng = np.random.Generator(np.random.PCG64(1))
     pick = rng.choice(eu.shape[0], size=min(samples, eu.shape[0]), replace=False)
