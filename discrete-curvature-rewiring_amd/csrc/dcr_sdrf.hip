@@ -714,6 +714,44 @@ __global__ void k_pick_candidate(const int32_t *ci, const int32_t *cj, int64_t i
 // exact path (numpy's own exp and sums) for this iteration.
 constexpr int DRAW_BLOCKS = 256;
 
+// tau = +inf: softmax is one-hot at the first arg-max of the improvements (utils/softmax.py:5-8), so the index np.random.choice
+// returns is that arg-max whatever the uniform (which it still consumes: the caller has taken it).  Candidate count from the
+// result block: nothing here needs a host value.
+__global__ void __launch_bounds__(256) k_argmax_array_dev(const double *a, const DevResult *res, Ext *partial) {
+    __shared__ Ext sh[4];
+    const int64_t n = res->n_cand;
+    Ext best;
+    best.val = 0.0;
+    best.slot = -1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        Ext c;
+        c.val = a[i];
+        c.slot = (int32_t)i;
+        best = ext_better(best, c, 1);
+    }
+    best = ext_block_reduce(best, 1, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+
+__global__ void k_draw_from_argmax(const int32_t *ci, const int32_t *cj, DevResult *res) {
+    const int64_t n = res->n_cand, idx = res->imp_argmax;
+    if (n <= 0) {
+        res->draw_status = 2;
+        res->draw_idx = -1;
+        return;
+    }
+    if (idx < 0 || idx >= n) {  // (not a number anywhere: the host path decides what numpy does with it)
+        res->draw_status = 1;
+        res->draw_idx = -1;
+        return;
+    }
+    const int32_t a = ci[idx], b = cj[idx];
+    res->cand_i = a < b ? a : b;
+    res->cand_j = a < b ? b : a;
+    res->draw_idx = idx;
+    res->draw_status = 0;
+}
+
 __global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__ imp, const DevResult *res, double tau,
                                                        double *__restrict__ bsum) {
     __shared__ double red[256];
@@ -1193,8 +1231,9 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
     if (!g || !out_status || !out_n_cand) DCR_FAIL(DCR_EINVAL, "null argument");
     if (x < 0 || y < 0 || x >= g->n || y >= g->n || x == y) DCR_FAIL(DCR_EINVAL, "bad node ids");
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
-    if (!(tau == tau) || tau > 1.7e308 || tau < -1.7e308 || !(uniform >= 0.0 && uniform < 1.0))
-        DCR_FAIL(DCR_EINVAL, "device draw: finite tau and a uniform in [0, 1) expected");
+    const bool tau_inf = tau > 1.7e308;  // +inf: the first arg-max
+    if (!(tau == tau) || tau < -1.7e308 || !(uniform >= 0.0 && uniform < 1.0))
+        DCR_FAIL(DCR_EINVAL, "device draw: tau finite or +inf and a uniform in [0, 1) expected");
     if (do_remove && !g->curv_valid) DCR_FAIL(DCR_ESTATE, "removal needs a curvature pass first");
     DCR_HIP(hipSetDevice(g->device));
     // the stale arg-max of the removal step does not depend on the edge about to be drawn (see dcr_improvements), nor on the
@@ -1212,11 +1251,23 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
         DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[0], 0));
         g->amax_valid = true;
     }
-    hipLaunchKernelGGL(k_draw_partial, dim3(DRAW_BLOCKS), dim3(256), 0, g->stream, g->imp_out, g->dres, tau, g->draw_bsum);
     // (DCR_DRAW_MARGIN_SCALE widens the margin: the tests use it to send draws down the undecided path)
     const double margin_scale = getenv("DCR_DRAW_MARGIN_SCALE") ? atof(getenv("DCR_DRAW_MARGIN_SCALE")) : 1.0;
-    hipLaunchKernelGGL(k_draw_pick, dim3(1), dim3(256), 0, g->stream, g->imp_out, g->imp_ci, g->imp_cj, g->dres, tau, uniform,
-                       g->draw_bsum, margin_scale >= 1.0 ? margin_scale : 1.0);
+    if (tau_inf && margin_scale <= 1.0) {
+        if (!g->red_scratch) {
+            Ext *p = nullptr;
+            DCR_TRY(dev_alloc(&p, ARGEXT_BLOCKS));
+            g->red_scratch = p;
+        }
+        // (red_scratch is free again: the stale arg-max beside the pipeline has been joined above)
+        hipLaunchKernelGGL(k_argmax_array_dev, dim3(256), dim3(256), 0, g->stream, g->imp_out, g->dres, (Ext *)g->red_scratch);
+        hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, (const Ext *)g->red_scratch, 256, g->dres);
+        hipLaunchKernelGGL(k_draw_from_argmax, dim3(1), dim3(1), 0, g->stream, g->imp_ci, g->imp_cj, g->dres);
+    } else {
+        hipLaunchKernelGGL(k_draw_partial, dim3(DRAW_BLOCKS), dim3(256), 0, g->stream, g->imp_out, g->dres, tau, g->draw_bsum);
+        hipLaunchKernelGGL(k_draw_pick, dim3(1), dim3(256), 0, g->stream, g->imp_out, g->imp_ci, g->imp_cj, g->dres, tau, uniform,
+                           g->draw_bsum, margin_scale >= 1.0 ? margin_scale : 1.0);
+    }
     // A host round trip here, without any transfer or host arithmetic: enqueuing the tail and the pass behind a stream that
     // is still working through the small kernels above cost 0.2 ms per iteration more than enqueuing them on an idle one
     // (measured, interleaved in one run: 1.89 against 1.59 ms), and the draw's verdict comes over with it, so an undecided

@@ -219,7 +219,7 @@ class SdrfRun:
                 raise ValueError('min() arg is an empty sequence')  # what the reference's min() raises
         rec = {'argmin': [x, y]} if want_trace else None
 
-        if self.device_draw and more and not want_trace and np.isfinite(tau):
+        if self.device_draw and more and not want_trace and (np.isfinite(tau) or tau == float('inf')):
             # The whole iteration without bringing the improvements to the host: the uniform np.random.choice would take is
             # taken here and the draw itself runs on the device (dcr_sdrf_iteration_device_draw), accepted only when it is
             # certain to be numpy's index.  Otherwise nothing was edited: the uniform goes back into the stream and the

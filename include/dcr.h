@@ -135,7 +135,7 @@ int dcr_sdrf_tail_at_pass_argmin(dcr_graph *g, int64_t cand_index, int do_remove
                                  int incremental, int32_t out_added[2], int32_t out_removed[2], int32_t *out_u, int32_t *out_v,
                                  double *out_val);
 
-/* One whole loop iteration for finite tau (sdrf_no_cuda.py:29-66 for the edge (x, y) the previous call returned, then :24,:27 of
+/* One whole loop iteration for finite tau or tau = +inf (then the draw is the first arg-max, utils/softmax.py:5-8) (sdrf_no_cuda.py:29-66 for the edge (x, y) the previous call returned, then :24,:27 of
  * the next iteration) with the improvements staying on the device (two host round trips of the 1 KB result block; no
  * transfer of the improvements, no host arithmetic).  The draw np.random.choice(n, p=softmax(improvements, tau)) (:49-50) runs
  * on the device from `uniform`, the one double the caller has taken from numpy's global stream: the index is the first i whose

@@ -830,7 +830,7 @@ def test_device_side_draw_is_numpys_draw(dcr, oracle, monkeypatch, incremental):
     import torch
     ei, n = synthetic.powerlaw_graph(400, 4, seed=21)
     loops = 120
-    for tau in (163.0, 0.7):
+    for tau in (163.0, 0.7, float('inf')):   # (inf: the first arg-max, utils/softmax.py:5-8; the uniform is still consumed)
         np.random.seed(11)
         want = oracle.sdrf(ei, n, 'bfc', loops, True, 0.8, tau, nthreads=4)
         want_next = np.random.random_sample()
