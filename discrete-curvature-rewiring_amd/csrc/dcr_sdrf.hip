@@ -104,24 +104,25 @@ __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_tot
         int u[4], v[4];
         int2 ru[4];
         bool ok[4];
+        double cv[4];
+        // everything addressed by the slot itself in one round (owner row, neighbour, value: all in bounds for every slot,
+        // slack included), the row extent in a second one
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t s = s0 + q * stride;
             ok[q] = s < cap_total;
             u[q] = ok[q] ? g.slot_row[s] : 0;
+            v[q] = ok[q] ? g.col[s] : -1;
+            cv[q] = ok[q] ? curv[s] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t s = s0 + q * stride;
-            ru[q] = ok[q] ? g.rowinfo[u[q]] : make_int2(0, 0);
-            v[q] = ok[q] ? g.col[s] : -1;
-        }
+        for (int q = 0; q < 4; ++q) ru[q] = ok[q] ? g.rowinfo[u[q]] : make_int2(0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t s = s0 + q * stride;
             if (!ok[q] || (int)(s - ru[q].x) >= ru[q].y || v[q] <= u[q] || (u[q] == excl_u && v[q] == excl_v)) continue;
             Ext c;
-            c.val = curv[s];
+            c.val = cv[q];
             c.slot = (int32_t)s;
             best = ext_better(best, c, want_max);
         }
