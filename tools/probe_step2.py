@@ -11,7 +11,7 @@ from rewiring import sdrf_no_cuda as S
 ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
 inc = os.environ.get('INC', '0') == '1'
 np.random.seed(0)
-run = S.SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0, incremental=inc)
+run = S.SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, float(os.environ.get('TAU', '163')), incremental=inc)
 for _ in range(10):
     run.step()
 variants = {'host': (False, None, '0'), 'device': (True, None, '0')}
