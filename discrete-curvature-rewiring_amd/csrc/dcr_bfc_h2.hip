@@ -798,6 +798,7 @@ struct H2Tasks {
     int4 *cand;    // {w, M_u(w) - 1, task, unused}
     int32_t *part;
     int64_t task_cap, cand_cap, part_cap;
+    int32_t *n_task, *n_cand, *n_part, *n_done;  // this pool's counters in the result block
     DevResult *res;
     const int32_t *weight;  // bit 31: the node went to the retry list (what its first attempt listed is void)
     unsigned retry_flag;    // 0x80000000 in the retry launch
@@ -827,18 +828,18 @@ __device__ inline bool h2_pool_reserve(const H2Tasks tk, H2Alloc &al, int nt, in
     if (al.t_end - al.t_cur < nt) {
         h2_void_tasks(tk, al.t_cur, al.t_end);
         const int n = nt > H2_CHUNK_T ? nt : H2_CHUNK_T;
-        al.t_cur = h2_pool_grab(&tk.res->h2_ntask, n);
+        al.t_cur = h2_pool_grab(tk.n_task, n);
         al.t_end = al.t_cur + n;
     }
     if (al.c_end - al.c_cur < nc) {
         h2_void_candidates(tk, al.c_cur, al.c_end);
         const int n = nc > H2_CHUNK_C ? nc : H2_CHUNK_C;
-        al.c_cur = h2_pool_grab(&tk.res->h2_ncand, n);
+        al.c_cur = h2_pool_grab(tk.n_cand, n);
         al.c_end = al.c_cur + n;
     }
     if (al.p_end - al.p_cur < np) {
         const int n = np > H2_CHUNK_P ? np : H2_CHUNK_P;
-        al.p_cur = h2_pool_grab(&tk.res->h2_npart, n);
+        al.p_cur = h2_pool_grab(tk.n_part, n);
         al.p_end = al.p_cur + n;
     }
     t0 = al.t_cur;
@@ -950,7 +951,7 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Ta
                 const int nc = __popcll(mC);
                 if (al.c_end - al.c_cur < nc) {
                     h2_void_candidates(tk, al.c_cur, al.c_end);
-                    al.c_cur = h2_pool_grab(&tk.res->h2_ncand, H2_CHUNK_C);
+                    al.c_cur = h2_pool_grab(tk.n_cand, H2_CHUNK_C);
                     al.c_end = al.c_cur + H2_CHUNK_C;
                 }
                 const int c0 = al.c_cur;
@@ -1433,11 +1434,11 @@ __device__ inline int h2_probe_partners(const H2EdgeSet es, int w, const int32_t
 // Launched twice: `second` = 0 as soon as the block classes have finished (beside the wave classes, which list nothing),
 // for the candidates there are then; `second` = 1 after the retry launch for what that one listed.  (The split is read
 // from / left in the result block: h2_ncand_done is only written by the kernel that marks the first launch's end.)
-__global__ void k_h2_triangles_mark(DevResult *res) { res->h2_ncand_done = res->h2_ncand; }
+__global__ void k_h2_triangles_mark(H2Tasks tk) { *tk.n_done = *tk.n_cand; }
 __global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status, int second) {
     if (*status != 0) return;
-    const int first = second ? tk.res->h2_ncand_done : 0;
-    const int total = second ? tk.res->h2_ncand : tk.res->h2_ncand_done;
+    const int first = second ? *tk.n_done : 0;
+    const int total = second ? *tk.n_cand : *tk.n_done;
     if (total <= first || first < 0 || total > tk.cand_cap) return;  // (beyond the pool: the pass is run again with larger pools)
     const int lane = threadIdx.x & 63;
     for (int64_t base = first + (((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll); base < total; base += (int64_t)gridDim.x * 256) {
@@ -1618,9 +1619,7 @@ __global__ void k_h2_clear(DevResult *res) {
     if (threadIdx.x == 0) {
         res->h2_status = 0;
         res->h2_retry = 0;
-        res->h2_ntask = 0;
-        res->h2_ncand = 0;
-        res->h2_npart = 0;
+        for (int p = 0; p < 2; ++p) res->h2_ntask[p] = res->h2_ncand[p] = res->h2_npart[p] = res->h2_ncand_done[p] = 0;
         for (int c = 0; c < 6; ++c) res->h2_failed[c] = 0;
         res->flag_too_big = 0;
     }
@@ -1679,7 +1678,9 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
 // ---- host side ---------------------------------------------------------------------------------------------------------
 // the pools of the triangle step were too small for the last pass: remember what it asked for (the counters kept counting)
 bool h2_grow_pools(dcr_graph *g) {
-    const int64_t t = g->hres->h2_ntask, c = g->hres->h2_ncand, p = g->hres->h2_npart;
+    const DevResult &h = *g->hres;  // (per pool; both pools have the same size)
+    const int64_t t = std::max(h.h2_ntask[0], h.h2_ntask[1]), c = std::max(h.h2_ncand[0], h.h2_ncand[1]), p = std::max(h.h2_npart[0], h.h2_npart[1]);
+    if (h.h2_ntask[0] < 0 || h.h2_ntask[1] < 0 || h.h2_ncand[0] < 0 || h.h2_ncand[1] < 0 || h.h2_npart[0] < 0 || h.h2_npart[1] < 0) return false;
     if (t < 0 || c < 0 || p < 0) return false;  // the 31-bit counters wrapped: not a case for this engine
     // (a pass that ran out of one pool stopped listing into the others too: ask for twice what it counted)
     g->h2_want[0] = std::max<int64_t>(g->h2_want[0], 2 * t + 4096);
@@ -1726,9 +1727,10 @@ static int ensure_h2(dcr_graph *g) {
     // triangle step pools: tasks are edges (with the partitions of split nodes: a few times that), candidates and partners
     // adjacency entries of theirs
     // (sized for power-law graphs; a pass that needs more says how much — h2_grow_pools — and is run again)
-    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, std::max<int64_t>(g->cap_total + 4096, g->h2_want[0])));
-    DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, std::max<int64_t>(2 * g->cap_total + 65536, g->h2_want[1])));
-    DCR_TRY(dev_regrow(&g->h2_part, &g->h2_part_cap, std::max<int64_t>(g->cap_total + 65536, g->h2_want[2])));
+    // (two pools of each kind, h2_*_cap counts both: see DevResult)
+    DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, 2 * std::max<int64_t>(g->cap_total + 4096, g->h2_want[0])));
+    DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, 2 * std::max<int64_t>(2 * g->cap_total + 65536, g->h2_want[1])));
+    DCR_TRY(dev_regrow(&g->h2_part, &g->h2_part_cap, 2 * std::max<int64_t>(g->cap_total + 65536, g->h2_want[2])));
     return DCR_OK;
 }
 
@@ -1777,7 +1779,12 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     }
     int32_t *status = &g->dres->h2_status;
     const H2Retry rt{g->h2_retry, g->h2_retry_cap, g->h2_weight, g->dres};
-    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, g->h2_task_cap, g->h2_cand_cap, g->h2_part_cap, g->dres, g->h2_weight, 0u};
+    const int64_t tcap = g->h2_task_cap / 2, ccap = g->h2_cand_cap / 2, pcap = g->h2_part_cap / 2;
+    DevResult *dr = g->dres;
+    H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, tcap, ccap, pcap, &dr->h2_ntask[0], &dr->h2_ncand[0], &dr->h2_npart[0],
+               &dr->h2_ncand_done[0], g->dres, g->h2_weight, 0u};  // pool 0: the split class and the retry launch
+    const H2Tasks tkM{g->h2_task + tcap, g->h2_cand + ccap, g->h2_part + pcap, tcap, ccap, pcap, &dr->h2_ntask[1], &dr->h2_ncand[1],
+                      &dr->h2_npart[1], &dr->h2_ncand_done[1], g->dres, g->h2_weight, 0u};  // pool 1: class M
     hipLaunchKernelGGL(k_h2_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
     const int64_t sblocks = (g->cap_total + 255) / 256;
@@ -1815,7 +1822,7 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     const int64_t hint3 = g->h2_last_count[3] >= 0 ? (int64_t)g->h2_last_count[3] + 8 : 3 * (int64_t)g->num_cu;
     launch_h2_block<4, true>(g, vw, tk, rt, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4], hint4, 0, sL);
     if (!serial) DCR_HIP(hipStreamWaitEvent(sM, g->ev_fork, 0));
-    launch_h2_block<3, false>(g, vw, tk, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, sM);
+    launch_h2_block<3, false>(g, vw, tkM, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, sM);
     if (!serial) DCR_HIP(hipStreamWaitEvent(sS2, g->ev_fork, 0));
     launch_h2_small<2>(g, vw, rt, sS2);
     if (!serial) DCR_HIP(hipStreamWaitEvent(sS1, g->ev_fork, 0));
@@ -1835,11 +1842,14 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         DCR_HIP(hipEventRecord(g->ev_join[0], sL));
         DCR_HIP(hipEventRecord(g->ev_join[1], sM));
         DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[0], 0));
-        DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[1], 0));
         DCR_HIP(hipStreamWaitEvent(sT, g->ev_aux, 0));
     }
-    hipLaunchKernelGGL(k_h2_triangles_mark, dim3(1), dim3(1), 0, sT, g->dres);
-    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sT, es, tk, g->h2_rec, status, 0);
+    // the split class's candidates as soon as IT is done (beside class M and the wave classes), class M's when M is
+    hipLaunchKernelGGL(k_h2_triangles_mark, dim3(1), dim3(1), 0, sT, tk);
+    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 4)), dim3(256), 0, sT, es, tk, g->h2_rec, status, 0);
+    if (!serial) DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[1], 0));
+    hipLaunchKernelGGL(k_h2_triangles_mark, dim3(1), dim3(1), 0, sT, tkM);
+    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sT, es, tkM, g->h2_rec, status, 0);
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_join[3], sT));
         DCR_HIP(hipEventRecord(g->ev_join[2], sS0));
@@ -1879,8 +1889,9 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         fprintf(stderr, "[h2] units per class %d %d %d %d %d, retry units %d, status %d, failed per class %d %d %d %d %d retry %d\n",
                 h.h2_count[0], h.h2_count[1], h.h2_count[2], h.h2_count[3], h.h2_count[4], h.h2_retry, h.h2_status, h.h2_failed[0],
                 h.h2_failed[1], h.h2_failed[2], h.h2_failed[3], h.h2_failed[4], h.h2_failed[5]);
-        fprintf(stderr, "[h2] triangle step: %d tasks, %d candidates, %d partners (pool slots, chunk tails included; pools %lld %lld %lld)\n",
-                h.h2_ntask, h.h2_ncand, h.h2_npart, (long long)g->h2_task_cap, (long long)g->h2_cand_cap, (long long)g->h2_part_cap);
+        fprintf(stderr, "[h2] triangle step: split class + retry %d tasks, %d candidates, %d partners; class M %d, %d, %d (pool slots, chunk tails "
+                "included; pools of %lld %lld %lld each)\n", h.h2_ntask[0], h.h2_ncand[0], h.h2_npart[0], h.h2_ntask[1], h.h2_ncand[1], h.h2_npart[1],
+                (long long)g->h2_task_cap / 2, (long long)g->h2_cand_cap / 2, (long long)g->h2_part_cap / 2);
     }
     return DCR_OK;
 }

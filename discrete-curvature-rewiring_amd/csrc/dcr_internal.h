@@ -76,8 +76,11 @@ struct DevResult {
     int32_t h2_fill[24];
     int32_t h2_count[5];
     int32_t h2_failed[6];  // diagnostic: nodes whose tables filled up, per class (5: on the retry list itself)
-    int32_t h2_ntask, h2_ncand, h2_npart;  // triangle step: listed edges, candidates, partners
-    int32_t h2_ncand_done;                 // candidates the first k_h2_triangles launch has taken
+    // triangle step, one pool per block class (0: the split class and the retry launch, 1: class M), so that the candidates of
+    // a class can be taken as soon as THAT class is done: listed edges, candidates, partners; candidates the first
+    // k_h2_triangles launch of the pool has taken
+    int32_t h2_ntask[2], h2_ncand[2], h2_npart[2];
+    int32_t h2_ncand_done[2];
     int32_t h2_retry;   // units on the retry list (nodes whose tables filled up in their class, redone by the largest class)
     int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels)
 };

@@ -117,8 +117,10 @@ class CGraph:
         eu = np.ascontiguousarray(eu, dtype=np.int32)
         ev = np.ascontiguousarray(ev, dtype=np.int32)
         out = np.empty(eu.shape[0], dtype=np.float64)
-        lib().dcro_curv_edges(self.h, CURV[curv_type], nthreads, eu.shape[0], _p(eu, _i32p), _p(ev, _i32p),
-                              _p(out, _f64p))
+        rc = lib().dcro_curv_edges(self.h, CURV[curv_type], nthreads, eu.shape[0], _p(eu, _i32p), _p(ev, _i32p),
+                                   _p(out, _f64p))
+        if rc != 0:
+            raise MemoryError(f'dcro_curv_edges failed ({rc})')
         return out
 
     def curv_all(self, curv_type='bfc', nthreads=1):

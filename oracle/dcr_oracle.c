@@ -24,9 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#ifdef _OPENMP
-#include <omp.h>
-#endif
+#include <pthread.h>
 
 typedef struct {
     int32_t *nbr;
@@ -165,8 +163,15 @@ int dcro_edges(const dcro_graph *g, int32_t *eu, int32_t *ev) {
 
 static scratch_t *scratch_new(int64_t n) {
     scratch_t *s = (scratch_t *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
     s->m1 = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
     s->m2 = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    if (!s->m1 || !s->m2) {
+        free(s->m1);
+        free(s->m2);
+        free(s);
+        return NULL;
+    }
     s->stamp = 0;
     return s;
 }
@@ -261,17 +266,45 @@ int dcro_curv_edge(const dcro_graph *g, int32_t u, int32_t v, int ct, double *ou
     return 0;
 }
 
-/* Curvature of the listed edges (any subset, any order). */
+/* Curvature of the listed edges (any subset, any order).  Plain pthreads, chunks of 64 edges handed out through an atomic
+ * cursor: no OpenMP runtime of this library's own inside a process that already hosts torch's. */
+typedef struct {
+    const dcro_graph *g;
+    int ct;
+    int64_t ne;
+    const int32_t *eu, *ev;
+    double *out;
+    int64_t *cursor;
+} edges_job_t;
+
+static void *edges_worker(void *arg) {
+    edges_job_t *j = (edges_job_t *)arg;
+    scratch_t *s = scratch_new(j->g->n);
+    if (!s) return NULL;
+    for (;;) {
+        const int64_t e0 = __atomic_fetch_add(j->cursor, 64, __ATOMIC_RELAXED);
+        if (e0 >= j->ne) break;
+        const int64_t e1 = e0 + 64 < j->ne ? e0 + 64 : j->ne;
+        for (int64_t e = e0; e < e1; ++e) j->out[e] = curv_edge(j->g, j->eu[e], j->ev[e], j->ct, s);
+    }
+    scratch_free(s);
+    return NULL;
+}
+
 int dcro_curv_edges(const dcro_graph *g, int ct, int nthreads, int64_t ne, const int32_t *eu, const int32_t *ev,
                     double *out) {
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel num_threads(nthreads)
-    {
-        scratch_t *s = scratch_new(g->n);
-#pragma omp for schedule(dynamic, 64)
-        for (int64_t e = 0; e < ne; ++e) out[e] = curv_edge(g, eu[e], ev[e], ct, s);
-        scratch_free(s);
-    }
+    if (nthreads > 256) nthreads = 256;
+    int64_t cursor = 0;
+    edges_job_t job = {g, ct, ne, eu, ev, out, &cursor};
+    pthread_t th[256];
+    int started = 0;
+    for (int t = 1; t < nthreads && (int64_t)t * 64 < ne; ++t)
+        if (pthread_create(&th[started], NULL, edges_worker, &job) == 0) ++started;
+    edges_worker(&job); /* the calling thread works too (and alone if no thread could be started) */
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    /* a worker that could not get its scratch leaves its chunks to the others; if none could, nothing was written */
+    if (cursor < ne) return -2;
     return 0;
 }
 
