@@ -1346,8 +1346,10 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
 }
 
 // RETRY: the units come from the retry list (whose tables must not fill up again: the pass falls back then)
+// (at least three waves per SIMD: class M's fast path wanted 232 registers, i.e. two of its 4-wave workgroups per CU where its
+//  LDS lets three live; at 168 registers and 136 bytes of spills the pass is 2.6 % faster on S100k, 4.3 % on S1M)
 template <int L1, int EXS, int NW, bool PARTS>
-__global__ void __launch_bounds__(64 * NW) k_h2_block(View g, H2Tasks tk, const int4 *units, const int32_t *count, int64_t unit_cap,
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) k_h2_block(View g, H2Tasks tk, const int4 *units, const int32_t *count, int64_t unit_cap,
                                                        uint4 *rec, H2Retry rt, int is_retry) {
     __shared__ __attribute__((aligned(16))) unsigned bits[(1 << L1) / 32 + (1 << (L1 - 2)) / 32];
     __shared__ __attribute__((aligned(16))) unsigned key[EXS];
