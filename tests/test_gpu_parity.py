@@ -855,3 +855,26 @@ def test_device_side_draw_is_numpys_draw(dcr, oracle, monkeypatch, incremental):
                 assert run.device_draws == 0 and run.host_draws >= done - 1
             else:
                 assert run.device_draws == run.host_draws == 0
+
+
+def test_device_draw_without_candidates_leaves_numpys_stream_alone(oracle):
+    """Complete and nearly complete graphs: the arg-min edge has no admissible candidate in some iterations, so
+    np.random.choice is never called there (sdrf_no_cuda.py:47-50) — the device-draw path has taken a uniform by then and
+    must put it back (status 2).  Edge lists and the state of numpy's stream against the oracle's loop, untraced."""
+    from dcr.data import Data
+    from rewiring.sdrf_no_cuda import SdrfRun
+    import torch
+    k6 = np.array([[a, b] for a in range(6) for b in range(6) if a != b]).T.copy()
+    almost = k6[:, ~(((k6[0] == 0) & (k6[1] == 5)) | ((k6[0] == 5) & (k6[1] == 0)))].copy()
+    for ei, n in ((k6, 6), (almost, 6)):
+        for remove, bound, tau in ((True, 0.2, 3.0), (True, 5.0, 50.0), (False, 0.5, 1.0)):
+            np.random.seed(21)
+            want = oracle.sdrf(ei, n, 'bfc', 12, remove, bound, tau, nthreads=1)
+            want_next = np.random.random_sample()
+            np.random.seed(21)
+            run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', remove, bound, tau)
+            for i in range(12):
+                if not run.step(more=i + 1 < 12):
+                    break
+            assert np.array_equal(run.result().edge_index.numpy(), want), (n, remove, bound, tau)
+            assert np.random.random_sample() == want_next, (n, remove, bound, tau)
