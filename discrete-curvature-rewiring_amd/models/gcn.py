@@ -199,11 +199,36 @@ class RowSelection:
     columns: the gradient of the loss is zero outside them, so dZ = Âᵀ·dOut needs the selected columns only."""
 
     def __init__(self, csr, rows):
-        idx = rows.nonzero().squeeze(1) if rows.dtype == torch.bool else rows
-        self.idx = idx.to(torch.int64).contiguous()
+        # ``expand``: None, or the positions in ``idx`` of the caller's entries when its index tensor repeats a node:
+        # the kernels (and ``transposed``, whose column map holds one position per node) then work on the distinct nodes and
+        # the callers gather ``out.index_select(0, expand)``, whose backward ADDS the gradients of the repeats — what
+        # ``model(data)[rows].backward()`` does.  Checked once per selection (one host sync; selections are cached).
+        self.expand = None
+        if rows.dtype == torch.bool:
+            if rows.dim() != 1 or rows.numel() != csr.n_rows:
+                raise IndexError(f'row mask of shape {tuple(rows.shape)} for {csr.n_rows} nodes')
+            idx = rows.nonzero().squeeze(1)
+        else:
+            if rows.dim() != 1 or rows.dtype not in (torch.int64, torch.int32):
+                raise IndexError('rows must be a boolean node mask or a 1-d int64 / int32 index tensor')
+            idx = rows.to(torch.int64)
+            if idx.numel():
+                lo, hi = int(idx.min()), int(idx.max())
+                if lo < -csr.n_rows or hi >= csr.n_rows:
+                    raise IndexError(f'row index out of range for {csr.n_rows} nodes: [{lo}, {hi}]')
+                if lo < 0:
+                    idx = torch.where(idx < 0, idx + csr.n_rows, idx)     # as tensor indexing reads them
+                uniq, inverse = torch.unique(idx, return_inverse=True)
+                if uniq.numel() != idx.numel():
+                    idx, self.expand = uniq, inverse.contiguous()
+        self.idx = idx.contiguous()
         self.n = int(self.idx.numel())
         self._csr = csr
         self._t = None
+
+    def expanded(self, out):
+        """``out`` (one row per distinct selected node) in the caller's index order, repeats included."""
+        return out if self.expand is None else out.index_select(0, self.expand)
 
     def joined_with(self, other):
         """[idx | other.idx] as one tensor (the row list of ``dcr_spmm_csr_rows2_f32_dev``); built once per pair."""
@@ -657,7 +682,8 @@ class GCN(torch.nn.Module):
             else:
                 _, z = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
             if rows is not None and conv is layers[-1]:
-                h = aggregate_rows(z, conv.bias, csr, conv.row_selection(rows, csr))
+                sel = conv.row_selection(rows, csr)
+                h = sel.expanded(aggregate_rows(z, conv.bias, csr, sel))
             else:
                 h = aggregate(z, conv.bias, csr)
         return torch.nn.functional.log_softmax(h, dim=1)
@@ -684,8 +710,9 @@ class GCN(torch.nn.Module):
                 _, z_ev = act_then_linear(o_ev, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
             csr = conv.norm_csr(data.edge_index, data.edge_attr, o_tr.shape[0])
             if rows_train is not None and depth == last:
-                o_tr, o_ev = _AggregateRowsPair.apply(z_tr, z_ev, conv.bias, csr, conv.row_selection(rows_train, csr),
-                                                      conv.row_selection(rows_eval, csr))
+                sel_tr, sel_ev = conv.row_selection(rows_train, csr), conv.row_selection(rows_eval, csr)
+                o_tr, o_ev = _AggregateRowsPair.apply(z_tr, z_ev, conv.bias, csr, sel_tr, sel_ev)
+                o_tr, o_ev = sel_tr.expanded(o_tr), sel_ev.expanded(o_ev)
             else:
                 o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, conv.bias, csr)
         if rows_train is not None and last == 0:

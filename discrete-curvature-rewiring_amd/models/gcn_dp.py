@@ -190,7 +190,10 @@ class ShardedGCN(torch.nn.Module):
             cache = self._rowsel = {}
         key = (idx.data_ptr(), idx._version, tuple(idx.shape))
         if key not in cache:
-            cache[key] = (RowSelection(self.csr, idx), idx)
+            sel = RowSelection(self.csr, idx)
+            if sel.expand is not None:   # (the local selections come from split masks; a repeated node is a caller's mistake)
+                raise ValueError('row selection of the data-parallel model repeats a node')
+            cache[key] = (sel, idx)
         return cache[key][0]
 
     def forward(self, x_local, rows=None):

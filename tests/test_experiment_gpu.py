@@ -283,6 +283,36 @@ def test_row_selected_forward_is_the_indexed_full_forward():
         assert torch.allclose(a, p.grad, rtol=1e-4, atol=1e-7), (a - p.grad).abs().max()
 
 
+def test_row_selection_with_repeated_and_negative_indices():
+    """An index tensor that names a node twice (or from the end): ``model(data, rows=idx)`` still equals
+    ``model(data)[idx]`` row for row AND its backward adds the repeats' gradients as indexing does (round-3 advisor: the
+    column map of the restricted transpose keeps one position per node and silently dropped the others); out-of-range
+    indices raise like indexing does."""
+    model, _, data = _gcn_case(0.0)
+    n = data.num_nodes
+    base = data.train_mask.nonzero().squeeze(1)[:40]
+    idx = torch.cat([base, base[:7], base[3:5], torch.tensor([-1, -n, n - 1], device=base.device)]).contiguous()
+    for mode in ('train', 'eval'):
+        model.train(mode == 'train')
+        with torch.no_grad():
+            assert torch.equal(model(data, rows=idx), model(data)[idx])
+    model.train()
+    w = torch.randn(idx.numel(), data.y.max().item() + 1, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3))
+    model.zero_grad()
+    (model(data, rows=idx) * w).sum().backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    (model(data)[idx] * w).sum().backward()
+    for a, p in zip(got, model.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-4, atol=1e-6), (a - p.grad).abs().max()
+    lp_tr, lp_ev = model.forward_pair(data, rows_train=idx, rows_eval=idx)
+    f_tr, f_ev = model.forward_pair(data)
+    assert torch.equal(lp_tr, f_tr[idx]) and torch.equal(lp_ev, f_ev[idx])
+    for bad in (torch.tensor([0, n], device='cuda'), torch.tensor([-n - 1], device='cuda')):
+        with pytest.raises(IndexError):
+            model(data, rows=bad)
+
+
 def test_epochs_on_selected_rows_follow_the_full_output_epochs(monkeypatch):
     """Twelve epochs with the last aggregation evaluated at the split rows against twelve epochs on the full output
     (DCR_GCN_ALL_ROWS=1): the same accuracies, weights equal to rounding."""
