@@ -113,8 +113,10 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     torch.manual_seed(0)
     data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=train_mask, val_mask=val_mask)
     model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
-    opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                            {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True, fused=True)
+    from experiment.save_models import make_adam
+    fused_adam = os.environ.get('DCR_FUSED_ADAM', '1') == '1'   # (the experiment drivers default to the stock implementation)
+    opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                     {'params': model.reg_params, 'weight_decay': 5e-4}], 0.01, dev, fused=fused_adam)
 
     def sync():
         if dist is not None:
@@ -169,6 +171,8 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     res['epoch_floor_frac'] = floor_ms / res['ms_per_epoch']
     res['epoch_floor_definition'] = ('layer-1 forward + weight-gradient contractions (2 x 2 N F H flop) at 157.3 TFLOP/s f32 MFMA, plus '
                                      'the bytes of the fused activation kernels and of the row-selected aggregations at 8 TB/s')
+    res['adam'] = ('torch fused (one kernel per group; DCR_FUSED_ADAM=0: stock foreach implementation, the experiment drivers\' default)'
+                   if getattr(opt, 'defaults', {}).get('fused') else 'torch stock (foreach), capturable')
     res['last_aggregation'] = ('evaluated at the rows the epoch reads (training rows for the loss, validation rows for the accuracy: '
                                f'{n_tr} + {n_va} of {n}); DCR_GCN_ALL_ROWS=1 computes every row')
     if dist is None and not args.no_cpu_baseline:   # the same epoch with every row of the last aggregation, for comparison
@@ -176,8 +180,8 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
         try:
             torch.manual_seed(0)
             model2 = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
-            opt2 = torch.optim.Adam([{'params': model2.non_reg_params, 'weight_decay': 0},
-                                     {'params': model2.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True, fused=True)
+            opt2 = make_adam([{'params': model2.non_reg_params, 'weight_decay': 0},
+                              {'params': model2.reg_params, 'weight_decay': 5e-4}], 0.01, dev, fused=fused_adam)
             epoch2 = make_epoch(model2, opt2, data, lagged=True)
             for _ in range(6):
                 epoch2()
@@ -299,8 +303,9 @@ def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, ep
                 val_mask=(r >= 0.1) & (r < 0.4))
     torch.manual_seed(0)
     model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=dropout).to(dev)
-    opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                            {'params': model.reg_params, 'weight_decay': wd}], lr=lr, capturable=True, fused=True)
+    from experiment.save_models import make_adam
+    opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                     {'params': model.reg_params, 'weight_decay': wd}], lr, dev, fused=os.environ.get('DCR_FUSED_ADAM', '1') == '1')
     # the epoch as experiment/training_loop.py runs it: eager for the first calls, then two captured HIP graphs
     epoch = make_epoch(model, opt, data, lagged=True)
     for _ in range(10):

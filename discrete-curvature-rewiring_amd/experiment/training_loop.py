@@ -26,7 +26,9 @@ import torch.nn.functional as F
 
 class _PickedMean(torch.autograd.Function):
     """``-log_probs.gather(1, y[:, None]).mean()`` and its backward as one kernel each (csrc/dcr_gcn.hip): the gradient is
-    ``-g / m`` at the picked entries and zero elsewhere, bit for bit what ``F.nll_loss`` (training_loop.py:51) gives."""
+    ``-g / m`` at the picked entries and zero elsewhere, bit for bit what ``F.nll_loss`` (training_loop.py:51) gives for class ids
+    in [0, C) (the callers check that once: ``GraphedEpoch._labels_fit``).  The loss VALUE is summed in float64 and rounded
+    once: equal to the stock op's to the last ulp, not necessarily bit for bit."""
 
     @staticmethod
     def forward(ctx, log_probs, y):
@@ -128,6 +130,14 @@ class GraphedEpoch:
         self.y_val = data.y.index_select(0, self.val_idx)
         self.n_val = int(self.val_idx.numel())
         self.rows = _takes_rows(model)
+        # The one-kernel loss / accuracy (dcr_nll_picked_mean_*, dcr_count_argmax_equal_f32_dev) read the labels as int64
+        # class ids in [0, C): F.nll_loss raises on anything else except ignore_index = -100, which it leaves out of the mean.
+        # Checked once here (a host sync before anything is captured); labels they do not cover go the stock way.
+        # Only the GRADIENT of the fused loss is bit-identical to F.nll_loss's (-1/m at the picked entries); the loss VALUE is
+        # reduced in float64 and rounded once, so loss.item() may differ from the stock op in the last ulp.
+        self.fused_labels = bool(data.y.dtype == torch.int64 and self.y_train.is_contiguous() and self.y_val.is_contiguous()
+                                 and self.y_train.numel() > 0 and int(self.y_train.min()) >= 0 and int(self.y_val.min()) >= 0)
+        self._n_classes_checked = None
 
     @staticmethod
     def supported(model, optimizer, data):
@@ -146,9 +156,22 @@ class GraphedEpoch:
         backward at the bench shape), a gather and a mean are a few small multi-workgroup kernels."""
         if not self.rows:
             log_probs = log_probs.index_select(0, self.train_idx)
-        if self.rows and _fused_ok(log_probs):
+        if self.rows and _fused_ok(log_probs) and self._labels_fit(log_probs.shape[1]):
             return _PickedMean.apply(log_probs, self.y_train)
         return -log_probs.gather(1, self.y_train.unsqueeze(1)).mean()
+
+    def _labels_fit(self, n_classes):
+        """Labels are class ids below the model's output width (checked on the first, eager, epochs; cached)."""
+        if not self.fused_labels:
+            return False
+        if self._n_classes_checked != n_classes:
+            if torch.cuda.is_current_stream_capturing():
+                return False   # (never reached: the eager warm-up epochs run the same code first)
+            if max(int(self.y_train.max()), int(self.y_val.max())) >= n_classes:
+                self.fused_labels = False   # F.nll_loss raises on such a target: let the stock op do so
+                return False
+            self._n_classes_checked = n_classes
+        return True
 
     def _train_step(self):
         log_probs = self.model(self.data, rows=self.train_idx) if self.rows else self.model(self.data)
@@ -161,7 +184,7 @@ class GraphedEpoch:
         with torch.no_grad():
             if self.rows:
                 lp = self.model(self.data, rows=self.val_idx)
-                return _count_correct(lp, self.y_val) if _fused_ok(lp) else lp.max(1)[1].eq(self.y_val).sum()
+                return _count_correct(lp, self.y_val) if _fused_ok(lp) and self._labels_fit(lp.shape[1]) else lp.max(1)[1].eq(self.y_val).sum()
             log_probs = self.model(self.data)
         return log_probs.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()
 
@@ -223,7 +246,8 @@ class LaggedGraphedEpoch(GraphedEpoch):
         torch._foreach_copy_(self.prev, list(self.model.state_dict().values()))   # (one launch for the snapshot)
         if self.rows:
             lp_train, lp_eval = self.model.forward_pair(self.data, rows_train=self.train_idx, rows_eval=self.val_idx)
-            correct_prev = _count_correct(lp_eval, self.y_val) if _fused_ok(lp_eval) else lp_eval.max(1)[1].eq(self.y_val).sum()
+            correct_prev = (_count_correct(lp_eval, self.y_val) if _fused_ok(lp_eval) and self._labels_fit(lp_eval.shape[1])
+                            else lp_eval.max(1)[1].eq(self.y_val).sum())
         else:
             lp_train, lp_eval = self.model.forward_pair(self.data)
             correct_prev = lp_eval.index_select(0, self.val_idx).max(1)[1].eq(self.y_val).sum()

@@ -196,7 +196,7 @@ class SdrfRun:
         self.G = DcrGraph.from_data(data, device=device)
         # DCR_DEVICE_DRAW=0: always draw on the host (numpy's exp / sum / cumsum on the downloaded improvements)
         self.device_draw = os.environ.get('DCR_DEVICE_DRAW', '1') != '0'
-        self.device_draws = self.host_draws = 0
+        self.device_draws = self.host_draws = self.no_candidate_iterations = 0
         self._mark = _StreamMark()
         self._next_argmin = None  # (x, y) of the pass already run for the coming iteration (see step)
         self.last = (None, None, None)  # (x, y, candidates) of the last iteration (bench.py: bytes of the improvement step)
@@ -224,17 +224,26 @@ class SdrfRun:
             # taken here and the draw itself runs on the device (dcr_sdrf_iteration_device_draw), accepted only when it is
             # certain to be numpy's index.  Otherwise nothing was edited: the uniform goes back into the stream and the
             # iteration runs the long way below (numpy's own exp, sum and cumsum on the host).
+            # (single-threaded contract, as the reference's own use of the global stream: nothing else may draw from numpy's
+            #  legacy generator between mark() and rewind())
             self._mark.mark()
             uniform = np.random.random_sample()
-            status, n_cand, _, _, nxt = G.sdrf_iteration_device_draw(x, y, curv_type, tau, uniform, self.remove_edges,
-                                                                    self.removal_bound, incremental=self.incremental)
+            try:
+                status, n_cand, _, _, nxt = G.sdrf_iteration_device_draw(x, y, curv_type, tau, uniform, self.remove_edges,
+                                                                        self.removal_bound, incremental=self.incremental)
+            except BaseException:
+                self._mark.rewind()   # the call failed before any edit was accepted: the uniform was not numpy's to lose
+                raise
             if status == 0:
                 self._next_argmin = nxt[:2]
                 self.last = (x, y, int(n_cand))
                 self.device_draws += 1
                 return True
             self._mark.rewind()
-            self.host_draws += 1
+            if status == 2:
+                self.no_candidate_iterations += 1   # np.random.choice is never reached (sdrf_no_cuda.py:47-52)
+            else:
+                self.host_draws += 1                # left undecided by the margin test: numpy draws on the host below
 
         k = l = idx = None
         if tau == float('inf') and not want_trace:

@@ -51,6 +51,8 @@ def lib():
                                       _i64p]
         L.dcro_improvements.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int64,
                                         _i32p, _i32p, _f64p]
+        L.dcro_improvements_mt.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int64,
+                                           _i32p, _i32p, _f64p, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -135,10 +137,18 @@ class CGraph:
         lib().dcro_candidates(self.h, x, y, cap, _p(ci, _i32p), _p(cj, _i32p), ctypes.byref(n))
         return ci[:n.value].copy(), cj[:n.value].copy()
 
-    def improvements(self, x, y, ci, cj, curv_type='bfc'):
+    def improvements(self, x, y, ci, cj, curv_type='bfc', nthreads=1):
+        """sdrf_no_cuda.py:41-46 per candidate; ``nthreads`` > 1: the same literal add / recompute / remove, each worker on
+        a private copy of the graph (the candidates are independent of one another)."""
         ci = np.ascontiguousarray(ci, dtype=np.int32)
         cj = np.ascontiguousarray(cj, dtype=np.int32)
         out = np.empty(ci.shape[0], dtype=np.float64)
+        if nthreads > 1:
+            rc = lib().dcro_improvements_mt(self.h, x, y, CURV[curv_type], ci.shape[0], _p(ci, _i32p), _p(cj, _i32p),
+                                            _p(out, _f64p), nthreads)
+            if rc != 0:
+                raise MemoryError(f'dcro_improvements_mt failed ({rc})')
+            return out
         lib().dcro_improvements(self.h, x, y, CURV[curv_type], ci.shape[0], _p(ci, _i32p), _p(cj, _i32p),
                                 _p(out, _f64p))
         return out
@@ -159,8 +169,12 @@ def softmax(a, tau=1):
     return weights / weights.sum()
 
 
-def sdrf(edge_index, num_nodes, curv_type, loops, remove_edges, removal_bound, tau, trace=None, nthreads=1):
-    """rewiring/sdrf_no_cuda.py:9-68 composed over the C restatement."""
+def sdrf(edge_index, num_nodes, curv_type, loops, remove_edges, removal_bound, tau, trace=None, nthreads=1, compact=False,
+         progress=None):
+    """rewiring/sdrf_no_cuda.py:9-68 composed over the C restatement.  ``compact``: the trace keeps the number of candidates
+    and a SHA-256 of the improvement vector's float64 bytes instead of the two lists (runs at the bench sizes: 10^5-10^6
+    candidates per iteration); ``progress(iteration, record)`` is called after every iteration."""
+    import hashlib
     G = CGraph(edge_index, num_nodes)
     for _ in range(loops):
         can_add = True
@@ -169,18 +183,26 @@ def sdrf(edge_index, num_nodes, curv_type, loops, remove_edges, removal_bound, t
         x, y = int(eu[m]), int(ev[m])
         rec = {'argmin': [x, y]}
         ci, cj = G.candidates(x, y)
-        rec['candidates'] = np.stack([ci, cj], 1).tolist()
+        if compact:
+            rec['n_candidates'] = int(len(ci))
+            rec['candidates_sha256'] = hashlib.sha256(np.stack([ci, cj], 1).astype(np.int32).tobytes()).hexdigest()
+        else:
+            rec['candidates'] = np.stack([ci, cj], 1).tolist()
         k = l = None
         if len(ci):
-            imp = G.improvements(x, y, ci, cj, curv_type)
-            rec['improvements'] = imp.tolist()
+            imp = G.improvements(x, y, ci, cj, curv_type, nthreads)
+            if compact:
+                rec['improvements_sha256'] = hashlib.sha256(np.ascontiguousarray(imp, dtype=np.float64).tobytes()).hexdigest()
+                rec['argmin_value_hex'] = float(curv[m]).hex()
+            else:
+                rec['improvements'] = imp.tolist()
             idx = np.random.choice(range(len(ci)), p=softmax(imp, tau=tau))
             rec['choice'] = int(idx)
             k, l = int(ci[idx]), int(cj[idx])
             G.add_edge(k, l)
             rec['added'] = [k, l]
         else:
-            rec.update(improvements=[], choice=None, added=None)
+            rec.update(choice=None, added=None) if compact else rec.update(improvements=[], choice=None, added=None)
             can_add = False
             if not remove_edges:
                 rec['removed'] = None
@@ -202,6 +224,8 @@ def sdrf(edge_index, num_nodes, curv_type, loops, remove_edges, removal_bound, t
                 stop = True
         if trace is not None:
             trace.append(rec)
+        if progress is not None:
+            progress(len(trace) if trace is not None else -1, rec)
         if stop:
             break
     return G.to_edge_index()

@@ -14,7 +14,9 @@
  *   classical           curvature/classical_curvatures.py:14-28
  *   candidates          rewiring/sdrf_no_cuda.py:29-37
  *   improvements        rewiring/sdrf_no_cuda.py:41-46  (literally: add the
- *                       edge, recompute, subtract, remove the edge)
+ *                       edge, recompute, subtract, remove the edge; the
+ *                       threaded form does the same on a private copy of
+ *                       the graph per thread — candidates are independent)
  *   graph container     networkx.Graph as used at sdrf_no_cuda.py:20,27,51,
  *                       59-63,68: insertion-ordered adjacency, append on add,
  *                       in-place delete, G.edges enumeration by (node, position)
@@ -342,5 +344,81 @@ int dcro_improvements(dcro_graph *g, int32_t x, int32_t y, int ct, int64_t n, co
         dcro_remove_edge(g, ci[c], cj[c]);
     }
     scratch_free(s);
+    return 0;
+}
+
+/* The same loop body, candidates shared out over threads.  Every candidate is independent of the others (the graph is restored
+ * after each, sdrf_no_cuda.py:46), so each worker runs the literal add / recompute / subtract / remove on a PRIVATE deep copy
+ * of the graph and the shared graph is never written.  Same values as dcro_improvements, bit for bit (tested). */
+static dcro_graph *graph_clone(const dcro_graph *g) {
+    dcro_graph *c = (dcro_graph *)calloc(1, sizeof(*c));
+    if (!c) return NULL;
+    c->n = g->n;
+    c->rows = (row_t *)calloc((size_t)(g->n > 0 ? g->n : 1), sizeof(row_t));
+    if (!c->rows) { free(c); return NULL; }
+    for (int64_t u = 0; u < g->n; ++u) {
+        const row_t *r = &g->rows[u];
+        if (r->deg == 0) continue;
+        c->rows[u].nbr = (int32_t *)malloc((size_t)(r->deg + 2) * sizeof(int32_t));
+        if (!c->rows[u].nbr) { dcro_graph_destroy(c); return NULL; }
+        memcpy(c->rows[u].nbr, r->nbr, (size_t)r->deg * sizeof(int32_t));
+        c->rows[u].deg = r->deg;
+        c->rows[u].cap = r->deg + 2;
+    }
+    return c;
+}
+
+typedef struct {
+    const dcro_graph *g;
+    int32_t x, y;
+    int ct;
+    int64_t n;
+    const int32_t *ci, *cj;
+    double *out;
+    int64_t *cursor;
+    int *failed;
+} imp_job_t;
+
+static void *imp_worker(void *arg) {
+    imp_job_t *j = (imp_job_t *)arg;
+    dcro_graph *mine = graph_clone(j->g);
+    scratch_t *s = mine ? scratch_new(mine->n) : NULL;
+    if (!mine || !s) {
+        __atomic_store_n(j->failed, 1, __ATOMIC_RELAXED);
+    } else {
+        for (;;) {
+            const int64_t c0 = __atomic_fetch_add(j->cursor, 16, __ATOMIC_RELAXED);
+            if (c0 >= j->n) break;
+            const int64_t c1 = c0 + 16 < j->n ? c0 + 16 : j->n;
+            for (int64_t c = c0; c < c1; ++c) {
+                double before = curv_edge(mine, j->x, j->y, j->ct, s);
+                dcro_add_edge(mine, j->ci[c], j->cj[c]);
+                double after = curv_edge(mine, j->x, j->y, j->ct, s);
+                j->out[c] = after - before;
+                dcro_remove_edge(mine, j->ci[c], j->cj[c]);
+            }
+        }
+    }
+    if (s) scratch_free(s);
+    if (mine) dcro_graph_destroy(mine);
+    return NULL;
+}
+
+int dcro_improvements_mt(const dcro_graph *g, int32_t x, int32_t y, int ct, int64_t n, const int32_t *ci, const int32_t *cj,
+                         double *out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    int64_t cursor = 0;
+    int failed = 0;
+    imp_job_t job = {g, x, y, ct, n, ci, cj, out, &cursor, &failed};
+    pthread_t th[256];
+    int started = 0;
+    for (int t = 1; t < nthreads && (int64_t)t * 16 < n; ++t)
+        if (pthread_create(&th[started], NULL, imp_worker, &job) == 0) ++started;
+    imp_worker(&job);
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    /* a worker without memory for its copy takes nothing; the others finish the list.  If none could, say so. */
+    if (cursor < n) return -2;
+    (void)failed;
     return 0;
 }
