@@ -801,6 +801,11 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     if (curv_type < DCR_CURV_BFC || curv_type > DCR_CURV_HAANTJES) DCR_FAIL(DCR_EINVAL, "unknown curvature type");
     DCR_HIP(hipSetDevice(g->device));
     g->amax_valid = false;
+    g->ext_part_valid = false;  // (set again by the two-hop pass's closing kernel)
+    // first minimum in G.edges order, same host sync as the pass: from the closing kernel's per-block minima when it left some
+    auto argmin_after_pass = [&]() -> int {
+        return g->ext_part_valid ? launch_argext_from_parts(g, 0) : launch_argext(g, 0, -1, -1);
+    };
     // incremental is only sound on top of a complete buffer of the same curvature kind whose later edits were all
     // recorded in the dirty flags (dcr_graph_add_edge / _remove_edge / dcr_sdrf_tail do that)
     const bool incremental = want_incremental && g->curv_valid && g->curv_type_last == curv_type && g->dirty_tracked;
@@ -810,28 +815,31 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     g->dirty_tracked = true;
     g->pending_edits = 0;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
-    if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));  // first minimum in G.edges order, same host sync
+    if (with_argmin) DCR_TRY(argmin_after_pass());
     DCR_TRY(sync_result(g));
     if (g->last_engine == 0) {
         for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
         for (int grow = 0; grow < 4 && g->hres->h2_status == 2 && g->hres->misc[0] == 0 && h2_grow_pools(g); ++grow) {
             // the pools of its triangle step were too small (dense neighbourhoods): run it again with what it asked for
+            g->ext_part_valid = false;
             DCR_TRY(launch_curvature_pass(g, curv_type, false));
             if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
-            if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));
+            if (with_argmin) DCR_TRY(argmin_after_pass());
             DCR_TRY(sync_result(g));
             for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
         }
+        if (g->hres->h2_status != 0) g->ext_part_valid = false;  // (the closing kernel wrote nothing)
         if (g->hres->h2_status != 0 && g->hres->misc[0] == 0) {
             // a table of the two-hop pass filled up (keys of a split node hashed unevenly) or a unit list overflowed:
             // nothing it wrote is kept, the node-centric kernels redo the whole pass
             const int keep = g->pass_impl;
+            g->ext_part_valid = false;
             g->pass_impl = 2;
             const int rc = launch_curvature_pass(g, curv_type, false);
             g->pass_impl = keep;
             DCR_TRY(rc);
             if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
-            if (with_argmin) DCR_TRY(launch_argext(g, 0, -1, -1));
+            if (with_argmin) DCR_TRY(argmin_after_pass());
             DCR_TRY(sync_result(g));
         }
     }

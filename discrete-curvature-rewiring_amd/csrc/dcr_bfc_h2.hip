@@ -352,20 +352,30 @@ __device__ unsigned long long h2_prof[32];
 // =====================================================================================================================
 // wave classes: a node of at most 64 neighbours, by one wave
 // =====================================================================================================================
+// The LDS of one wave is used in two phases that never overlap (round 4: the arrays of both phases side by side held
+// occupancy at 6 / 12 / 20 waves per CU): up to the end of sweep A the first-level bitmap and the row descriptors the
+// pieces are addressed with (the pieces themselves are in registers from then on), from sweep B on the exact table, the
+// row masks, the queue and the candidate list.  Only the second-level bitmap lives through both.
 template <int L1, int EXS, int CLCAP>
 struct __attribute__((aligned(16))) H2Small {
-    unsigned b1[(1 << L1) / 32];
     unsigned b2[(1 << (L1 - 2)) / 32];
-    unsigned exkey[EXS];           // candidate key, or a member of N(u) | H2_NBR
-    unsigned exlo[EXS], exhi[EXS];  // candidate: the rows that hold it (64-bit mask); member of N(u): its position in row u
-    unsigned adjlo[64], adjhi[64];  // per row i: the rows adjacent to it = triangle partners of edge {u, v_i}
-    int2 desc[64];
-    int poff[66];
-    int pos[64], mx[64], rev[64];
-    unsigned qk[H2_QCAP];
-    unsigned short cls[CLCAP];     // candidate occurrences: EX slot ...
-    unsigned char qr[H2_QCAP];
-    unsigned char clr[CLCAP];      // ... and row
+    union {
+        struct {
+            unsigned b1[(1 << L1) / 32];   // (directly behind b2: the two are cleared as one range)
+            int2 desc[64];
+            int poff[66];
+        } a;
+        struct {
+            unsigned exkey[EXS];            // candidate key, or a member of N(u) | H2_NBR
+            unsigned exlo[EXS], exhi[EXS];  // candidate: the rows that hold it (64-bit mask); member of N(u): its position in row u
+            unsigned adjlo[64], adjhi[64];  // per row i: the rows adjacent to it = triangle partners of edge {u, v_i}
+            int pos[64], mx[64], rev[64];
+            unsigned qk[H2_QCAP];
+            unsigned short cls[CLCAP];     // candidate occurrences: EX slot ...
+            unsigned char qr[H2_QCAP];
+            unsigned char clr[CLCAP];      // ... and row
+        } b;
+    };
 #ifdef H2_PROF
     unsigned long long prof[8];    // per wave, flushed when the kernel ends
 #endif
@@ -414,40 +424,30 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
 #ifdef H2_PROF
     long long t_prof = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    {   // clear: bitmaps and row masks to zero, keys to "free"
-        uint4 *z = reinterpret_cast<uint4 *>(s->b1);
-        constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;  // b1 and b2 are adjacent
+    {   // clear: both bitmaps to zero (the second phase's arrays are set up between the sweeps)
+        uint4 *z = reinterpret_cast<uint4 *>(s->b2);
+        constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;  // b2, then b1 directly behind it
+        using Lds = H2Small<L1, EXS, CLCAP>;
+        static_assert(__builtin_offsetof(Lds, a) == sizeof(unsigned) * ((1 << (L1 - 2)) / 32), "b1 directly behind b2");
         for (int i = lane; i < NZ; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        uint4 *k4 = reinterpret_cast<uint4 *>(s->exkey);
-        for (int i = lane; i < EXS / 4; i += 64) k4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
-        uint4 *m4 = reinterpret_cast<uint4 *>(s->exlo);  // exlo and exhi are adjacent
-        for (int i = lane; i < 2 * EXS / 4; i += 64) m4[i] = make_uint4(0u, 0u, 0u, 0u);
-        s->adjlo[lane] = 0u;
-        s->adjhi[lane] = 0u;
-        s->pos[lane] = 0;
-        s->mx[lane] = 0;
-        s->rev[lane] = -1;
     }
     h2_wave_sync();
     H2_STAMP(0)
-    // the members of N(u): seeded into both bitmaps and the exact table (flagged, with their position in row u)
+    // the members of N(u): seeded into both bitmaps (into the exact table between the sweeps)
     bool full = false;
     if (lane >= ru.y || k < 0 || k >= g.n || k == u) {
         k = -1;
         rk = make_int2(0, 0);
     } else {
         if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
-        const int slot = h2s_insert_nbr<EXS>(s->exkey, (unsigned)k);
-        if (slot < 0) full = true;
-        else s->exlo[slot] = (unsigned)lane;
-        h2_seed(s->b1, s->b2, h2_bit<L1>((unsigned)k));
+        h2_seed(s->a.b1, s->b2, h2_bit<L1>((unsigned)k));
     }
     const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
     int poff_lane;
     const int P = h2_prefix(np, poff_lane);
-    s->desc[lane] = rk;
-    s->poff[lane] = poff_lane;
-    if (lane == 0) s->poff[64] = P;
+    s->a.desc[lane] = rk;
+    s->a.poff[lane] = poff_lane;
+    if (lane == 0) s->a.poff[64] = P;
     h2_wave_sync();
     H2_STAMP(1)
     if (P > 64 * NP) full = true;  // (cannot happen: the class bounds the weight; such a node would be redone elsewhere)
@@ -461,10 +461,10 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
         meta[q] = 0ull;
         const int jf = 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
         if (jf >= P) continue;  // uniform
-        const int r = h2_piece_row(s->poff, poff_lane, j < P ? j : jl, jf, jl);
+        const int r = h2_piece_row(s->a.poff, poff_lane, j < P ? j : jl, jf, jl);
         if (j < P) {
-            const int2 d = s->desc[r];
-            const int a = (d.x & ~3) + 4 * (j - s->poff[r]);
+            const int2 d = s->a.desc[r];
+            const int a = (d.x & ~3) + 4 * (j - s->a.poff[r]);
             w[q] = load_piece(g.col, a);
             meta[q] = (unsigned long long)h2_piece_mask(a, d.x, d.x + d.y) | ((unsigned long long)r << 4) | ((unsigned long long)(unsigned)a << 12);
         }
@@ -476,9 +476,27 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
         if (64 * q >= P) continue;  // uniform
         const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
         const unsigned vm = (unsigned)meta[q] & 0xFu;
-        h2_mark4<L1>(s->b1, s->b2, kk, vm & ~h2_eq4(kk, (unsigned)u));
+        h2_mark4<L1>(s->a.b1, s->b2, kk, vm & ~h2_eq4(kk, (unsigned)u));
     }
     mid();
+    h2_wave_sync();  // sweep A is through: b1 and the descriptors are dead, their space becomes the second phase's arrays
+    {
+        uint4 *k4 = reinterpret_cast<uint4 *>(s->b.exkey);
+        for (int i = lane; i < EXS / 4; i += 64) k4[i] = make_uint4(H2_EMPTY, H2_EMPTY, H2_EMPTY, H2_EMPTY);
+        uint4 *m4 = reinterpret_cast<uint4 *>(s->b.exlo);  // exlo and exhi are adjacent
+        for (int i = lane; i < 2 * EXS / 4; i += 64) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+        s->b.adjlo[lane] = 0u;
+        s->b.adjhi[lane] = 0u;
+        s->b.pos[lane] = 0;
+        s->b.mx[lane] = 0;
+        s->b.rev[lane] = -1;
+    }
+    h2_wave_sync();
+    if (k >= 0) {  // the members of N(u) into the exact table, flagged, with their position in row u
+        const int slot = h2s_insert_nbr<EXS>(s->b.exkey, (unsigned)k);
+        if (slot < 0) full = true;
+        else s->b.exlo[slot] = (unsigned)lane;
+    }
     h2_wave_sync();
     H2_STAMP(3)
     // sweep B: entries whose B2 bit is set are queued and settled against the exact table 64 at a time
@@ -490,16 +508,16 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
             bool cand = false;
             int slot = -1, row = 0;
             if (i < qn) {
-                const unsigned w = s->qk[i];
-                row = s->qr[i];
-                slot = h2s_find_or_insert<EXS>(s->exkey, w);
+                const unsigned w = s->b.qk[i];
+                row = s->b.qr[i];
+                slot = h2s_find_or_insert<EXS>(s->b.exkey, w);
                 if (slot < 0) {
                     full = true;
-                } else if (s->exkey[slot] & H2_NBR) {  // a member of N(u) in row `row`: rows `row` and exlo[slot] are adjacent
-                    const unsigned x = s->exlo[slot];
-                    atomicOr(x < 32u ? &s->adjlo[row] : &s->adjhi[row], 1u << (x & 31u));
+                } else if (s->b.exkey[slot] & H2_NBR) {  // a member of N(u) in row `row`: rows `row` and exlo[slot] are adjacent
+                    const unsigned x = s->b.exlo[slot];
+                    atomicOr(x < 32u ? &s->b.adjlo[row] : &s->b.adjhi[row], 1u << (x & 31u));
                 } else {
-                    atomicOr(row < 32 ? &s->exlo[slot] : &s->exhi[slot], 1u << (row & 31));
+                    atomicOr(row < 32 ? &s->b.exlo[slot] : &s->b.exhi[slot], 1u << (row & 31));
                     cand = true;
                 }
             }
@@ -507,8 +525,8 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
             if (cand) {
                 const int idx = cln + __popcll(m & below);
                 if (idx < CLCAP) {
-                    s->cls[idx] = (unsigned short)slot;
-                    s->clr[idx] = (unsigned char)row;
+                    s->b.cls[idx] = (unsigned short)slot;
+                    s->b.clr[idx] = (unsigned char)row;
                 } else {
                     full = true;
                 }
@@ -526,7 +544,7 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
         const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
         const unsigned vm = (unsigned)meta[q] & 0xFu;
         const unsigned isu = h2_eq4(kk, (unsigned)u) & vm;
-        if (isu) s->rev[(int)((meta[q] >> 4) & 0xFFull)] = (int)(meta[q] >> 12) + __ffs((int)isu) - 1;  // where u sits in that row
+        if (isu) s->b.rev[(int)((meta[q] >> 4) & 0xFFull)] = (int)(meta[q] >> 12) + __ffs((int)isu) - 1;  // where u sits in that row
         fl[q] = h2_again4<L1>(s->b2, kk, vm & ~isu);
     }
     // the flagged entries are queued; the drain has ONE call site (inlined per entry position the kernels outgrew the
@@ -549,8 +567,8 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
                 }
                 if (p) {
                     const int idx = qn + __popcll(m & below);
-                    s->qk[idx] = kk[jj];
-                    s->qr[idx] = (unsigned char)((meta[q] >> 4) & 0xFFull);
+                    s->b.qk[idx] = kk[jj];
+                    s->b.qr[idx] = (unsigned char)((meta[q] >> 4) & 0xFFull);
                     fl[q] &= ~(1u << jj);
                 }
                 qn += __popcll(m);
@@ -569,21 +587,21 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
     // step C: c(w) for the occurrence of w in row i = the rows that hold w, less row i, less the rows adjacent to row i
     const int cl_n = cln < CLCAP ? cln : CLCAP;
     for (int e = lane; e < cl_n; e += 64) {
-        const int slot = s->cls[e], row = s->clr[e];
-        const int c = __popc(s->exlo[slot] & ~s->adjlo[row]) + __popc(s->exhi[slot] & ~s->adjhi[row]) - 1;
+        const int slot = s->b.cls[e], row = s->b.clr[e];
+        const int c = __popc(s->b.exlo[slot] & ~s->b.adjlo[row]) + __popc(s->b.exhi[slot] & ~s->b.adjhi[row]) - 1;
         if (c > 0) {
-            atomicAdd(&s->pos[row], 1);
-            atomicMax(&s->mx[row], c);
+            atomicAdd(&s->b.pos[row], 1);
+            atomicMax(&s->b.mx[row], c);
         }
     }
     h2_wave_sync();
     if (k >= 0) {
-        const int rev = s->rev[lane];
+        const int rev = s->b.rev[lane];
         if (rev < 0 || rev >= g.cap_total) {
             row_ok(g, make_int2(-1, rev), 33, u, k);  // adjacency not symmetric: report, never publish
         } else {
-            const int T = __popc(s->adjlo[lane]) + __popc(s->adjhi[lane]);
-            rec[(int64_t)ru.x + lane] = make_uint4((unsigned)s->pos[lane], (unsigned)s->mx[lane], (unsigned)T, (unsigned)rev);
+            const int T = __popc(s->b.adjlo[lane]) + __popc(s->b.adjhi[lane]);
+            rec[(int64_t)ru.x + lane] = make_uint4((unsigned)s->b.pos[lane], (unsigned)s->b.mx[lane], (unsigned)T, (unsigned)rev);
         }
     }
     h2_wave_sync();  // the arrays are rewritten by the next node
@@ -594,8 +612,21 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
 // dependent device-memory reads (unit -> row of u -> rows of its members -> their pieces) with little to do in between,
 // so the chain of the NEXT node is started while the current one is worked on: its unit two nodes ahead, its row at the
 // start of this node, the rows' descriptors between the sweeps.
+// waves per SIMD the three wave-class kernels are compiled for (registers; their LDS allows as many since the two phases
+// share it).  Measured one class at a time (us, S100k; profiles/r04_occupancy_ab.txt): lightest class 5 / 6 / 7 / 8 waves:
+// 155 / 153 / 144 / 162 (near its vector-issue limit: more waves buy little); middle 3 / 4 / 5: 158 / 150 / 147;
+// heaviest 2 / 3: 142 / 106 (latency-bound: a third wave per SIMD is worth its 40 spilled registers).
+#ifndef H2_OCC0
+#define H2_OCC0 7
+#endif
+#ifndef H2_OCC1
+#define H2_OCC1 4
+#endif
+#ifndef H2_OCC2
+#define H2_OCC2 3
+#endif
 template <int L1, int EXS, int CLCAP, int WPB, int NP>
-__global__ void __launch_bounds__(64 * WPB, (L1 == 14 ? 5 : 1)) k_h2_small(View g, const int4 *units, const int32_t *count, int64_t unit_cap,
+__global__ void __launch_bounds__(64 * WPB, (L1 == 14 ? H2_OCC0 : L1 == 15 ? H2_OCC1 : H2_OCC2)) k_h2_small(View g, const int4 *units, const int32_t *count, int64_t unit_cap,
                                                        uint4 *rec, H2Retry rt) {
     __shared__ H2Small<L1, EXS, CLCAP> sm[WPB];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -732,9 +763,13 @@ __device__ inline int h2_query(const H2Tab t, unsigned w, bool &nbr) {
 }
 
 // ---- the edge set: every undirected edge as one 64-bit key in an open-addressing table in device memory -------------------
-// Rebuilt by every pass (one CAS per edge).  The triangle step asks it "is w adjacent to t?" a few times per edge with
-// triangles.
+// The triangle step asks it "is w adjacent to t?" a few times per edge with triangles.  Built once (one CAS per edge) and
+// then KEPT across passes (round 4): the SDRF loop changes one or two edges between two passes, the edit kernels journal them
+// (DevResult::edit_log) and k_h2_eset_apply brings the set up to date — an insertion, or a tombstone in place of a removed
+// key (probes walk over tombstones; the bitmap in front of the table keeps the removed edge's bit: a false positive the
+// table then answers).  Rebuilt when the journal overflowed, the table was re-sized, or tombstones have piled up.
 constexpr unsigned long long H2_ESET_EMPTY = ~0ull;
+constexpr unsigned long long H2_ESET_TOMB = ~0ull - 1ull;
 __device__ inline unsigned long long h2_edge_key(int a, int b) {
     return a < b ? ((unsigned long long)(unsigned)a << 32) | (unsigned)b : ((unsigned long long)(unsigned)b << 32) | (unsigned)a;
 }
@@ -762,8 +797,52 @@ __device__ inline bool h2_eset_has(const H2EdgeSet es, int a, int b) {
     }
     return false;
 }
-__global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int32_t *status) {
+// the journaled edits, in order, by one thread (a handful per SDRF iteration)
+__global__ void k_h2_eset_apply(H2EdgeSet es, DevResult *res, int32_t *status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = res->edit_n;
+    res->edit_n = 0;
+    if (n < 0 || n > EDIT_LOG_CAP) {  // (the host counts the edit launches and rebuilds instead: cannot happen)
+        *status = 1;
+        return;
+    }
+    const unsigned long long mask = (1ull << es.bits) - 1ull;
+    for (int e = 0; e < n; ++e) {
+        const int op = res->edit_log[3 * e], u = res->edit_log[3 * e + 1], v = res->edit_log[3 * e + 2];
+        const unsigned long long key = h2_edge_key(u, v);
+        unsigned long long h = h2_eset_slot(key, es.bits), free_at = ~0ull;
+        bool found = false;
+        for (unsigned long long walk = 0; walk <= mask; ++walk) {
+            const unsigned long long k = es.tab[h];
+            if (k == key) {
+                found = true;
+                break;
+            }
+            if (k == H2_ESET_TOMB && free_at == ~0ull) free_at = h;
+            if (k == H2_ESET_EMPTY) {
+                if (free_at == ~0ull) free_at = h;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        if (op > 0) {
+            if (!found) {
+                if (free_at == ~0ull) {
+                    *status = 1;
+                    return;
+                }
+                es.tab[free_at] = key;
+            }
+            const unsigned bb = h2_bloom_bit(key, es.bloom_bits);
+            es.bloom[bb >> 5] |= 1u << (bb & 31u);
+        } else if (found) {
+            es.tab[h] = H2_ESET_TOMB;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_h2_eset_build(View g, H2EdgeSet es, int32_t *status, DevResult *res) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) res->edit_n = 0;  // the set is built from the rows as they are: every journaled edit is in it
     if (s >= g.cap_total) return;
     const int u = g.slot_row[s];
     if (u < 0 || u >= g.n) return;
@@ -1157,6 +1236,10 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
     constexpr int NT = 64 * NW, NP = H2_NPB;
     const unsigned long long below = (1ull << lane) - 1ull;
     if (ru.y > 64 * NW) return false;  // uniform
+#ifdef H2_PROF
+    long long t_prof = (long long)__builtin_amdgcn_s_memtime();
+    H2Scratch *s = sc;
+#endif
     const int i = lane * NW + wid;
     int k = -1;
     int2 rk = make_int2(0, 0);
@@ -1207,6 +1290,7 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
         }
     }
     __syncthreads();  // the tables are cleared
+    H2_STAMP(0 + (PARTS ? 4 : 0))
     if (k >= 0) {     // the members of N(u): flagged table entries (in every partition's tables)
         const int sl = h2_insert<EXS>(t.key, (unsigned)k);
         if (sl < 0) *t.full = 1;
@@ -1229,12 +1313,16 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
         h2_mark4<L1>(t.b1, t.b2, kk, valid);
     }
     __syncthreads();
+    H2_STAMP(1 + (PARTS ? 4 : 0))
     // sweeps B and C: flagged entries are queued, the drain has one call site per sweep
     int qn = 0, tbase = -1, trow = 0;
 #pragma unroll 1
     for (int phase = 1; phase <= 2; ++phase) {
         unsigned fl[NP];
-        if (phase == 2) h2_batch_begin(tk, al, sc, k, tbase, trow);
+        if (phase == 2) {
+            h2_batch_begin(tk, al, sc, k, tbase, trow);
+            H2_STAMP(12)
+        }
         h2_wave_sync();
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -1284,10 +1372,13 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
         }
         if (phase == 1) {
             __syncthreads();
+            H2_STAMP(2 + (PARTS ? 4 : 0))
             ok = *t.full == 0;  // uniform
             if (!ok) break;
         } else {
+            H2_STAMP(13)
             h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
+            H2_STAMP(15)
         }
     }
     __syncthreads();  // the tables are rewritten by the next unit
@@ -1641,40 +1732,97 @@ __global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int4 *units
 }
 
 // ---- join the two records of every edge and evaluate the closing expression ------------------------------------------
-__global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv, const int32_t *status) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= g.cap_total) return;
-    if (*status != 0) return;  // some records are missing: the whole pass is redone by the node-centric kernels
-    // Two rounds of loads, not six behind one another: everything addressed by the slot itself first (its row, its
-    // neighbour, its record — all in bounds for every slot, slack included), then everything addressed by those (the two row
-    // headers, the partner slot's neighbour, row and record, from clamped indices); validity is decided afterwards.
-    const int u = g.slot_row[s];
-    const int v = g.col[s];
-    const uint4 a = rec[s];  // from u's side: statistics over N(v) \ N(u) \ {u}
-    const bool uok = u >= 0 && u < g.n, vok = v >= 0 && v < g.n;
-    const int64_t r = (int64_t)a.w;
-    const bool rok = r >= 0 && r < g.cap_total;
-    const int2 ru = g.rowinfo[uok ? u : 0];
-    const int dv = g.rowinfo[vok ? v : 0].y;
-    const int rcol = g.col[rok ? r : 0], rrow = g.slot_row[rok ? r : 0];
-    const uint4 b = rec[rok ? r : 0];  // from v's side: statistics over N(u) \ N(v) \ {v}
-    if (!uok) return;
-    if (s < ru.x || (int)(s - ru.x) >= ru.y) return;
-    if (v <= u || !vok) return;  // the value lives at the slot whose neighbour id exceeds the row id
-    if ((ru.y < dv ? ru.y : dv) == 1) {  // bfc_naive.py:18-19
-        curv[s] = 0.0;
-        return;
+// Round 4: a fixed grid walks the slots and every WAVE leaves the first minimum and the first maximum (value, slot) of what
+// it wrote: the arg-min that follows every pass of the SDRF loop (sdrf_no_cuda.py:27) and the stale arg-max of its removal
+// step (:57-61) are then one small reduction each instead of two more sweeps over the slots.  (Per wave, not per workgroup:
+// with a barrier at the end a workgroup holds its place until its slowest wave's gathers are back — measured, the kernel
+// took 137-268 us instead of 60, growing with the number of workgroups.)  The partner slot's record is only fetched by the
+// lanes whose slot holds a value (neighbour id above the row id) — under the execution mask, not from a clamped index:
+// half the lanes of every wave asking for element 0 of five arrays is a hot spot of its own.
+#ifndef H2_FINAL_Q
+#define H2_FINAL_Q 1
+#endif
+#ifndef H2_FINAL_BLOCKS
+#define H2_FINAL_BLOCKS 4096
+#endif
+__global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv, const int32_t *status, Ext *part_min,
+                                                  Ext *part_max) {
+    double lo_v = 0.0, hi_v = 0.0;
+    int lo_s = -1, hi_s = -1;
+    const bool live = *status == 0;  // (else some records are missing: the whole pass is redone by the node-centric kernels)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    constexpr int Q = H2_FINAL_Q;
+    for (int64_t s0 = (int64_t)blockIdx.x * 256 + threadIdx.x; live && s0 < g.cap_total; s0 += Q * stride) {
+        // Round one: everything addressed by the slot itself (its row, its neighbour, its record — all in bounds for every
+        // slot, slack included).  Round two, for the slots that may hold a value: the two row headers, the partner slot's
+        // neighbour, row and record.  Validity is decided afterwards.
+        int u[Q], v[Q];
+        uint4 a[Q];
+        bool want[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int64_t s = s0 + q * stride;
+            const bool in = s < g.cap_total;
+            u[q] = in ? g.slot_row[s] : -1;
+            v[q] = in ? g.col[s] : -1;
+            a[q] = in ? rec[s] : make_uint4(0u, 0u, 0u, 0u);  // from u's side: statistics over N(v) \ N(u) \ {u}
+        }
+        int2 ru[Q];
+        int dv[Q], rcol[Q], rrow[Q];
+        uint4 b[Q];
+        bool rok[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            // the value lives at the slot whose neighbour id exceeds the row id
+            want[q] = u[q] >= 0 && u[q] < g.n && v[q] > u[q] && v[q] < g.n;
+            const int64_t r = (int64_t)a[q].w;
+            rok[q] = want[q] && r >= 0 && r < g.cap_total;
+            ru[q] = make_int2(0, 0);
+            dv[q] = 0;
+            rcol[q] = rrow[q] = -1;
+            b[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (want[q]) {
+                ru[q] = g.rowinfo[u[q]];
+                dv[q] = g.rowinfo[v[q]].y;
+            }
+            if (rok[q]) {
+                rcol[q] = g.col[r];
+                rrow[q] = g.slot_row[r];
+                b[q] = rec[r];  // from v's side: statistics over N(u) \ N(v) \ {v}
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int64_t s = s0 + q * stride;
+            if (!want[q]) continue;
+            if (s < ru[q].x || (int)(s - ru[q].x) >= ru[q].y) continue;  // slack behind the row
+            double val;
+            if ((ru[q].y < dv[q] ? ru[q].y : dv[q]) == 1) {  // bfc_naive.py:18-19
+                val = 0.0;
+            } else {
+                if (!rok[q] || rcol[q] != u[q] || rrow[q] != v[q]) {
+                    row_ok(g, make_int2(-1, (int)a[q].w), 39, u[q], v[q]);
+                    continue;
+                }
+                if (a[q].z != b[q].z) {  // both sides count the same triangles
+                    row_ok(g, make_int2(-1, (int)a[q].z), 40, u[q], v[q]);
+                    continue;
+                }
+                const int gam = (int)(a[q].y > b[q].y ? a[q].y : b[q].y);
+                val = bfc_formula(ru[q].y, dv[q], (int)a[q].z, (int)b[q].x, (int)a[q].x, gam);
+            }
+            curv[s] = val;
+            ext_take(lo_v, lo_s, val, (int)s, 0);
+            ext_take(hi_v, hi_s, val, (int)s, 1);
+        }
     }
-    if (!rok || rcol != u || rrow != v) {
-        row_ok(g, make_int2(-1, (int)a.w), 39, u, v);
-        return;
+    ext_wave_reduce(lo_v, lo_s, 0);
+    ext_wave_reduce(hi_v, hi_s, 1);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+        part_min[w] = ext_make(lo_v, lo_s);
+        part_max[w] = ext_make(hi_v, hi_s);
     }
-    if (a.z != b.z) {        // both sides count the same triangles
-        row_ok(g, make_int2(-1, (int)a.z), 40, u, v);
-        return;
-    }
-    const int gam = (int)(a.y > b.y ? a.y : b.y);
-    curv[s] = bfc_formula(ru.y, dv, (int)a.z, (int)b.x, (int)a.x, gam);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -1714,6 +1862,7 @@ static int ensure_h2(dcr_graph *g) {
         g->h2_eset = nullptr;
         DCR_TRY(dev_alloc(&g->h2_eset, (int64_t)1 << bits));
         g->h2_eset_bits = bits;
+        g->h2_eset_valid = false;
     }
     int bbits = 16;
     while ((1ll << bbits) < 4 * g->cap_total) ++bbits;
@@ -1722,6 +1871,7 @@ static int ensure_h2(dcr_graph *g) {
         g->h2_bloom = nullptr;
         DCR_TRY(dev_alloc(&g->h2_bloom, ((int64_t)1 << bbits) / 32));
         g->h2_bloom_bits = bbits;
+        g->h2_eset_valid = false;
     }
     const int64_t need[H2_CLASSES] = {g->n + 64, g->n + 64, g->n + 64, g->n + 64, g->n + g->cap_total / 4 + 64};
     for (int c = 0; c < H2_CLASSES; ++c) DCR_TRY(dev_regrow(&g->h2_units[c], &g->h2_units_cap[c], need[c]));
@@ -1739,18 +1889,28 @@ static int ensure_h2(dcr_graph *g) {
 template <int C>
 static void launch_h2_small(dcr_graph *g, const View &vw, const H2Retry &rt, hipStream_t st) {
     constexpr int H2_WPB = h2_wpb(C);
-    constexpr int LDS = H2_WPB * (int)sizeof(H2Small<h2_l1(C), h2_exs(C), h2_clcap(C)>);
-    int per_cu = (160 * 1024) / LDS;
-    if (per_cu > 32 / H2_WPB) per_cu = 32 / H2_WPB;
-    if (per_cu < 1) per_cu = 1;
+    constexpr int NP = h2_maxw(C) / 256 + 1;  // 64-piece steps: W / 4 pieces and at most one more per row (alignment)
+    auto kern = k_h2_small<h2_l1(C), h2_exs(C), h2_clcap(C), H2_WPB, NP>;
+    // workgroups a CU holds at once (LDS and registers): the units are dealt to the workgroups up front (grid-stride), so a
+    // workgroup that has to wait for a place still has its whole share ahead of it — launch what is resident, no more
+    static int per_cu_res = 0;
+    if (per_cu_res == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * H2_WPB, 0) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = (160 * 1024) / (H2_WPB * (int)sizeof(H2Small<h2_l1(C), h2_exs(C), h2_clcap(C)>));
+            if (nb > 32 / H2_WPB) nb = 32 / H2_WPB;
+        }
+        per_cu_res = nb < 1 ? 1 : nb;
+    }
+    int per_cu = per_cu_res;
     int64_t grid = (int64_t)g->num_cu * per_cu;
     static const int64_t cap = getenv("DCR_H2_GRID") ? atoll(getenv("DCR_H2_GRID")) : 0;  // tuning aid: workgroups per CU
     if (cap > 0) grid = cap * g->num_cu;
     const int64_t units = g->h2_last_count[C] >= 0 ? (int64_t)g->h2_last_count[C] + g->h2_last_count[C] / 32 + 8 : g->n;
     if (grid > (units + H2_WPB - 1) / H2_WPB) grid = (units + H2_WPB - 1) / H2_WPB;  // small graphs: no idle workgroups
     if (grid < 1) grid = 1;
-    constexpr int NP = h2_maxw(C) / 256 + 1;  // 64-piece steps: W / 4 pieces and at most one more per row (alignment)
-    hipLaunchKernelGGL((k_h2_small<h2_l1(C), h2_exs(C), h2_clcap(C), H2_WPB, NP>), dim3((unsigned)grid), dim3(64 * H2_WPB), 0, st, vw,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * H2_WPB), 0, st, vw,
                        g->h2_units[C], &g->dres->h2_count[C], g->h2_units_cap[C], g->h2_rec, rt);
 }
 
@@ -1832,13 +1992,24 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     if (!serial) DCR_HIP(hipStreamWaitEvent(sS0, g->ev_fork, 0));
     launch_h2_small<0>(g, vw, rt, sS0);
     if (!serial) DCR_HIP(hipStreamWaitEvent(sa, g->ev_fork, 0));
-    // the edge set (probed by k_h2_triangles only).  (Beside weights and plan, which are short and on the critical path,
-    // its 32 MB memset and 1 M atomics tripled their time.)
-    // (Built ahead of the pass instead — beside the improvement pipeline of the SDRF loop, patched after the tail's edits —
-    //  the pass gained 0.03 ms and the small kernels it ran beside lost 0.12: measured, dropped.)
-    DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, sa));
-    DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), sa));
-    if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, sa, vw, es, status);
+    // the edge set (probed by k_h2_triangles only): kept from the last pass and patched with the journaled edits, or rebuilt
+    // (32 MB of fill and a million atomics beside the class kernels: 0.17 ms of chip time per pass on the bench graph)
+    static const bool keep_eset = !(getenv("DCR_H2_ESET_KEEP") && atoi(getenv("DCR_H2_ESET_KEEP")) == 0);
+    const bool patch = keep_eset && g->h2_eset_valid && g->h2_eset_pending <= EDIT_LOG_CAP &&
+                       g->h2_eset_tombs + g->h2_eset_pending <= ((int64_t)1 << g->h2_eset_bits) / 16;
+    if (patch) {
+        if (g->h2_eset_pending > 0) {
+            hipLaunchKernelGGL(k_h2_eset_apply, dim3(1), dim3(64), 0, sa, es, g->dres, status);
+            g->h2_eset_tombs += g->h2_eset_pending;
+        }
+    } else {
+        DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, sa));
+        DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), sa));
+        if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, sa, vw, es, status, g->dres);
+        g->h2_eset_tombs = 0;
+    }
+    g->h2_eset_valid = true;
+    g->h2_eset_pending = 0;
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_aux, sa));
         DCR_HIP(hipEventRecord(g->ev_join[0], sL));
@@ -1865,7 +2036,21 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     tk.retry_flag = 0x80000000u;
     launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
     hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 2)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status, 1);
-    if (sblocks > 0) hipLaunchKernelGGL(k_h2_final, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status);
+    {
+        if (!g->ext_part) {
+            Ext *p = nullptr;
+            DCR_TRY(dev_alloc(&p, 2 * EXT_PART_BLOCKS));
+            g->ext_part = p;
+        }
+        int64_t fblocks = (sblocks + H2_FINAL_Q - 1) / H2_FINAL_Q;
+        if (fblocks > H2_FINAL_BLOCKS) fblocks = H2_FINAL_BLOCKS;
+        if (fblocks > EXT_PART_BLOCKS / 4) fblocks = EXT_PART_BLOCKS / 4;  // (a pair of partial extrema per WAVE)
+        if (fblocks < 1) fblocks = 1;
+        hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
+                           (Ext *)g->ext_part + EXT_PART_BLOCKS);
+        g->ext_part_n = (int)fblocks * 4;
+        g->ext_part_valid = true;  // (dropped again by the caller if the pass reports a failure, and by every edit)
+    }
     DCR_HIP(hipGetLastError());
     static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;
 #ifdef H2_PROF
@@ -1880,6 +2065,8 @@ int launch_curvature_pass_h2(dcr_graph *g) {
                 h[11] / 1e6, h[12] / 1e6, h[13] / 1e6, h[14] / 1e6, h[15] / 1e6);
         fprintf(stderr, "[h2 prof] sweep C of both block classes: batch set-up %.1f; pieces + drains %.1f; last drain %.1f; batch end %.1f\n",
                 h[16] / 1e6, h[17] / 1e6, h[18] / 1e6, h[19] / 1e6);
+        fprintf(stderr, "[h2 prof] class M (register-resident path), third sweep: batch set-up %.1f; flags + queue + drains %.1f; batch end %.1f\n",
+                h[20] / 1e6, h[21] / 1e6, h[23] / 1e6);
         unsigned long long z[32] = {0};
         DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_prof), z, sizeof(z)));
     }

@@ -64,7 +64,7 @@ __device__ inline void wave_erase(int32_t *row, double *crow, int deg, int pos, 
 }
 
 __device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32_t u, int32_t v, int lane,
-                                int *status) {
+                                int *status, DevResult *res) {
     int2 ru = rowinfo[u], rv = rowinfo[v];
     int pu = wave_find(col + ru.x, ru.y, v, lane);
     int pv = wave_find(col + rv.x, rv.y, u, lane);
@@ -78,6 +78,7 @@ __device__ void dev_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32
         rowinfo[u] = make_int2(ru.x, ru.y - 1);
         rowinfo[v] = make_int2(rv.x, rv.y - 1);
         *status = 0;
+        journal_edit(res, -1, u, v);
     }
 }
 
@@ -112,6 +113,7 @@ __device__ inline void dev_add_edge(int2 *rowinfo, const int32_t *rowcap, int32_
     rowinfo[u] = make_int2(ru.x, ru.y + 1);
     rowinfo[v] = make_int2(rv.x, rv.y + 1);
     res->add_status = 0;
+    journal_edit(res, +1, u, v);
 }
 
 __global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *rowcap, int32_t *col, int32_t u,
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(64) k_add_edge(int2 *rowinfo, const int32_t *r
 __global__ void __launch_bounds__(64) k_remove_edge(int2 *rowinfo, int32_t *col, double *curv, int32_t u, int32_t v,
                                                     DevResult *res) {
     int st = 0;
-    dev_remove_edge(rowinfo, col, curv, u, v, threadIdx.x, &st);
+    dev_remove_edge(rowinfo, col, curv, u, v, threadIdx.x, &st, res);
     if (threadIdx.x == 0) res->misc[0] = st;
 }
 
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *
         return;
     }
     int st = 0;
-    dev_remove_edge(rowinfo, col, curv, u, v, lane, &st);
+    dev_remove_edge(rowinfo, col, curv, u, v, lane, &st, res);
     if (lane == 0) {
         res->removed_u = u;
         res->removed_v = v;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(256) k_sdrf_tail(int2 *rowinfo, const int32_t 
         return;
     }
     int st = 0;
-    dev_remove_edge(rowinfo, col, curv, res->ext_u, res->ext_v, tid, &st);
+    dev_remove_edge(rowinfo, col, curv, res->ext_u, res->ext_v, tid, &st, res);
     if (tid == 0) {
         res->removed_u = res->ext_u;
         res->removed_v = res->ext_v;
@@ -263,15 +265,21 @@ __global__ void k_relayout(const int2 *old_info, const int32_t *old_col, const d
 // host side
 // ---------------------------------------------------------------------------------------------
 void launch_add_edge(dcr_graph *g, int32_t u, int32_t v) {
+    g->h2_eset_pending += 1;
+    g->ext_part_valid = false;
     hipLaunchKernelGGL(k_add_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->rowcap, g->col, u, v, g->dres);
 }
 
 void launch_sdrf_tail(dcr_graph *g, int32_t u, int32_t v, int edit_add, int do_remove, double bound, int edit_rem) {
+    g->h2_eset_pending += 2;
+    g->ext_part_valid = false;
     hipLaunchKernelGGL(k_sdrf_tail, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->rowcap, g->col, g->curv, g->dirty, g->dres, u, v,
                        edit_add, do_remove, bound, edit_rem);
 }
 
 void launch_remove_if_above(dcr_graph *g, double bound, int edit) {
+    g->h2_eset_pending += 1;
+    g->ext_part_valid = false;
     // flag the neighbourhood while the edge is still there, then remove it
     hipLaunchKernelGGL(k_mark_dirty_ext, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, g->dres, bound,
                        edit);
@@ -300,6 +308,7 @@ static int alloc_layout(dcr_graph *g, int64_t cap_total) {
 // Re-pack every row with fresh slack (called when an append finds its row full).
 // Row order, in-row order and the (stale) curvature values keep their relative slot order.
 int relayout(dcr_graph *g) {
+    g->ext_part_valid = false;  // slots move
     std::vector<int2> info((size_t)g->n);
     DCR_HIP(hipMemcpyAsync(info.data(), g->rowinfo, sizeof(int2) * (size_t)g->n, hipMemcpyDeviceToHost, g->stream));
     DCR_HIP(hipStreamSynchronize(g->stream));
@@ -484,7 +493,7 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
                         g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
                         g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_units[3], g->h2_units[4], g->h2_retry, g->h2_task, g->h2_cand, g->h2_part, g->h2_bloom,
-                        g->h2_rec, g->h2_eset};
+                        g->h2_rec, g->h2_eset, g->ext_part};
     for (void *p : dev_ptrs)
         if (p) (void)hipFree(p);
     for (int b = 0; b < NBINS; ++b)
@@ -556,6 +565,8 @@ int dcr_graph_remove_edge(dcr_graph *g, int32_t u, int32_t v) {
     g->am_valid = false;
     g->amax_valid = false;
     launch_mark_dirty(g, u, v, g->pending_edits++);
+    g->h2_eset_pending += 1;
+    g->ext_part_valid = false;
     hipLaunchKernelGGL(k_remove_edge, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->curv, u, v, g->dres);
     DCR_HIP(hipGetLastError());
     DCR_TRY(sync_result(g));

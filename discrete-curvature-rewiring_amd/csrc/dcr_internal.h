@@ -81,6 +81,11 @@ struct DevResult {
     // k_h2_triangles launch of the pool has taken
     int32_t h2_ntask[2], h2_ncand[2], h2_npart[2];
     int32_t h2_ncand_done[2];
+    // Edit journal (round 4): every edge the device adds or removes since the two-hop pass last brought its edge set up to
+    // date: {+1 / -1, u, v} per edit, in order; edit_n keeps counting past the capacity (the host then knows the bound on
+    // its own and rebuilds the set).  Written by dev_add_edge / dev_remove_edge, consumed by k_h2_eset_apply.
+    int32_t edit_n;
+    int32_t edit_log[3 * 8];
     int32_t h2_retry;   // units on the retry list (nodes whose tables filled up in their class, redone by the largest class)
     int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels)
 };
@@ -91,11 +96,78 @@ struct DevResult {
 // a in N(x) and b in N(l) (or the other way round).  Per node, one byte: DIRTY_ENDPOINT on x and l, bit A_e on the
 // members of N(x) and B_e on those of N(l) for the e-th edit since the last pass (three edits fit; dcr_sdrf_tail makes
 // two); further edits fall back to DIRTY_COARSE on {x,l} ∪ N(x) ∪ N(l) (every edge with a flagged endpoint).
+constexpr int EDIT_LOG_CAP = 8;
+constexpr int EXT_PART_BLOCKS = 16384;  // capacity of the per-block extrema arrays
+__device__ inline void journal_edit(DevResult *res, int op, int32_t u, int32_t v) {  // one thread of a single-workgroup edit kernel
+    const int i = res->edit_n;
+    if (i >= 0 && i < EDIT_LOG_CAP) {
+        res->edit_log[3 * i] = op;
+        res->edit_log[3 * i + 1] = u;
+        res->edit_log[3 * i + 2] = v;
+    }
+    res->edit_n = i + 1;
+}
 constexpr unsigned DIRTY_COARSE = 0x80u, DIRTY_ENDPOINT = 0x40u;
 constexpr int DIRTY_EDITS = 3;
 __device__ __host__ inline bool edge_dirty(unsigned du, unsigned dv) {
     if ((du | dv) & (DIRTY_COARSE | DIRTY_ENDPOINT)) return true;
     return ((((du >> 1) & dv) | ((dv >> 1) & du)) & 0x15u) != 0u;  // some edit has its A bit on one side, its B bit on the other
+}
+
+// ---- (value, slot) extrema: first in G.edges order (= smallest slot) on ties (sdrf_no_cuda.py:27,59,61) ----
+struct Ext {  // how a partial result is stored; the running pair lives in two plain registers (ext_take): passed around as a
+              // struct it ended up in scratch memory (88-117 scratch accesses per kernel, round 4)
+    double val;
+    int32_t slot;
+    int32_t pad;
+};
+
+// (bv, bs) <- the better of (bv, bs) and (v, sl); a slot < 0 means "none"
+__device__ inline void ext_take(double &bv, int &bs, double v, int sl, int want_max) {
+    const bool better = bs < 0 || (want_max ? v > bv : v < bv) || (v == bv && sl < bs);
+    if (sl >= 0 && better) {
+        bv = v;
+        bs = sl;
+    }
+}
+
+__device__ inline void ext_wave_reduce(double &bv, int &bs, int want_max) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int os = __shfl_xor(bs, off);
+        ext_take(bv, bs, ov, os, want_max);
+    }
+}
+
+// shv / shs: one entry per wave of the workgroup
+__device__ inline void ext_block_reduce(double &bv, int &bs, int want_max, double *shv, int *shs) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    ext_wave_reduce(bv, bs, want_max);
+    if (lane == 0) {
+        shv[wid] = bv;
+        shs[wid] = bs;
+    }
+    __syncthreads();
+    if (wid == 0) {
+        double tv = lane < nw ? shv[lane] : 0.0;
+        int ts = lane < nw ? shs[lane] : -1;
+        ext_wave_reduce(tv, ts, want_max);
+        if (lane == 0) {
+            shv[0] = tv;
+            shs[0] = ts;
+        }
+    }
+    __syncthreads();
+    bv = shv[0];
+    bs = shs[0];
+}
+__device__ inline Ext ext_make(double v, int sl) {
+    Ext e;
+    e.val = v;
+    e.slot = sl;
+    e.pad = 0;
+    return e;
 }
 
 struct ImpStats {  // per (x,y) statistics for the improvement kernels; lives in device memory
@@ -169,6 +241,9 @@ struct dcr_graph {
     int64_t h2_weight_cap = 0;
     unsigned long long *h2_eset = nullptr;  // every undirected edge as one 64-bit key (open addressing), rebuilt per pass
     int h2_eset_bits = 0;
+    bool h2_eset_valid = false;        // the set holds the graph's edges as of the last two-hop pass; later edits are in the journal
+    int h2_eset_pending = 0;           // upper bound of the edits journaled since (host-side count of the edit launches)
+    int64_t h2_eset_tombs = 0;         // upper bound of the tombstones in the set (removals applied since the last rebuild)
     int32_t h2_last_count[5] = {-1, -1, -1, -1, -1};  // units per class of the previous pass (sizes the next grids)
 
     // edges beyond every LDS table (dcr_bfc_giant.hip): records {slot, u, v, deg u, deg v}; position map over all ids
@@ -188,6 +263,12 @@ struct dcr_graph {
 
     // reductions / scans
     void *red_scratch = nullptr;  // argext partials
+    // per-block (value, slot) minima and maxima left by the two-hop pass's closing kernel (k_h2_final): the first minimum
+    // after the pass and the stale first maximum of the removal step then need no sweep of their own.  Valid until the next
+    // edit (a removal moves values between slots) or pass.
+    void *ext_part = nullptr;     // Ext[2][EXT_PART_BLOCKS]: minima, then maxima
+    int ext_part_n = 0;
+    bool ext_part_valid = false;
     int32_t *scan_a = nullptr, *scan_b = nullptr;
     int64_t scan_cap = 0;
 
@@ -245,6 +326,8 @@ void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit);  // flag t
 
 // dcr_sdrf.hip
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_t st = nullptr);  // st: default the library stream
+// the same from the per-block extrema of the last two-hop pass (g->ext_part_valid), without sweeping the edges again
+int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st = nullptr);
 int process_giant_edges(dcr_graph *g, int curv_type);  // dcr_bfc_giant.hip; syncs once
 int process_hub_edges(dcr_graph *g, int curv_type, bool incremental);  // dcr_bfc_giant.hip; syncs once
 int giant_edge(dcr_graph *g, int u, int v, int du, int dv, int64_t slot, int curv_type, bool need_cycles, int64_t *d_out6);  // result in DevResult after the next sync

@@ -45,57 +45,17 @@ __device__ inline double bfc_value(int d1, int d2, int T, int s1, int s2, int ga
 // ---------------------------------------------------------------------------------------------
 // arg-extremum over undirected edges, first in G.edges order (= smallest slot) on ties
 // ---------------------------------------------------------------------------------------------
-struct Ext {
-    double val;
-    int32_t slot;
-    int32_t pad;
-};
-
-__device__ inline Ext ext_better(const Ext &a, const Ext &b, int want_max) {
-    if (b.slot < 0) return a;
-    if (a.slot < 0) return b;
-    bool take_b = want_max ? (b.val > a.val) : (b.val < a.val);
-    if (!take_b && b.val == a.val && b.slot < a.slot) take_b = true;
-    return take_b ? b : a;
-}
-
-__device__ inline Ext ext_wave_reduce(Ext e, int want_max) {
-    for (int off = 32; off > 0; off >>= 1) {
-        Ext o;
-        o.val = __shfl_xor(e.val, off);
-        o.slot = __shfl_xor(e.slot, off);
-        e = ext_better(e, o, want_max);
-    }
-    return e;
-}
-
-__device__ inline Ext ext_block_reduce(Ext e, int want_max, Ext *sh) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    e = ext_wave_reduce(e, want_max);
-    if (lane == 0) sh[wid] = e;
-    __syncthreads();
-    if (wid == 0) {
-        Ext t;
-        t.val = 0.0;
-        t.slot = -1;
-        if (lane < nw) t = sh[lane];
-        t = ext_wave_reduce(t, want_max);
-        if (lane == 0) sh[0] = t;
-    }
-    __syncthreads();
-    return sh[0];
-}
-
+// (Ext, ext_better and the reductions live in dcr_internal.h: the two-hop pass's closing kernel leaves per-block extrema too)
 __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_total, const double *curv, int want_max,
                                                        int excl_u, int excl_v, const DevResult *res, Ext *partial) {
-    __shared__ Ext sh[4];
+    __shared__ double shv[4];
+    __shared__ int shs[4];
     if (excl_u == -2) {  // the edge picked on the device (dcr_sdrf_tail_at)
         excl_u = res->cand_i;
         excl_v = res->cand_j;
     }
-    Ext best;
-    best.val = 0.0;
-    best.slot = -1;
+    double best_v = 0.0;
+    int best_s = -1;
     // four slots per thread and round, their chains of dependent loads (owner row -> row extent -> neighbour ->
     // value) in flight together; slots are visited in increasing order per thread, so "first" extremum is preserved by
     // ext_better's (value, slot) order
@@ -121,60 +81,61 @@ __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_tot
         for (int q = 0; q < 4; ++q) {
             const int64_t s = s0 + q * stride;
             if (!ok[q] || (int)(s - ru[q].x) >= ru[q].y || v[q] <= u[q] || (u[q] == excl_u && v[q] == excl_v)) continue;
-            Ext c;
-            c.val = cv[q];
-            c.slot = (int32_t)s;
-            best = ext_better(best, c, want_max);
+            ext_take(best_v, best_s, cv[q], (int)s, want_max);
         }
     }
-    best = ext_block_reduce(best, want_max, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+    ext_block_reduce(best_v, best_s, want_max, shv, shs);
+    if (threadIdx.x == 0) partial[blockIdx.x] = ext_make(best_v, best_s);
 }
 
 __global__ void __launch_bounds__(256) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
                                                        DevResult *res) {
-    __shared__ Ext sh[4];
-    Ext best;
-    best.val = 0.0;
-    best.slot = -1;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) best = ext_better(best, partial[i], want_max);
-    best = ext_block_reduce(best, want_max, sh);
+    __shared__ double shv[4];
+    __shared__ int shs[4];
+    double best_v = 0.0;
+    int best_s = -1;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        const Ext e = partial[i];
+        ext_take(best_v, best_s, e.val, e.slot, want_max);
+    }
+    ext_block_reduce(best_v, best_s, want_max, shv, shs);
     if (threadIdx.x == 0) {
-        res->ext_val = best.val;
-        res->ext_slot = best.slot;
-        res->ext_u = best.slot >= 0 ? g.slot_row[best.slot] : -1;
-        res->ext_v = best.slot >= 0 ? g.col[best.slot] : -1;
-        res->ext_du = best.slot >= 0 ? g.rowinfo[res->ext_u].y : 0;
-        res->ext_dv = best.slot >= 0 ? g.rowinfo[res->ext_v].y : 0;
+        res->ext_val = best_v;
+        res->ext_slot = best_s;
+        const int eu = best_s >= 0 ? g.slot_row[best_s] : -1, ev = best_s >= 0 ? g.col[best_s] : -1;
+        res->ext_u = eu;
+        res->ext_v = ev;
+        res->ext_du = best_s >= 0 ? g.rowinfo[eu].y : 0;
+        res->ext_dv = best_s >= 0 ? g.rowinfo[ev].y : 0;
     }
 }
 
 // first maximum of a plain array (np.argmax of the improvements, utils/softmax.py:7)
 __global__ void __launch_bounds__(256) k_argmax_array(const double *a, int64_t n, Ext *partial, int64_t *idx_hi) {
-    __shared__ Ext sh[4];
-    Ext best;
-    best.val = 0.0;
-    best.slot = -1;
+    __shared__ double shv[4];
+    __shared__ int shs[4];
+    double best_v = 0.0;
+    int best_s = -1;
     // indices may exceed int32 only beyond 2^31 candidates, which the row capacity already excludes
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        Ext c;
-        c.val = a[i];
-        c.slot = (int32_t)i;
-        best = ext_better(best, c, 1);
+        ext_take(best_v, best_s, a[i], (int)i, 1);
     }
-    best = ext_block_reduce(best, 1, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+    ext_block_reduce(best_v, best_s, 1, shv, shs);
+    if (threadIdx.x == 0) partial[blockIdx.x] = ext_make(best_v, best_s);
     (void)idx_hi;
 }
 
 __global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int nparts, DevResult *res) {
-    __shared__ Ext sh[4];
-    Ext best;
-    best.val = 0.0;
-    best.slot = -1;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) best = ext_better(best, partial[i], 1);
-    best = ext_block_reduce(best, 1, sh);
-    if (threadIdx.x == 0) res->imp_argmax = best.slot;
+    __shared__ double shv[4];
+    __shared__ int shs[4];
+    double best_v = 0.0;
+    int best_s = -1;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        const Ext e = partial[i];
+        ext_take(best_v, best_s, e.val, e.slot, 1);
+    }
+    ext_block_reduce(best_v, best_s, 1, shv, shs);
+    if (threadIdx.x == 0) res->imp_argmax = best_s;
 }
 
 constexpr int ARGEXT_BLOCKS = 1024;  // (8192 blocks: 92 us instead of 33 on S100k, the per-block reduction dominates)
@@ -195,6 +156,16 @@ int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_
                        want_max, excl_u, excl_v, g->dres, (Ext *)g->red_scratch);
     hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, st, vw, (const Ext *)g->red_scratch, (int)blocks,
                        want_max, g->dres);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st) {
+    if (!st) st = g->stream;
+    g->amax_valid = false;  // the ext fields of the result block are about to be overwritten
+    RowView vw{g->rowinfo, g->col, g->slot_row};
+    const Ext *parts = (const Ext *)g->ext_part + (want_max ? EXT_PART_BLOCKS : 0);
+    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, st, vw, parts, g->ext_part_n, want_max, g->dres);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
@@ -719,19 +690,16 @@ constexpr int DRAW_BLOCKS = 256;
 // returns is that arg-max whatever the uniform (which it still consumes: the caller has taken it).  Candidate count from the
 // result block: nothing here needs a host value.
 __global__ void __launch_bounds__(256) k_argmax_array_dev(const double *a, const DevResult *res, Ext *partial) {
-    __shared__ Ext sh[4];
+    __shared__ double shv[4];
+    __shared__ int shs[4];
     const int64_t n = res->n_cand;
-    Ext best;
-    best.val = 0.0;
-    best.slot = -1;
+    double best_v = 0.0;
+    int best_s = -1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        Ext c;
-        c.val = a[i];
-        c.slot = (int32_t)i;
-        best = ext_better(best, c, 1);
+        ext_take(best_v, best_s, a[i], (int)i, 1);
     }
-    best = ext_block_reduce(best, 1, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+    ext_block_reduce(best_v, best_s, 1, shv, shs);
+    if (threadIdx.x == 0) partial[blockIdx.x] = ext_make(best_v, best_s);
 }
 
 __global__ void k_draw_from_argmax(const int32_t *ci, const int32_t *cj, DevResult *res) {
@@ -1031,7 +999,8 @@ int dcr_improvements(dcr_graph *g, int32_t x, int32_t y, int curv_type, int want
     // about to be drawn (that one is excluded there only because it has no stale value): compute it now, while the host
     // draws, and let dcr_sdrf_tail* pick it up.  Any pass or edit in between drops it.
     if (g->curv_valid && n > 0) {
-        DCR_TRY(launch_argext(g, 1, -1, -1));
+        if (g->ext_part_valid) DCR_TRY(launch_argext_from_parts(g, 1));  // left by the two-hop pass's closing kernel
+        else DCR_TRY(launch_argext(g, 1, -1, -1));
         g->amax_valid = true;
     }
     if (out_improvement) *out_improvement = n > 0 ? g->imp_out_h : nullptr;
@@ -1240,7 +1209,8 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
     // the stale arg-max of the removal step does not depend on the edge about to be drawn (see dcr_improvements), nor on the
     // improvement pipeline: beside it, on a stream of its own (it writes other fields of the result block)
     const bool amax = g->curv_valid && do_remove;
-    if (amax) {
+    const bool amax_parts = amax && g->ext_part_valid;  // one small reduction over what the pass's closing kernel left: in line
+    if (amax && !amax_parts) {
         DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
         DCR_HIP(hipStreamWaitEvent(g->side[0], g->ev_fork, 0));
         DCR_TRY(launch_argext(g, 1, -1, -1, g->side[0]));
@@ -1248,7 +1218,10 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
     }
     int64_t upper = 0;
     DCR_TRY(imp_enqueue(g, x, y, curv_type, &upper));
-    if (amax) {
+    if (amax_parts) {
+        DCR_TRY(launch_argext_from_parts(g, 1));
+        g->amax_valid = true;
+    } else if (amax) {
         DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[0], 0));
         g->amax_valid = true;
     }

@@ -106,6 +106,56 @@ def test_engines_agree_on_the_bench_graph_and_after_edits(h2graph, monkeypatch):
                 D.remove_edge(a, b)
 
 
+def test_edge_set_is_patched_not_rebuilt_between_passes(h2graph, monkeypatch):
+    """Round 4: the edge set of the triangle step is kept across passes and brought up to date from the journal of device-side
+    edits (insertions, tombstones, re-insertions over tombstones; more than eight edits between two passes: rebuilt).  A
+    handful of edits per round among hubs and their neighbours — where the triangle step probes — then a pass, against the
+    node-centric engine on a twin graph, for 40 rounds; one round has too many edits for the journal."""
+    from dcr import synthetic
+    from dcr.graph import DcrGraph
+    ei, n = synthetic.powerlaw_graph(30000, 8, seed=77)
+    H = h2graph(ei, n)
+    monkeypatch.setenv('DCR_PASS', 'nc')
+    D = DcrGraph(ei, n)
+    monkeypatch.delenv('DCR_PASS')
+    rng = np.random.Generator(np.random.PCG64(5))
+    removed, added = [], []
+    for rnd in range(40):
+        hu, hv, hc = H.curvature_all('bfc')
+        du, dv, dc = D.curvature_all('bfc')
+        assert H.pass_engine() == 'two-hop' and D.pass_engine() == 'node-centric'
+        assert np.array_equal(hu, du) and np.array_equal(hv, dv)
+        bad = np.flatnonzero(hc.view(np.int64) != dc.view(np.int64))
+        assert bad.size == 0, (rnd, bad[:5], hu[bad[:5]], hv[bad[:5]])
+        edits = 30 if rnd == 17 else int(rng.integers(1, 5))
+        for _ in range(edits):
+            kind = int(rng.integers(0, 4))
+            if kind == 0 and removed:                      # put a removed edge back (a key over its own tombstone)
+                a, b = removed.pop(int(rng.integers(0, len(removed))))
+                if not D.has_edge(a, b):
+                    H.add_edge(a, b), D.add_edge(a, b)
+            elif kind == 1 and added:                      # take an added edge out again
+                a, b = added.pop(int(rng.integers(0, len(added))))
+                if D.has_edge(a, b):
+                    H.remove_edge(a, b), D.remove_edge(a, b)
+                    removed.append((a, b))
+            elif kind == 2:                                # remove an edge at a hub
+                hub = int(rng.integers(0, 40))
+                nb = D.neighbors(hub)
+                if len(nb) > 3:
+                    b = int(nb[int(rng.integers(0, len(nb)))])
+                    H.remove_edge(hub, b), D.remove_edge(hub, b)
+                    removed.append((hub, b))
+            else:                                          # join two neighbours of a hub (a new triangle at the hub) or two hubs
+                hub = int(rng.integers(0, 40))
+                nb = D.neighbors(hub)
+                a, b = (int(nb[int(rng.integers(0, len(nb)))]), int(nb[int(rng.integers(0, len(nb)))])) if rng.random() < 0.7 \
+                    else (int(rng.integers(0, 40)), int(rng.integers(0, 40)))
+                if a != b and not D.has_edge(a, b):
+                    H.add_edge(a, b), D.add_edge(a, b)
+                    added.append((a, b))
+
+
 def test_automatic_engine_choice(monkeypatch):
     """Without DCR_PASS the two-hop kernels take the full Balanced Forman passes of sparse graphs, the node-centric ones
     small dense graphs (where nearly every 2-hop key repeats), every incremental pass and the classical curvatures."""
