@@ -56,6 +56,9 @@ constexpr int H2_SMALL_DEG = 64;
 #ifndef H2_Q
 #define H2_Q 2                            // 16-byte pieces per lane in flight in the streaming loops
 #endif
+#ifndef H2_QL
+#define H2_QL 2                           // the same for the split class (16 waves per unit, a few pieces per lane and sweep)
+#endif
 constexpr int H2_QCAP = 128;              // queued exact-path items per wave (worked off when fewer than 64 slots are left)
 __host__ __device__ constexpr int h2_wpb(int c) { return c == 2 ? 2 : 4; }  // waves (= nodes in flight) per workgroup of the wave classes
 
@@ -230,19 +233,19 @@ __device__ inline void h2_for_pieces(const int32_t *col, const int2 *desc, const
 // push(index, key, row) stores one; drain() works the queue off and resets qn.  The drain is called from ONE place per
 // iteration (inlined at every entry position it was 4 x H2_Q copies of the table walks per sweep, and the kernels
 // outgrew the instruction cache: 135-190 KB each).
-template <typename Flags, typename Push, typename Drain>
+template <int Q, typename Flags, typename Push, typename Drain>
 __device__ inline void h2_for_pieces_queued(const int32_t *col, const int2 *desc, const int *poff, int poff_lane, int P, int &qn,
                                             Flags flags, Push push, Drain drain) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll 1
-    for (int j0 = 0; j0 < P; j0 += 64 * H2_Q) {
-        int4 w[H2_Q];
-        int rr[H2_Q];
-        unsigned fl[H2_Q];
+    for (int j0 = 0; j0 < P; j0 += 64 * Q) {
+        int4 w[Q];
+        int rr[Q];
+        unsigned fl[Q];
         unsigned anyf = 0u;
 #pragma unroll
-        for (int q = 0; q < H2_Q; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int j = j0 + 64 * q + lane;
             rr[q] = -1;
             fl[q] = 0u;
@@ -267,7 +270,7 @@ __device__ inline void h2_for_pieces_queued(const int32_t *col, const int2 *desc
         while (true) {
             bool stop = false;  // uniform: the queue is full, the rest waits for the drain
 #pragma unroll
-            for (int q = 0; q < H2_Q; ++q) {
+            for (int q = 0; q < Q; ++q) {
                 const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -1153,9 +1156,13 @@ __device__ inline void h2_batch_end(const View &g, const H2Tasks tk, H2Alloc &al
 // Wave `wid` of NW takes the rows i = wid, wid + NW, ... of row u (strided: a hub's heaviest rows, adjacent at the
 // front of its row, spread over the waves); lane l of the batch starting at `base` stands for row base + l * NW + wid.
 // PHASE 0: bitmaps; 1: occurrences of the repeated keys; 2: per-row statistics, triangle step, records.
+// k0, rk0: this lane's row of the FIRST batch (member of N(u) and its row header, validated), read once by the caller for all
+// three sweeps: a unit of the streaming path is a chain of dependent device-memory reads (row of u -> headers of its
+// members' rows -> their pieces) with a handful of pieces per lane behind it, and two of its three links do not change
+// between the sweeps (round 4: the split class spent most of every sweep waiting for them).
 template <int L1, int EXS, int NW, bool PARTS, int PHASE>
 __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
-                                 const H2Tab t, H2Scratch *sc, uint4 *rec) {
+                                 const H2Tab t, H2Scratch *sc, uint4 *rec, int k0, int2 rk0) {
     const int lane = threadIdx.x & 63;
     const int wid = (int)(threadIdx.x >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -1166,15 +1173,19 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
 #endif
     for (int base = 0; base < ru.y; base += 64 * NW) {
         const int i = base + lane * NW + wid;
-        int k = -1;
-        int2 rk = make_int2(0, 0);
-        if (i < ru.y) {
-            k = g.col[ru.x + i];
-            if (k >= 0 && k < g.n && k != u) {
-                rk = g.rowinfo[k];
-                if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
-            } else {
-                k = -1;
+        int k = k0;
+        int2 rk = rk0;
+        if (base > 0) {  // uniform
+            k = -1;
+            rk = make_int2(0, 0);
+            if (i < ru.y) {
+                k = g.col[ru.x + i];
+                if (k >= 0 && k < g.n && k != u) {
+                    rk = g.rowinfo[k];
+                    if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
+                } else {
+                    k = -1;
+                }
             }
         }
         const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
@@ -1206,7 +1217,7 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
             }
             return h2_again4<L1>(t.b2, kk, valid);
         };
-        h2_for_pieces_queued(g.col, sc->desc, sc->poff, poff_lane, P, qn, flags,
+        h2_for_pieces_queued<(PARTS ? H2_QL : H2_Q)>(g.col, sc->desc, sc->poff, poff_lane, P, qn, flags,
                              [&](int idx, unsigned key, int r) {
                                  sc->qw[idx] = key;
                                  if (PHASE == 2) sc->qr[idx] = (unsigned char)r;
@@ -1401,6 +1412,21 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
     long long t_prof = (long long)__builtin_amdgcn_s_memtime();
     H2Scratch *s = sc;
 #endif
+    // this lane's row of the first batch of every sweep (requested before the tables are cleared)
+    int k0 = -1;
+    int2 rk0 = make_int2(0, 0);
+    {
+        const int i0 = (tid & 63) * NW + (tid >> 6);
+        if (i0 < ru.y) {
+            k0 = g.col[ru.x + i0];
+            if (k0 >= 0 && k0 < g.n && k0 != u) {
+                rk0 = g.rowinfo[k0];
+                if (!row_ok(g, rk0, 32, k0, u)) rk0 = make_int2(0, 0);
+            } else {
+                k0 = -1;
+            }
+        }
+    }
     {
         uint4 *z = reinterpret_cast<uint4 *>(t.b1);  // b1 and b2 are adjacent
         constexpr int NZ = ((1 << L1) / 32 + (1 << (L1 - 2)) / 32) / 4;
@@ -1423,14 +1449,14 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
     }
     __syncthreads();
     H2_STAMP(8 - 8 + (PARTS ? 4 : 0))
-    h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec);
+    h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0);
     __syncthreads();
     H2_STAMP(1 + (PARTS ? 4 : 0))
-    h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec);
+    h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0);
     __syncthreads();
     H2_STAMP(2 + (PARTS ? 4 : 0))
     const bool ok = *t.full == 0;  // uniform
-    if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec);
+    if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0);
     __syncthreads();  // the tables are rewritten by the next unit
     H2_STAMP(3 + (PARTS ? 4 : 0))
     return ok;
@@ -1745,8 +1771,12 @@ __global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int4 *units
 #ifndef H2_FINAL_BLOCKS
 #define H2_FINAL_BLOCKS 4096
 #endif
+// Launched twice per pass: `when` = 0 right behind the class kernels, BESIDE the retry launch, and it does the work iff the retry
+// list is empty (the usual case: the three retry kernels are then 27 us of empty launches that used to sit on the critical
+// path in front of it); `when` = 1 behind the retry launch, doing the work iff there was something to retry.
 __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv, const int32_t *status, Ext *part_min,
-                                                  Ext *part_max) {
+                                                  Ext *part_max, const int32_t *retry_count, int when) {
+    if ((*retry_count > 0) != (when != 0)) return;  // uniform (the count is final once the class kernels are through)
     double lo_v = 0.0, hi_v = 0.0;
     int lo_s = -1, hi_s = -1;
     const bool live = *status == 0;  // (else some records are missing: the whole pass is redone by the node-centric kernels)
@@ -1886,6 +1916,21 @@ static int ensure_h2(dcr_graph *g) {
     return DCR_OK;
 }
 
+// Share of its full-chip grid each class kernel is launched with, in percent: {split class, class M, wave classes 2, 1, 0}.
+// All five are persistent kernels that deal their units out up front; each sized for the whole chip, the ones launched first
+// hold the LDS and the others' workgroups queue behind them (round 3 timeline: the fifth kernel started 0.7 ms late).
+// DCR_H2_SHARE="l,m,s2,s1,s0" overrides (tuning aid, read at every pass).
+static int h2_share(int idx, int64_t n_nodes) {
+    static const int small_graph[5] = {100, 100, 100, 100, 100};
+    static const int large_graph[5] = {100, 100, 100, 100, 100};
+    int v = (n_nodes >= 400000 ? large_graph : small_graph)[idx];
+    if (const char *e = getenv("DCR_H2_SHARE")) {
+        int a[5];
+        if (sscanf(e, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) == 5 && a[idx] > 0 && a[idx] <= 400) v = a[idx];
+    }
+    return v;
+}
+
 template <int C>
 static void launch_h2_small(dcr_graph *g, const View &vw, const H2Retry &rt, hipStream_t st) {
     constexpr int H2_WPB = h2_wpb(C);
@@ -1907,6 +1952,7 @@ static void launch_h2_small(dcr_graph *g, const View &vw, const H2Retry &rt, hip
     int64_t grid = (int64_t)g->num_cu * per_cu;
     static const int64_t cap = getenv("DCR_H2_GRID") ? atoll(getenv("DCR_H2_GRID")) : 0;  // tuning aid: workgroups per CU
     if (cap > 0) grid = cap * g->num_cu;
+    grid = grid * h2_share(4 - C, g->n) / 100;
     const int64_t units = g->h2_last_count[C] >= 0 ? (int64_t)g->h2_last_count[C] + g->h2_last_count[C] / 32 + 8 : g->n;
     if (grid > (units + H2_WPB - 1) / H2_WPB) grid = (units + H2_WPB - 1) / H2_WPB;  // small graphs: no idle workgroups
     if (grid < 1) grid = 1;
@@ -1918,7 +1964,8 @@ template <int C, bool PARTS>
 static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, const H2Retry &rt, const int4 *units,
                             const int32_t *count, int64_t cap, int64_t units_hint, int is_retry, hipStream_t st) {
     int64_t grid = units_hint;
-    const int64_t most = (int64_t)g->num_cu * (C == 3 ? 3 : 1);
+    int64_t most = (int64_t)g->num_cu * (C == 3 ? 3 : 1);
+    if (!is_retry) most = most * h2_share(C == 3 ? 1 : 0, g->n) / 100;
     if (grid > most) grid = most;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((k_h2_block<h2_l1(C), h2_exs(C), h2_waves(C), PARTS>), dim3((unsigned)grid), dim3(64 * h2_waves(C)), 0,
@@ -2030,27 +2077,34 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         DCR_HIP(hipEventRecord(g->ev_fork, sS2));
         for (hipEvent_t ev : {g->ev_join[3], g->ev_join[2], g->ev_aux2, g->ev_fork}) DCR_HIP(hipStreamWaitEvent(g->stream, ev, 0));
     }
+    if (!g->ext_part) {
+        Ext *p = nullptr;
+        DCR_TRY(dev_alloc(&p, 2 * EXT_PART_BLOCKS));
+        g->ext_part = p;
+    }
+    int64_t fblocks = (sblocks + H2_FINAL_Q - 1) / H2_FINAL_Q;
+    if (fblocks > H2_FINAL_BLOCKS) fblocks = H2_FINAL_BLOCKS;
+    if (fblocks > EXT_PART_BLOCKS / 4) fblocks = EXT_PART_BLOCKS / 4;  // (a pair of partial extrema per WAVE)
+    if (fblocks < 1) fblocks = 1;
+    // the closing kernel, optimistically beside the retry launch (it steps aside when there is something to retry)
+    if (!serial) {
+        DCR_HIP(hipEventRecord(g->ev_aux, g->stream));
+        DCR_HIP(hipStreamWaitEvent(sT, g->ev_aux, 0));
+    }
+    hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fblocks), dim3(256), 0, sT, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
+                       (Ext *)g->ext_part + EXT_PART_BLOCKS, &g->dres->h2_retry, 0);
+    if (!serial) DCR_HIP(hipEventRecord(g->ev_join[3], sT));
     // nodes whose tables filled up in their class: zero their records, redo them with worst-case partitions
     hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
                        g->h2_rec);
     tk.retry_flag = 0x80000000u;
     launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
     hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 2)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status, 1);
-    {
-        if (!g->ext_part) {
-            Ext *p = nullptr;
-            DCR_TRY(dev_alloc(&p, 2 * EXT_PART_BLOCKS));
-            g->ext_part = p;
-        }
-        int64_t fblocks = (sblocks + H2_FINAL_Q - 1) / H2_FINAL_Q;
-        if (fblocks > H2_FINAL_BLOCKS) fblocks = H2_FINAL_BLOCKS;
-        if (fblocks > EXT_PART_BLOCKS / 4) fblocks = EXT_PART_BLOCKS / 4;  // (a pair of partial extrema per WAVE)
-        if (fblocks < 1) fblocks = 1;
-        hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
-                           (Ext *)g->ext_part + EXT_PART_BLOCKS);
-        g->ext_part_n = (int)fblocks * 4;
-        g->ext_part_valid = true;  // (dropped again by the caller if the pass reports a failure, and by every edit)
-    }
+    if (!serial) DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[3], 0));
+    hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
+                       (Ext *)g->ext_part + EXT_PART_BLOCKS, &g->dres->h2_retry, 1);
+    g->ext_part_n = (int)fblocks * 4;
+    g->ext_part_valid = true;  // (dropped again by the caller if the pass reports a failure, and by every edit)
     DCR_HIP(hipGetLastError());
     static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;
 #ifdef H2_PROF
