@@ -106,17 +106,31 @@ __device__ inline int h2_part(unsigned key, int nparts) {
 }
 
 // ---- the bitmaps ------------------------------------------------------------------------------------------------------
-// B1: one bit per 2-hop entry (seen); B2 (a quarter of the bits, indexed by the same hash): seen again
-__device__ inline void h2_mark(unsigned *b1, unsigned *b2, unsigned b) {  // sweep A: one returning LDS atomic per entry
-    const unsigned m = 1u << (b & 31u);
-    const unsigned old = atomicOr(&b1[b >> 5], m);
-    if (old & m) {
-        const unsigned c = b >> 2;
-        atomicOr(&b2[c >> 5], 1u << (c & 31u));
-    }
+// B1: TWO bits per 2-hop entry in ONE 32-bit word — the word and the first bit from the first hash, the second bit from an
+// independent one (a blocked Bloom filter); "seen" = both were set; B2 (a quarter of the bits, indexed by the first hash):
+// seen again.  (Round 4: with one bit per entry in 16, one key in sixteen that occurs ONCE found its bit set by another key
+// and went down the exact path — half of all exact-path items, and the exact tables of the heaviest nodes of every wave class
+// ran at 85 % load; with two bits a singleton needs both taken: 1-2 %.  Both bits go in ONE atomic: two atomics were tried
+// first and were WRONG — two lanes holding the same key in one instruction are served in an order of the hardware's choosing,
+// not necessarily the same for the second atomic, and then neither lane sees both bits set.)
+#ifndef H2_TWO_HASH
+#define H2_TWO_HASH 1
+#endif
+__device__ inline unsigned h2_mul24c(unsigned key) {  // a third multiplier: independent of the bitmaps' first hash and of the tables'
+    unsigned prod;
+    asm("v_mul_u32_u24 %0, 0xb55a4f, %1" : "=v"(prod) : "v"(key));
+    return prod;
 }
-__device__ inline void h2_seed(unsigned *b1, unsigned *b2, unsigned b) {  // a member of N(u): every occurrence is exact
-    atomicOr(&b1[b >> 5], 1u << (b & 31u));
+// the entry's bits inside word (bit index >> 5) of B1
+__device__ inline unsigned h2_word_mask(unsigned key, unsigned b) {
+    unsigned m = 1u << (b & 31u);
+    if (H2_TWO_HASH) m |= 1u << ((h2_mul24c(key) >> 19) & 31u);
+    return m;
+}
+template <int L1>
+__device__ inline void h2_seed(unsigned *b1, unsigned *b2, unsigned key) {  // a member of N(u): every occurrence is exact
+    const unsigned b = h2_bit<L1>(key);
+    atomicOr(&b1[b >> 5], h2_word_mask(key, b));
     const unsigned c = b >> 2;
     atomicOr(&b2[c >> 5], 1u << (c & 31u));
 }
@@ -132,14 +146,14 @@ __device__ inline void h2_mark4(unsigned *b1, unsigned *b2, const unsigned kk[4]
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         b[jj] = h2_bit<L1>(kk[jj]);
-        m[jj] = ((valid >> jj) & 1u) << (b[jj] & 31u);  // (no bit for an entry that does not count: the atomic changes nothing)
+        m[jj] = ((valid >> jj) & 1u) ? h2_word_mask(kk[jj], b[jj]) : 0u;  // (no bit for an entry that does not count: the atomic changes nothing)
     }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) old[jj] = atomicOr(&b1[b[jj] >> 5], m[jj]);
     unsigned any = 0u;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        old[jj] &= m[jj];
+        old[jj] = (m[jj] != 0u && (old[jj] & m[jj]) == m[jj]) ? 1u : 0u;
         any |= old[jj];
     }
     if (any) {
@@ -443,7 +457,7 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
         rk = make_int2(0, 0);
     } else {
         if (!row_ok(g, rk, 32, k, u)) rk = make_int2(0, 0);
-        h2_seed(s->a.b1, s->b2, h2_bit<L1>((unsigned)k));
+        h2_seed<L1>(s->a.b1, s->b2, (unsigned)k);
     }
     const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
     int poff_lane;
@@ -583,7 +597,7 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
     h2_wave_sync();
     H2_STAMP(4)
     if (__ballot(full) != 0ull) {  // a table or the list filled up: nothing is published, the node is redone elsewhere
-        if (lane == 0) h2_retry_push(rt, u, ru.y, EXS == 128 ? 0 : EXS == 256 ? 1 : 2);
+        if (lane == 0) h2_retry_push(rt, u, ru.y, L1 == 14 ? 0 : L1 == 15 ? 1 : 2);
         h2_wave_sync();
         return;
     }
@@ -1306,7 +1320,7 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
         const int sl = h2_insert<EXS>(t.key, (unsigned)k);
         if (sl < 0) *t.full = 1;
         else h2_cnt_flag(t.cnt, sl);
-        h2_seed(t.b1, t.b2, h2_bit<L1>((unsigned)k));
+        h2_seed<L1>(t.b1, t.b2, (unsigned)k);
     }
     __syncthreads();
     // sweep A
@@ -1444,7 +1458,7 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
             const int s = h2_insert<EXS>(t.key, (unsigned)k);
             if (s < 0) *t.full = 1;
             else h2_cnt_flag(t.cnt, s);
-            h2_seed(t.b1, t.b2, h2_bit<L1>((unsigned)k));
+            h2_seed<L1>(t.b1, t.b2, (unsigned)k);
         }
     }
     __syncthreads();
