@@ -1883,16 +1883,29 @@ bool h2_grow_pools(dcr_graph *g) {
     return true;
 }
 
+// Which engine takes a full Balanced Forman pass (DCR_PASS=h2 / nc force one).  Round 4: two fitted cost models instead of two
+// thresholds from one graph family.  tools/probe_engine_choice.py times both engines on 31 graphs of four families
+// (preferential attachment m = 2 / 5 / 10 / 20 at 2k-500k nodes, uniform random graphs of mean degree 6-20, grids, a dense
+// random graph; profiles/r04_engine_choice.txt) and the pass times (ms, MI355X) are, within 11-15 % on average,
+//     node-centric:  0.127 + 0.438e-6 E + 1.135e-9 E s + 0.201 min(dmax, 400) / 400
+//     two-hop:       0.190 + 1.193e-6 n + 4.498e-9 (sum d^2) (1 + 60 s / n)
+// with E edges, n nodes, s = sum d^2 / n (the mean size of a 2-hop neighbourhood), dmax the largest degree: the node-centric
+// engine streams about s entries per edge and loses a tenth of a millisecond to the tail of its hub units; the two-hop
+// engine reads sum d^2 entries per pass, pays per node, and slows down as neighbourhoods overlap (s / n: the share of the
+// graph a 2-hop neighbourhood covers — repeated keys, fuller tables, more partitions).  The two-hop engine is taken when
+// its estimate is the lower one, and never for graphs under 3,000 nodes (both engines are launch-bound there and the
+// node-centric one has fewer launches), for s / n above 0.045 (measured 1.5-5 x slower there) or hubs beyond its tables.
 bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental) {
     if (curv_type != DCR_CURV_BFC || incremental || g->max_deg_bound > H2_MAXDEG || g->cap_total >= (int64_t)1 << 30) return false;
     if (g->pass_impl == 3) return true;
-    // automatic: this engine pays off while a node's 2-hop neighbourhood (sum of its neighbours' degrees, on average
-    // sum d^2 / n) is a small part of the graph, so that few of its keys repeat; on small dense graphs nearly all do, the
-    // wave classes' tables fill up and the nodes are redone one class up (measured, tools/probe_engines.py, pass ms
-    // node-centric / two-hop: 2,485 nodes x 2: 0.27 / 0.20; 2,500 x 10: 0.46 / 3.1; 10,000 x 10: 0.52 / 1.5; 30,000 x 10:
-    // 0.77 / 0.75; 100,000 x 10: 1.94 / 1.36; 300,000 x 10: 5.6 / 3.6)
-    static const double max_share = getenv("DCR_H2_MAX_SHARE") ? atof(getenv("DCR_H2_MAX_SHARE")) : 0.03;
-    return g->pass_impl == 0 && g->n > 0 && g->sum_deg2 <= max_share * (double)g->n * (double)g->n;
+    if (g->pass_impl != 0 || g->n < 3000) return false;
+    static const double max_share = getenv("DCR_H2_MAX_SHARE") ? atof(getenv("DCR_H2_MAX_SHARE")) : 0.045;
+    const double n = (double)g->n, E = (double)g->n_edges, sd2 = g->sum_deg2, s = sd2 / n, share = s / n;
+    if (share > max_share) return false;
+    const double dmax = (double)(g->max_deg_bound < 400 ? g->max_deg_bound : 400);
+    const double t_nc = 0.127 + 0.438e-6 * E + 1.135e-9 * E * s + 0.201 * dmax / 400.0;
+    const double t_h2 = 0.190 + 1.193e-6 * n + 4.498e-9 * sd2 * (1.0 + 60.0 * share);
+    return t_h2 < t_nc;
 }
 
 static int ensure_h2(dcr_graph *g) {

@@ -1,0 +1,56 @@
+"""Which engine the automatic choice (csrc/dcr_bfc_h2.hip: h2_can_take) picks for a full Balanced Forman pass, against both
+engines forced, on several graph families (timing only; parity on such families is tests/fuzz_parity.py).
+-> one line per graph: n, E, sum d^2 / n^2, largest degree, node-centric ms, two-hop ms, chosen engine, chosen / better.
+usage (GPU box): python tools/probe_engine_choice.py > gpurun_out/r04_engine_choice.txt"""
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, 'discrete-curvature-rewiring_amd')]
+from dcr import synthetic
+from dcr.graph import DcrGraph
+
+
+def timed(ei, n, mode, reps):
+    if mode:
+        os.environ['DCR_PASS'] = mode
+    else:
+        os.environ.pop('DCR_PASS', None)
+    G = DcrGraph(ei, n)
+    G.curvature_pass('bfc')
+    G.curvature_pass('bfc')
+    G.profile_reset()
+    for _ in range(reps):
+        G.curvature_pass('bfc')
+    ms, cnt = G.profile_read()
+    eng = G.pass_engine()
+    G.close()
+    return ms / cnt, eng
+
+
+def run(name, ei, n):
+    deg = np.bincount(ei[0], minlength=n).astype(np.float64)
+    E = ei.shape[1] // 2
+    reps = 20 if E < 300000 else 8
+    nc, _ = timed(ei, n, 'nc', reps)
+    h2, e2 = timed(ei, n, 'h2', reps)
+    auto, ea = timed(ei, n, None, reps)
+    best = min(nc, h2)
+    chosen = h2 if ea == 'two-hop' else nc
+    print(f'{name:38s} n={n:8d} E={E:9d} sum d^2/n^2={float((deg ** 2).sum()) / n / n:9.5f} sum d^2/n={float((deg ** 2).sum()) / n:9.1f} '
+          f'max deg {int(deg.max()):6d} | node-centric {nc:8.3f} ms  two-hop {h2:8.3f} ms ({e2}) | chosen {ea:12s} {auto:8.3f} ms '
+          f'| chosen / better {chosen / best:5.2f}', flush=True)
+
+
+rng = np.random.Generator(np.random.PCG64(3))
+for n, m in ((2485, 2), (2120, 2), (5000, 2), (20000, 2), (100000, 2), (500000, 2), (5000, 5), (20000, 5), (100000, 5),
+             (2500, 10), (5000, 10), (10000, 10), (20000, 10), (30000, 10), (50000, 10), (100000, 10), (300000, 10), (5000, 20), (20000, 20), (50000, 20),
+             (100000, 20)):
+    run(f'preferential attachment m={m}', *synthetic.powerlaw_graph(n, m, seed=12345 + n + m))
+for n, d in ((5000, 10), (30000, 10), (100000, 10), (30000, 20), (100000, 20), (300000, 6)):
+    ex = rng.integers(0, n, size=(2, n * d // 2))
+    run(f'uniform random, mean degree {d}', synthetic.coalesced_edge_index(ex[0], ex[1], n), n)
+for r in (50, 200, 1000):
+    run(f'grid {r} x {r}', *synthetic.grid_graph(r, r))
+n = 3000
+ex = rng.integers(0, n, size=(2, 300000))
+run('dense random, mean degree ~190', synthetic.coalesced_edge_index(ex[0], ex[1], n), n)
