@@ -247,18 +247,50 @@ class ShardedGCN(torch.nn.Module):
         log_softmax = torch.nn.functional.log_softmax
         return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)
 
+    def _column_block(self, q):
+        """(rowptr, col, val) of this rank's rows of Â restricted to the columns of rank q's block, renumbered 0..per-1."""
+        csr, lo = self.csr, q * self.per
+        keep = (csr.col >= lo) & (csr.col < lo + self.per)
+        cs = torch.zeros(keep.numel() + 1, dtype=torch.int64, device=keep.device)
+        torch.cumsum(keep, 0, out=cs[1:])
+        return cs[csr.rowptr].contiguous(), (csr.col[keep] - lo).to(csr.col.dtype).contiguous(), csr.val[keep].contiguous()
+
     def propagated_input_local(self, x_local):
-        """Rows of Â·X owned by this rank, computed once per (x_local, graph): all-gather X, one local SpMM."""
+        """Rows of Â·X owned by this rank, computed once per (x_local, graph).  Round 4: block-streamed — the peers' blocks of X
+        come one at a time into ONE buffer of N / P rows (a broadcast from their owner) and each adds its column range,
+        Â_p[:, block q] · X_q, to the result: the transient is two blocks (the buffer and a product), not the whole N x F
+        matrix on every rank (1 GB per rank at the 1M-node bench shape, 8 GB of gathers at eight ranks before the first
+        epoch).  ``DCR_DP_SETUP=gather`` restores the one-shot all-gather (same result to rounding: the row sums are formed
+        block by block here)."""
         # (the keyed tensor is held in _ax_ref: its storage cannot be recycled while the entry lives)
         key = (x_local.data_ptr(), x_local._version, tuple(x_local.shape), tuple(x_local.stride()))
         if key != getattr(self, '_ax_key', None):
             with torch.no_grad():
-                x_full = _GatherRows.apply(x_local.contiguous(), self.n, self.per, self.group)
-                from models.gcn import spmm
-                self._ax = spmm(self.csr.rowptr, self.csr.col, self.csr.val, x_full.contiguous(), self.csr.n_rows)
+                if os.environ.get('DCR_DP_SETUP', 'stream') == 'gather' or self.world == 1:
+                    x_full = _GatherRows.apply(x_local.contiguous(), self.n, self.per, self.group)
+                    self._ax = spmm(self.csr.rowptr, self.csr.col, self.csr.val, x_full.contiguous(), self.csr.n_rows)
+                else:
+                    mine = _pad_rows(x_local, self.per).contiguous()
+                    buf = torch.empty_like(mine)
+                    acc = torch.zeros((self.csr.n_rows, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+                    for q in range(self.world):
+                        src = dist.get_global_rank(self.group, q) if self.group is not None else q
+                        block = mine if q == self.rank else buf
+                        dist.broadcast(block, src=src, group=self.group)
+                        rp, ci, va = self._column_block(q)
+                        if ci.numel():
+                            acc += spmm(rp, ci, va, block, self.csr.n_rows)
+                        del rp, ci, va
+                    self._ax = acc
             self._ax_key = key
             self._ax_ref = x_local
         return self._ax
+
+    def setup_transient_bytes(self, n_features, itemsize=4):
+        """Peak device memory the set-up of Â_p·X holds beyond its result, per rank: the receive buffer and one block product
+        (block-streamed), against the whole gathered matrix (DCR_DP_SETUP=gather)."""
+        streamed = (self.per + self.csr.n_rows) * n_features * itemsize
+        return {'streamed': streamed, 'gathered': self.n * n_features * itemsize}
 
     def _grads_are_views(self):
         base = self._flat.data_ptr()

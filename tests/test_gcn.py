@@ -265,6 +265,68 @@ def test_data_parallel_ranks_gloo(world):
         assert err_fwd < TOL and err_w < TOL and dacc < 1e-6, (rank, err_fwd, err_w, dacc)
 
 
+def _dp_world8_worker(rank, world, port, ret):
+    """One of eight gloo ranks on a 20k-node power-law graph: degree-dealt partition, block-streamed set-up, logits of the
+    sharded model against the single-process model (models/gcn.py:32-44) and one training step's weights."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from models import gcn as gcn_mod
+    from models.gcn import GCN
+    from models.gcn_dp import ShardedGCN, balanced_partition
+    gcn_mod.set_aggregate_backend('torch')
+    ei_np, n = synthetic.powerlaw_graph(20000, 5, seed=17)
+    ei = torch.from_numpy(ei_np)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 24, generator=g)
+    y = torch.randint(0, 5, (n,), generator=g)
+    r = torch.rand(n, generator=g)
+    data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=r < 0.3, val_mask=(r >= 0.3) & (r < 0.6))
+    torch.manual_seed(4)
+    ref = GCN(Dataset(data, 5), hidden=[16], dropout=0.0)
+    torch.manual_seed(4)
+    base = GCN(Dataset(data, 5), hidden=[16], dropout=0.0)
+    sh = ShardedGCN(base, ei, n)
+    owner, index, per = balanced_partition(ei, n, world)
+    deg = torch.bincount(ei[0], minlength=n)
+    nnz_share = float((deg[owner == rank] + 1).sum()) / float((deg + 1).sum()) * world     # (+1: the self loop of every node)
+    xl, yl, tl = sh.shard(data.x), sh.shard(data.y), sh.shard(data.train_mask)
+    ref.eval(), sh.eval()
+    with torch.no_grad():
+        want = ref(data).index_select(0, sh.owned)
+        got = sh(xl)[:sh.owned.numel()]
+    err_fwd = (got - want).abs().max().item()
+    ropt = torch.optim.Adam(ref.parameters(), lr=0.01)
+    opt = torch.optim.Adam(base.parameters(), lr=0.01)
+    ref.train()
+    ropt.zero_grad()
+    torch.nn.functional.nll_loss(ref(data)[data.train_mask], data.y[data.train_mask]).backward()
+    ropt.step()
+    sh.train_step(opt, xl, yl, tl, int(data.train_mask.sum()))
+    err_w = max((a - b).abs().max().item() for a, b in zip(base.parameters(), ref.parameters()))
+    tr = sh.setup_transient_bytes(24)
+    ret[rank] = (err_fwd, err_w, nnz_share, tr['streamed'] / tr['gathered'])
+    dist.destroy_process_group()
+
+
+def test_data_parallel_eight_ranks_gloo():
+    """Eight ranks (the width of BASELINE.json's configs[4]) on the CPU: every rank's share of the non-zeros within 2 % of
+    1 / 8, logits within 1e-5 of the single-process model, weights after a step too; the set-up transient is a quarter of the
+    gathered matrix."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_world8_worker, args=(8, _free_port(), ret), nprocs=8, join=True)
+    assert len(ret) == 8
+    for rank, (err_fwd, err_w, share, transient) in ret.items():
+        assert err_fwd < TOL and err_w < TOL, (rank, err_fwd, err_w)
+        assert 0.98 < share < 1.02, (rank, share)
+        assert transient <= 0.26, (rank, transient)
+
+
 # ----------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize('feat', [1, 7, 16, 30, 64, 128, 130, 256])

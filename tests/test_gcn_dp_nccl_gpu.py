@@ -1,4 +1,5 @@
-"""Two RCCL ranks on two MI355X (skipped on a one-GPU box): the captured data-parallel epoch against the eager one.
+"""Two, four and eight RCCL ranks, one per MI355X (each skipped where fewer GPUs are visible: always on a one-GPU box): the
+captured data-parallel epoch against the eager one.
 Every other N > 1 test runs on gloo; this is the one that exercises RCCL collectives inside a captured HIP graph with more
 than one rank (models/gcn_dp.py::GraphedShardedEpoch; the model it shards is models/gcn.py:32-44)."""
 import os
@@ -11,17 +12,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_nccl_ranks_graphed_epoch_equals_eager():
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_nccl_ranks_graphed_epoch_equals_eager(world):
     import torch
-    if torch.cuda.device_count() < 2:      # (counting devices does not initialise the GPU in this process)
-        pytest.skip('needs two GPUs')
+    if torch.cuda.device_count() < world:  # (counting devices does not initialise the GPU in this process)
+        pytest.skip(f'needs {world} GPUs')
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp_nccl_worker.py')
     procs = []
-    for r in range(2):                     # fresh child processes, one per rank
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+    for r in range(world):                 # fresh child processes, one per rank
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
