@@ -3,7 +3,8 @@
   configs[3]  Citeseer shape (N = 2,120, F = 3,703, hidden 64, 6 classes; hyper-parameters utils/hyperparams.py 'Citeseer')
               on a graph that has been through rewire('bfc', 84, 0.22, 180): logits and gradients within 1e-5 of a
               dense fp64 evaluation of models/gcn.py:32-44 with GCNConv's published formula;
-  configs[4]  S1M (N = 1,000,000, E = 10 M, F = 256, hidden 128, 16 classes): logits within 1e-5 of an fp64 evaluation
+  configs[4]  S1M (N = 1,000,000, E = 10 M, F = 256, hidden 128, 16 classes) on the REWIRED graph (round 4: three SDRF
+              iterations, edge list equal to the C oracle's, tests/golden/sdrf_s1m_oracle.json): logits within 1e-5 of an fp64 evaluation
               (edge-list scatter, written here, independent of the product's CSR builder) on every row, and the
               row-partitioned two-rank model equal to the single-process one on sampled rows.
 
@@ -75,12 +76,25 @@ def test_citeseer_shape_on_a_rewired_graph_logits_and_gradients():
 
 
 def _s1m_inputs(dev):
+    """configs[4] as BASELINE.json words it: the 1M-node / 10M-edge graph REWIRED (rewire('bfc', ...) with the loop parameters of
+    tests/golden/sdrf_s1m_oracle.json: three iterations, tau = 163, bound 0.95, numpy seed 0), checked against the edge list the
+    C oracle recorded for the same run (SHA-256 of the int64 edge_index), then the features."""
+    import hashlib
+    import json
     from dcr import synthetic
-    path = '/tmp/dcr_s1m_edge_index.npy'
+    path = '/tmp/dcr_s1m_rewired_edge_index.npy'
     if os.path.exists(path):
         ei = np.load(path)
     else:
-        ei, _ = synthetic.powerlaw_graph(1_000_000, 10, seed=12345)
+        from dcr.data import Data
+        from rewiring.rewire import rewire
+        fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sdrf_s1m_oracle.json')))
+        raw, _ = synthetic.powerlaw_graph(fix['graph']['n'], fix['graph']['m'], seed=fix['graph']['seed'])
+        np.random.seed(fix['numpy_seed'])
+        ei = rewire(Data(edge_index=torch.from_numpy(raw), num_nodes=fix['graph']['n']), 'bfc', len(fix['iterations']),
+                    fix['removal_bound'], fix['tau']).numpy()
+        assert hashlib.sha256(np.ascontiguousarray(ei).tobytes()).hexdigest() == fix['final']['edge_index_sha256']
+        assert ei.shape[1] // 2 == fix['final']['edges'] != raw.shape[1] // 2
         np.save(path, ei)
     n = 1_000_000
     g = torch.Generator(device=dev).manual_seed(0)
