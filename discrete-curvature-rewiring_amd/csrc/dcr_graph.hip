@@ -462,6 +462,7 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_TRY(alloc_layout(g, tot));
     DCR_TRY(dev_alloc(&g->dres, 1));
     DCR_TRY(dev_alloc(&g->imp_stats, 1));
+    DCR_HIP(hipMemsetAsync(g->imp_stats, 0xFF, sizeof(*g->imp_stats), g->stream));  // (pos_x_in_y = -1)
     DCR_TRY(dev_alloc(&g->draw_bsum, 256));
     DCR_TRY(dev_alloc(&g->dirty, n + 4));  // OR-ed through 32-bit words
     DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(n > 0 ? n : 1), g->stream));

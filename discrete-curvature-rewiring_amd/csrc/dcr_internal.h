@@ -177,8 +177,10 @@ struct ImpStats {  // per (x,y) statistics for the improvement kernels; lives in
     int32_t table_mask;
     int32_t deg_min_is_one;
     int32_t pos_x_in_y;  // position of x inside row y
-    int32_t pad_;
+    int32_t done_rows;   // workgroups of k_imp_rows_count that are through (the last one closes the stage: statistics, scan)
     double before;
+    int32_t done_draw;   // the same for k_draw_partial (the last one picks)
+    int32_t pad_;
 };
 
 }  // namespace dcr
@@ -276,6 +278,7 @@ struct dcr_graph {
     int32_t *imp_table = nullptr;  // hash keys
     int32_t *imp_posx = nullptr, *imp_posy = nullptr;
     int64_t imp_table_cap = 0;
+    bool imp_table_dirty = true;   // the table is not all-empty (fresh allocation, or a pipeline that did not reach its last kernel)
     int32_t *imp_c1 = nullptr, *imp_c2 = nullptr;  // per position in row x / row y
     double *imp_b = nullptr, *imp_c = nullptr;     // class B / C improvements per position
     int32_t *imp_rowcount = nullptr, *imp_rowoff = nullptr;

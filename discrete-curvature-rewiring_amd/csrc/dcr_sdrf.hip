@@ -221,116 +221,58 @@ struct ImpBuf {
     ImpStats *st;
 };
 
-// K1a: insert row x.  grid-stride, any grid.
-__global__ void k_imp_insert_x(RowView g, ImpBuf B, int x, int y, unsigned mask) {
-    const int2 rx = g.rowinfo[x];
-    for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < rx.y; a += gridDim.x * blockDim.x) {
-        const int k = g.col[rx.x + a];
-        if (k == y) {
-            B.clsx[a] = 2;
-            continue;
+// K1 (round 4: one launch for both rows; the pipeline was eleven launch-bound kernels, 45 us of launch gaps in 115): row x and
+// row y go into the table concurrently — a key met in both rows (a triangle node) is inserted by whichever thread comes first
+// and found by the other; which of the two it was does not matter, posx / posy are separate arrays.  The classes (0: in its
+// own row only, 1: in both, 2: the other endpoint) are resolved by the next kernel, when the table is complete.
+__global__ void k_imp_insert(RowView g, ImpBuf B, int x, int y, unsigned mask) {
+    const int2 rx = g.rowinfo[x], ry = g.rowinfo[y];
+    const int total = rx.y + ry.y;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const bool isx = t < rx.y;
+        const int p = isx ? t : t - rx.y;
+        const int k = g.col[(isx ? rx.x : ry.x) + p];
+        if (isx) {
+            B.c1[p] = 0;
+            B.clsx[p] = k == y ? 2 : 0;
+        } else {
+            B.c2[p] = 0;
+            B.clsy[p] = k == x ? 2 : 0;
+            if (k == x) B.st->pos_x_in_y = p;
         }
-        B.clsx[a] = 0;
+        if (k == (isx ? y : x)) continue;  // the endpoints themselves are never in the table
         unsigned h = g_hash((unsigned)k, mask);
         while (true) {
             const unsigned old = atomicCAS((unsigned *)&B.keys[h], T_EMPTY, (unsigned)k);
-            if (old == T_EMPTY) break;
+            if (old == T_EMPTY || old == (unsigned)k) break;
             h = (h + 1) & mask;
         }
-        B.posx[h] = a;
+        if (isx) B.posx[h] = p;
+        else B.posy[h] = p;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int2 ry = g.rowinfo[y];
         B.st->x = x;
         B.st->y = y;
         B.st->dx = rx.y;
         B.st->dy = ry.y;
         B.st->table_mask = (int)mask;
         B.st->T = 0;
-        B.st->pos_x_in_y = -1;
         B.st->deg_min_is_one = (rx.y < ry.y ? rx.y : ry.y) == 1;
+        B.st->done_rows = 0;
+        B.st->done_draw = 0;
+        // (pos_x_in_y: written above by the thread that meets x in row y; reset to -1 by the pipeline's last kernel)
     }
 }
 
-// K1b: insert row y; a key already present came from row x: a triangle node.
-__global__ void k_imp_insert_y(RowView g, ImpBuf B, int x, int y, unsigned mask) {
-    const int2 ry = g.rowinfo[y];
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < ry.y; b += gridDim.x * blockDim.x) {
-        const int k = g.col[ry.x + b];
-        if (k == x) {
-            B.clsy[b] = 2;
-            B.st->pos_x_in_y = b;
-            continue;
-        }
-        unsigned h = g_hash((unsigned)k, mask);
-        int cls = 0;
-        while (true) {
-            unsigned e = __hip_atomic_load((unsigned *)&B.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (e == T_EMPTY) {
-                e = atomicCAS((unsigned *)&B.keys[h], T_EMPTY, (unsigned)k);
-                if (e == T_EMPTY) break;
-            }
-            if (e == (unsigned)k) {
-                cls = 1;
-                break;
-            }
-            h = (h + 1) & mask;
-        }
-        B.posy[h] = b;
-        B.clsy[b] = cls;
-        if (cls == 1) {
-            B.clsx[B.posx[h]] = 1;  // posx was written by the previous kernel
-            atomicAdd(&B.st->T, 1);
-        }
-    }
-}
-
-// K0: empty table, zero counters
-__global__ void __launch_bounds__(256) k_imp_clear(ImpBuf B, int64_t ts, int n1, int n2) {
+// empty table (only after a fresh allocation or a pipeline that did not run to its end: k_imp_emit leaves the table empty)
+__global__ void __launch_bounds__(256) k_imp_clear(ImpBuf B, int64_t ts) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = tid; i < ts; i += nth) {
         B.keys[i] = -1;
         B.posx[i] = -1;
         B.posy[i] = -1;
     }
-    for (int64_t i = tid; i < n1; i += nth) B.c1[i] = 0;
-    for (int64_t i = tid; i < n2; i += nth) B.c2[i] = 0;
-}
-
-// K2: c1[a] for a in DX by streaming row i_a; every hit also bumps c2 of the DY node it lands on.
-__global__ void __launch_bounds__(256) k_imp_count(RowView g, ImpBuf B, int x, unsigned mask) {
-    const int2 rx = g.rowinfo[x];
-    const int lane = threadIdx.x & 63;
-    const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (a >= rx.y) return;
-    if (B.clsx[a] != 0) {
-        if (lane == 0) B.c1[a] = 0;
-        return;
-    }
-    const int i = g.col[rx.x + a];
-    const int2 ri = g.rowinfo[i];
-    int c = 0;
-    for (int base = 0; base < ri.y; base += 256) {
-        int w[4], h[4];
-        bool in[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int t = base + 64 * q + lane;
-            in[q] = t < ri.y;
-            w[q] = in[q] ? g.col[ri.x + t] : -1;
-        }
-        g_find4(B.keys, mask, w, in, h);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bool hit = false;
-            if (h[q] >= 0 && B.posx[h[q]] < 0) {  // in N(y) only (x and y are never in the table)
-                hit = true;
-                atomicAdd(&B.c2[B.posy[h[q]]], 1);
-            }
-            c += __popcll(__ballot(hit));
-        }
-    }
-    if (lane == 0) B.c1[a] = c;
+    if (tid == 0) B.st->pos_x_in_y = -1;
 }
 
 struct Mx {
@@ -407,16 +349,25 @@ __device__ inline void block_stats(const int32_t *c, int n, int *cnt_pos, Mx *mx
     *mx = m;
 }
 
-// K3: |sq1|, |sq2|, maxima (with multiplicity and runner-up) and the base curvature.
-__global__ void __launch_bounds__(1024) k_imp_stats(ImpBuf B, int curv_type) {
-    __shared__ int shi[16 * 4];
+// |sq1|, |sq2|, maxima (with multiplicity and runner-up), triangles and the base curvature; called by one whole workgroup
+__device__ inline void imp_close_stats(ImpBuf B, int curv_type, int *shi) {
     ImpStats *st = B.st;
     const int dx = st->dx, dy = st->dy;
     int s1, s2;
     Mx m1, m2;
     block_stats(B.c1, dx, &s1, &m1, shi);
     block_stats(B.c2, dy, &s2, &m2, shi);
+    // triangles: the members of row x that are in row y too (class 1)
+    int T = 0;
+    for (int a = threadIdx.x; a < dx; a += blockDim.x) T += B.clsx[a] == 1;
+    for (int off = 32; off > 0; off >>= 1) T += __shfl_xor(T, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = T;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        T = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) T += shi[w];
+        st->T = T;
         st->s1 = s1;
         st->s2 = s2;
         st->max1 = m1.m < 0 ? 0 : m1.m;
@@ -429,12 +380,13 @@ __global__ void __launch_bounds__(1024) k_imp_stats(ImpBuf B, int curv_type) {
         double before;
         switch (curv_type) {
             case DCR_CURV_1D: before = (double)(4 - dx - dy); break;
-            case DCR_CURV_AUGMENTED: before = (double)(4 - dx - dy + 3 * st->T); break;
-            case DCR_CURV_HAANTJES: before = (double)st->T; break;
-            default: before = bfc_value(dx, dy, st->T, s1, s2, gam);
+            case DCR_CURV_AUGMENTED: before = (double)(4 - dx - dy + 3 * T); break;
+            case DCR_CURV_HAANTJES: before = (double)T; break;
+            default: before = bfc_value(dx, dy, T, s1, s2, gam);
         }
         st->before = before;
     }
+    __syncthreads();
 }
 
 // K4: class B (i == x, j = y_nb[b] in DY) for waves [0,dy), class C (j == y, i = x_nb[a] in DX) for waves [dy,dy+dx).
@@ -512,33 +464,71 @@ __global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int 
     out[p] = after - st.before;
 }
 
-// K5: per candidate row a (i = x_nb[a], a == dx: i = x): which j in y_nb + [y] are ruled out
-// (i == j or has_edge(i,j), sdrf_no_cuda.py:35), as a bitmap, plus the count of admitted ones.
-__global__ void __launch_bounds__(256) k_imp_rows(RowView g, ImpBuf B, int x, int y, unsigned mask, int words) {
+// K2 (round 4: one launch for what were k_imp_count, k_imp_stats, k_imp_rows and k_imp_scan).  One workgroup per candidate row
+// a (i = x_nb[a]; a == dx: i = x) streams row i ONCE: every entry is looked up in the table; an entry that is in row y only is
+// a 4-cycle x - i - w - y (c1[a] grows, and c2 of the node it lands on: bfc_naive.py:26-29,36-37), an entry that is in
+// row y at all rules the pair (i, that neighbour) out (sdrf_no_cuda.py:35: has_edge) — a bit in the row's bitmap, as do i == j,
+// w == y and w == x.  The workgroup also settles the classes of its row and of a share of row y.  The LAST workgroup to
+// finish closes the stage: statistics of c1 / c2, triangles, base curvature, exclusive scan of the rows' candidate counts.
+__global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int x, int y, unsigned mask, int words, int curv_type,
+                                                         DevResult *res) {
     extern __shared__ uint32_t bits[];
-    __shared__ int cnt_sh;
-    const ImpStats st = *B.st;
-    const int pos_x_in_y = st.pos_x_in_y;  // x is an endpoint, so it is not in the table
+    __shared__ int cnt_sh, c1_sh, cls_sh, last_sh;
+    __shared__ int shi[16 * 4];
+    ImpStats *stp = B.st;
+    const int dx = stp->dx, dy = stp->dy;
+    const int pos_x_in_y = stp->pos_x_in_y;  // x is an endpoint, so it is not in the table
     const int a = blockIdx.x;
-    const int i = a < st.dx ? g.col[g.rowinfo[x].x + a] : x;
+    const int2 rx = g.rowinfo[x], ry = g.rowinfo[y];
+    const int i = a < dx ? g.col[rx.x + a] : x;
     for (int w = threadIdx.x; w < words; w += blockDim.x) bits[w] = 0u;
-    if (threadIdx.x == 0) cnt_sh = 0;
+    if (threadIdx.x == 0) {
+        cnt_sh = 0;
+        c1_sh = 0;
+        // class of row a: 2 = the other endpoint, 1 = also in row y (a triangle node), 0 = in row x only
+        int cls = 3;
+        if (a < dx) {
+            if (i == y) cls = 2;
+            else {
+                const int h = g_find(B.keys, mask, i);
+                cls = (h >= 0 && B.posy[h] >= 0) ? 1 : 0;
+            }
+            B.clsx[a] = cls;
+        }
+        cls_sh = cls;
+    }
+    // classes of a share of row y (every position is settled by exactly one workgroup)
+    for (int b = a + (int)threadIdx.x * (int)gridDim.x; b < dy; b += (int)blockDim.x * (int)gridDim.x) {
+        const int k = g.col[ry.x + b];
+        if (k != x) {
+            const int h = g_find(B.keys, mask, k);
+            B.clsy[b] = (h >= 0 && B.posx[h] >= 0) ? 1 : 0;
+        }
+    }
     __syncthreads();
+    const bool counting = curv_type == DCR_CURV_BFC && cls_sh == 0;
     const int2 ri = g.rowinfo[i];
+    int c = 0;
     for (int t = threadIdx.x; t < ri.y; t += blockDim.x) {
         const int w = g.col[ri.x + t];
         int b = -1;
-        if (w == y) b = st.dy;
+        if (w == y) b = dy;
         else if (w == x) b = pos_x_in_y;
         else {
             const int h = g_find(B.keys, mask, w);
-            if (h >= 0) b = B.posy[h];
+            if (h >= 0) {
+                b = B.posy[h];
+                if (counting && b >= 0 && B.posx[h] < 0) {  // in N(y) only
+                    ++c;
+                    atomicAdd(&B.c2[b], 1);
+                }
+            }
         }
         if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
     }
     if (threadIdx.x == 0) {  // i == j
         int b = -1;
-        if (i == y) b = st.dy;
+        if (i == y) b = dy;
         else if (i == x) b = pos_x_in_y;
         else {
             const int h = g_find(B.keys, mask, i);
@@ -546,32 +536,41 @@ __global__ void __launch_bounds__(256) k_imp_rows(RowView g, ImpBuf B, int x, in
         }
         if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
     }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&c1_sh, c);
     __syncthreads();
-    int c = 0;
-    const int nb = st.dy + 1;
+    int adm = 0;
+    const int nb = dy + 1;
     for (int w = threadIdx.x; w < words; w += blockDim.x) {
         uint32_t v = bits[w];
         const int lo = w * 32;
         const uint32_t live = (nb - lo >= 32) ? 0xFFFFFFFFu : ((1u << (nb - lo)) - 1u);
-        c += __popc(~v & live);
+        adm += __popc(~v & live);
         B.adjbits[(size_t)a * words + w] = v;
     }
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt_sh, c);
+    for (int off = 32; off > 0; off >>= 1) adm += __shfl_xor(adm, off);
+    if ((threadIdx.x & 63) == 0 && adm) atomicAdd(&cnt_sh, adm);
     __syncthreads();
-    if (threadIdx.x == 0) B.rowcount[a] = cnt_sh;
-}
-
-// K6: exclusive scan of rowcount[0..rows) by one block; total -> res->n_cand
-__global__ void __launch_bounds__(1024) k_imp_scan(ImpBuf B, int rows, DevResult *res) {
-    __shared__ int wsum[16];
+    if (threadIdx.x == 0) {
+        B.rowcount[a] = cnt_sh;
+        if (a < dx) B.c1[a] = counting ? c1_sh : 0;
+        __threadfence();  // this workgroup's results, then its ticket
+        last_sh = atomicAdd(&stp->done_rows, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_sh) return;  // uniform
+    __threadfence();       // every other workgroup's results are visible from here on
+    imp_close_stats(B, curv_type, shi);
+    // exclusive scan of rowcount[0 .. rows): the candidates are emitted row by row (sdrf_no_cuda.py:32-37: outer loop over x_nb)
+    const int rows = (int)gridDim.x;
+    __shared__ int wsum[4];
     __shared__ int carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int base = 0; base < rows; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < rows ? B.rowcount[i] : 0;
+    for (int base = 0; base < rows; base += 256) {
+        const int r = base + (int)threadIdx.x;
+        const int v = r < rows ? __hip_atomic_load(&B.rowcount[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         int incl = v;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
@@ -582,21 +581,29 @@ __global__ void __launch_bounds__(1024) k_imp_scan(ImpBuf B, int rows, DevResult
         int woff = 0;
         for (int w = 0; w < wid; ++w) woff += wsum[w];
         const int carry = carry_sh;
-        if (i < rows) B.rowoff[i] = carry + woff + incl - v;
+        if (r < rows) B.rowoff[r] = carry + woff + incl - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry_sh = carry + woff + incl;
+        if (threadIdx.x == 255) carry_sh = carry + woff + incl;
         __syncthreads();
     }
     if (threadIdx.x == 0) res->n_cand = carry_sh;
 }
 
 // K7: write the admitted candidates of row a, in j order, with their improvements.
+// (Round 4: the pipeline's last user of the hash table leaves it EMPTY for the next iteration — nothing here reads it, and the
+//  separate clearing kernel at the head of the pipeline is gone.)
 __global__ void __launch_bounds__(256) k_imp_emit(RowView g, ImpBuf B, int x, int y, int words, int curv_type,
-                                                   double *out, int32_t *ci, int32_t *cj) {
+                                                   double *out, int32_t *ci, int32_t *cj, int64_t ts) {
     __shared__ int wsum[4];
     __shared__ int carry_sh;
     const ImpStats st = *B.st;
     const int a = blockIdx.x;
+    for (int64_t i = (int64_t)a * 256 + threadIdx.x; i < ts; i += (int64_t)gridDim.x * 256) {
+        B.keys[i] = -1;
+        B.posx[i] = -1;
+        B.posy[i] = -1;
+    }
+    if (a == 0 && threadIdx.x == 0) B.st->pos_x_in_y = -1;
     if (B.rowcount[a] == 0) return;
     const int2 rx = g.rowinfo[x], ry = g.rowinfo[y];
     const int i = a < st.dx ? g.col[rx.x + a] : x;
@@ -721,8 +728,27 @@ __global__ void k_draw_from_argmax(const int32_t *ci, const int32_t *cj, DevResu
     res->draw_status = 0;
 }
 
-__global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__ imp, const DevResult *res, double tau,
-                                                       double *__restrict__ bsum) {
+__device__ void draw_pick_block(const double *__restrict__ imp, const int32_t *__restrict__ ci, const int32_t *__restrict__ cj,
+                                DevResult *res, double tau, double u, const double *bsum, double margin_scale);
+__device__ void draw_block_sum(const double *__restrict__ imp, const DevResult *res, double tau, double *__restrict__ bsum);
+
+// Block sums of exp(tau * improvement); the LAST block to finish picks the index (round 4: k_draw_pick was a launch of its own).
+__global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__ imp, const int32_t *__restrict__ ci,
+                                                       const int32_t *__restrict__ cj, DevResult *res, double tau, double u,
+                                                       double *bsum, double margin_scale, ImpStats *st) {
+    __shared__ int last_sh;
+    draw_block_sum(imp, res, tau, bsum);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last_sh = atomicAdd(&st->done_draw, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_sh) return;  // uniform
+    __threadfence();
+    draw_pick_block(imp, ci, cj, res, tau, u, bsum, margin_scale);
+}
+
+__device__ void draw_block_sum(const double *__restrict__ imp, const DevResult *res, double tau, double *__restrict__ bsum) {
     __shared__ double red[256];
     const int64_t n = res->n_cand;
     const int64_t L = (n + DRAW_BLOCKS - 1) / DRAW_BLOCKS, l = (L + 255) / 256;
@@ -740,9 +766,8 @@ __global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__
     if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
 }
 
-__global__ void __launch_bounds__(256) k_draw_pick(const double *__restrict__ imp, const int32_t *__restrict__ ci,
-                                                    const int32_t *__restrict__ cj, DevResult *res, double tau, double u,
-                                                    const double *__restrict__ bsum, double margin_scale) {
+__device__ void draw_pick_block(const double *__restrict__ imp, const int32_t *__restrict__ ci, const int32_t *__restrict__ cj,
+                                DevResult *res, double tau, double u, const double *bsum, double margin_scale) {
     __shared__ double pre[256];
     __shared__ int found;
     const int t = threadIdx.x;
@@ -755,7 +780,7 @@ __global__ void __launch_bounds__(256) k_draw_pick(const double *__restrict__ im
         return;
     }
     // inclusive prefix of the block sums (256 values: one thread adds them in order)
-    pre[t] = bsum[t];
+    pre[t] = __hip_atomic_load(&bsum[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (other workgroups' sums)
     __syncthreads();
     if (t == 0) {
         double a = 0.0;
@@ -864,6 +889,7 @@ static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_
             DCR_TRY(dev_alloc(p, ts));
         }
         g->imp_table_cap = ts;
+        g->imp_table_dirty = true;
     }
     const int64_t rows_need = (int64_t)(dx > dy ? dx : dy) + 2;
     if (rows_need > g->imp_rows_cap) {
@@ -910,23 +936,23 @@ static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_
     B.st = g->imp_stats;
     RowView vw{g->rowinfo, g->col, g->slot_row};
 
-    {  // one launch instead of five memsets: the pipeline is bound by its launches
-        const int64_t most = ts > dx + 1 ? (ts > dy + 1 ? ts : dy + 1) : (dx + 1 > dy + 1 ? dx + 1 : dy + 1);
-        const unsigned blocks = (unsigned)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
-        hipLaunchKernelGGL(k_imp_clear, dim3(blocks), dim3(256), 0, g->stream, B, ts, dx + 1, dy + 1);
+    // Five launches (round 4; eleven before): insert both rows | per candidate row: classes, 4-cycle counters, admissibility
+    // bitmap, and the stage's closing statistics + scan by its last workgroup | classes B and C | emit (and leave the table
+    // empty) | the draw (its caller).  The table is only cleared here when the previous pipeline did not leave it empty.
+    if (g->imp_table_dirty) {
+        const unsigned blocks = (unsigned)((g->imp_table_cap + 255) / 256 > 1024 ? 1024 : (g->imp_table_cap + 255) / 256);
+        hipLaunchKernelGGL(k_imp_clear, dim3(blocks ? blocks : 1), dim3(256), 0, g->stream, B, g->imp_table_cap);
     }
-    const int gx = dx > 0 ? (dx + 255) / 256 : 1, gy = dy > 0 ? (dy + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_imp_insert_x, dim3(gx), dim3(256), 0, g->stream, vw, B, x, y, mask);
-    hipLaunchKernelGGL(k_imp_insert_y, dim3(gy), dim3(256), 0, g->stream, vw, B, x, y, mask);
-    if (curv_type == DCR_CURV_BFC && dx > 0)
-        hipLaunchKernelGGL(k_imp_count, dim3((dx + 3) / 4), dim3(256), 0, g->stream, vw, B, x, mask);
-    hipLaunchKernelGGL(k_imp_stats, dim3(1), dim3(1024), 0, g->stream, B, curv_type);
+    g->imp_table_dirty = true;  // (until k_imp_emit below has been enqueued)
+    const int gi = (dx + dy + 255) / 256 > 0 ? (dx + dy + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_imp_insert, dim3(gi), dim3(256), 0, g->stream, vw, B, x, y, mask);
+    hipLaunchKernelGGL(k_imp_rows_count, dim3(rows), dim3(256), (size_t)words * 4, g->stream, vw, B, x, y, mask, words, curv_type,
+                       g->dres);
     if (dx + dy > 0)
         hipLaunchKernelGGL(k_imp_bc, dim3((dx + dy + 3) / 4), dim3(256), 0, g->stream, vw, B, x, y, mask, curv_type);
-    hipLaunchKernelGGL(k_imp_rows, dim3(rows), dim3(256), (size_t)words * 4, g->stream, vw, B, x, y, mask, words);
-    hipLaunchKernelGGL(k_imp_scan, dim3(1), dim3(1024), 0, g->stream, B, rows, g->dres);
     hipLaunchKernelGGL(k_imp_emit, dim3(rows), dim3(256), 0, g->stream, vw, B, x, y, words, curv_type, g->imp_out,
-                       g->imp_ci, g->imp_cj);
+                       g->imp_ci, g->imp_cj, ts);
+    g->imp_table_dirty = false;
     DCR_HIP(hipGetLastError());
     *upper_out = upper;
     return DCR_OK;
@@ -1238,9 +1264,8 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
         hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, (const Ext *)g->red_scratch, 256, g->dres);
         hipLaunchKernelGGL(k_draw_from_argmax, dim3(1), dim3(1), 0, g->stream, g->imp_ci, g->imp_cj, g->dres);
     } else {
-        hipLaunchKernelGGL(k_draw_partial, dim3(DRAW_BLOCKS), dim3(256), 0, g->stream, g->imp_out, g->dres, tau, g->draw_bsum);
-        hipLaunchKernelGGL(k_draw_pick, dim3(1), dim3(256), 0, g->stream, g->imp_out, g->imp_ci, g->imp_cj, g->dres, tau, uniform,
-                           g->draw_bsum, margin_scale >= 1.0 ? margin_scale : 1.0);
+        hipLaunchKernelGGL(k_draw_partial, dim3(DRAW_BLOCKS), dim3(256), 0, g->stream, g->imp_out, g->imp_ci, g->imp_cj, g->dres, tau,
+                           uniform, g->draw_bsum, margin_scale >= 1.0 ? margin_scale : 1.0, g->imp_stats);
     }
     // A host round trip here, without any transfer or host arithmetic: enqueuing the tail and the pass behind a stream that
     // is still working through the small kernels above cost 0.2 ms per iteration more than enqueuing them on an idle one

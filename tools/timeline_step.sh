@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box: kernel timeline of one SDRF iteration at the bench shape (device draw), from k_imp_clear to the next one.
+# On the GPU box: kernel timeline of one SDRF iteration at the bench shape (device draw), from k_imp_insert to the next one.
 # usage: bash tools/timeline_step.sh <tag> -> gpurun_out/<tag>_step_timeline.txt
 TAG=${1:-step}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
@@ -11,7 +11,7 @@ python3 - > $OUT/${TAG}_step_timeline.txt <<'PY'
 import csv
 rows = list(csv.DictReader(open('/tmp/tl_step/p_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_imp_clear' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_imp_insert' in r['Kernel_Name']]
 # the first measured run is device-draw: take its 10th iteration (8 warm-up + a few)
 a, b = idx[14], idx[15]
 t0 = int(rows[a]['Start_Timestamp'])
