@@ -749,7 +749,8 @@ struct H2Scratch {
     int poff[66];    // exclusive prefix of their piece counts; poff[64] = total
     int rowT[64], rowPos[64], rowMx[64], rowRev[64];  // third-sweep accumulators per row of the batch
     unsigned qw[H2_QCAP];       // queued exact-path work: key ...
-    unsigned char qr[H2_QCAP];  // ... and row of the batch
+    unsigned char qr[H2_QCAP];  // ... row of the batch ...
+    unsigned char qb[H2_QCAP];  // ... and batch (the second sweep's queue runs across batches)
     unsigned plt[H2_PLCAP];       // third sweep: the members of N(u) met in the rows of the batch (triangle partners) ...
     unsigned char plr[H2_PLCAP];  // ... and the row each was met in
     int pln;                      // how many (counting past the capacity)
@@ -898,6 +899,7 @@ struct H2Tasks {
     DevResult *res;
     const int32_t *weight;  // bit 31: the node went to the retry list (what its first attempt listed is void)
     unsigned retry_flag;    // 0x80000000 in the retry launch
+    unsigned *lists;        // per-wave lists of the third step (H2_LIST_WORDS each, one per wave of the launch; nullptr: none)
 };
 // Pool space is handed out in chunks per wave (a reservation per edge on three shared counters cost more than the whole
 // step: same-address atomics serialise); what a wave leaves of a candidate chunk is marked void.  All members are uniform.
@@ -1000,14 +1002,97 @@ __device__ inline void h2_partners_short(const View &g, const H2Tasks tk, int u,
     if (pi != pend) row_ok(g, make_int2(-1, pi - pend), 43, npart, u);  // cannot happen
 }
 
+// ---- the third sweep from a list (round 4) ---------------------------------------------------------------------------------
+// The third sweep used to stream every row again, test every entry against B2 again, queue and LOOK UP every exact-path entry
+// again — for the per-row statistics of the few entries that matter (10 % of them in the middle class).  The second sweep has
+// those entries in its hands, table slot included: it now appends {slot, row, batch} to a per-wave list in device memory (and
+// where u sits in each row to a per-wave array), and the third step is one pass over that list once the counts are complete.
+// A wave whose list would overflow, or with more batches than the array holds, falls back to streaming (the old path).
+constexpr int H2_ITEMS = 2048;       // items per wave and unit
+constexpr int H2_REV_BATCHES = 16;   // batches of 64 rows per wave whose "position of u" the array holds
+constexpr int H2_LIST_WORDS = H2_ITEMS + H2_REV_BATCHES * 64;  // 32-bit words per wave
+struct H2List {       // all members uniform over the wave
+    unsigned *items;  // slot | row << 13 | batch << 19
+    int *revs;        // [batch][row of the batch]: slot of u inside that row, -1: not found
+    int n;            // items appended (counts past the capacity)
+    bool over;        // the list does not describe the unit: stream the third sweep
+};
+__device__ inline H2List h2_list_of(unsigned *pool, int waves_per_group) {
+    H2List ls;
+    unsigned *mine = pool ? pool + ((int64_t)blockIdx.x * waves_per_group + (threadIdx.x >> 6)) * H2_LIST_WORDS : nullptr;
+    ls.items = mine;
+    ls.revs = reinterpret_cast<int *>(mine ? mine + H2_ITEMS : nullptr);
+    ls.n = 0;
+    ls.over = mine == nullptr;
+    return ls;
+}
+
 // ---- the three sweeps: the rows of the neighbours of u, in batches of 64 rows per wave -----------------------------------
 // the queued exact-path work of one wave: n is uniform and lives in a register
 // PHASE 2 also LISTS what the triangle step needs, on the spot (no row is read again for it): every candidate occurrence
 // (w outside N(u), c = M_u(w) - 1 > 0) goes to the device-memory pool with the task of its row (tbase + row: a task
 // per row of the batch, filled in when the batch is complete), every member of N(u) met (a triangle partner of its row)
 // to the batch's LDS list.
-template <int L1, int EXS, int PHASE>
-__device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Tasks tk, H2Alloc &al, int tbase) {
+// what the third step does with ONE exact-path entry per lane: `have` (the lane holds one), its table slot, its row of the
+// batch, its key.  pln (uniform) counts the batch's triangle partners.
+template <int L1, int EXS>
+__device__ inline void h2_settle(const H2Tab t, H2Scratch *sc, bool have, int s, int r, unsigned w, int &pln, const H2Tasks tk,
+                                 H2Alloc &al, int tbase) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    bool cand = false, partner = false;
+    int c = 0;
+    if (have && s >= 0) {
+        const unsigned c16 = h2_cnt_get(t.cnt, s);
+        if (c16 & 0x8000u) {
+            atomicAdd(&sc->rowT[r], 1);
+            partner = true;
+        } else {
+            c = (int)(c16 & 0x7FFFu) - 1;
+            if (c > 0) {
+                atomicAdd(&sc->rowPos[r], 1);
+                atomicMax(&sc->rowMx[r], c);
+                cand = true;
+            }
+        }
+    }
+    const unsigned long long mC = __ballot(cand), mT = __ballot(partner);
+    if (mC != 0ull && tbase >= 0) {  // uniform
+        const int nc = __popcll(mC);
+        if (al.c_end - al.c_cur < nc) {
+            h2_void_candidates(tk, al.c_cur, al.c_end);
+            al.c_cur = h2_pool_grab(tk.n_cand, H2_CHUNK_C);
+            al.c_end = al.c_cur + H2_CHUNK_C;
+        }
+        const int c0 = al.c_cur;
+        al.c_cur += nc;
+        if (c0 < 0 || (int64_t)c0 + nc > tk.cand_cap) {
+            if (lane == 0) {
+                if (c0 < 0) tk.res->h2_status = 1;
+                else atomicCAS(&tk.res->h2_status, 0, 2);  // the pool is too small: the host grows it and runs the pass again
+            }
+        } else if (cand) {
+            tk.cand[c0 + __popcll(mC & below)] = make_int4((int)w, c, tbase + (int)sc->trank[r], 0);
+        }
+    }
+    if (mT != 0ull) {  // uniform
+        if (partner) {
+            const int idx = pln + __popcll(mT & below);
+            if (idx < H2_PLCAP) {
+                sc->plt[idx] = w;
+                sc->plr[idx] = (unsigned char)r;
+            }
+        }
+        pln += __popcll(mT);
+    }
+}
+
+// PHASE 1: occurrences of the repeated keys (and the list of the third step); PHASE 2 (streaming fallback): per-row statistics.
+// PARTS: the unit is one key partition of a split node — only its own keys are counted, but the flagged members of N(u), which
+// live in every partition's table, are met (and listed) whatever their partition: T and the partner lists are whole.
+template <int L1, int EXS, int PHASE, bool PARTS>
+__device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Tasks tk, H2Alloc &al, int tbase, H2List &ls, int part,
+                                int nparts) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     h2_wave_sync();
@@ -1016,61 +1101,35 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Ta
         const int i = base + lane;
         const unsigned w = i < n ? sc->qw[i] : 0u;
         if (PHASE == 1) {
+            int s = -1;
             if (i < n) {
-                const int s = h2_insert<EXS>(t.key, w);
-                if (s < 0) *t.full = 1;
-                else h2_cnt_add(t.cnt, s);
+                const bool own = !PARTS || h2_part(w, nparts) == part;
+                if (own) {
+                    s = h2_insert<EXS>(t.key, w);
+                    if (s < 0) *t.full = 1;
+                    else h2_cnt_add(t.cnt, s);
+                } else {  // another partition's key: of interest only as a member of N(u)
+                    s = h2_find<EXS>(t.key, w);
+                    if (s >= 0 && !(h2_cnt_get(t.cnt, s) & 0x8000u)) s = -1;
+                }
+            }
+            if (!ls.over) {  // uniform
+                const unsigned long long m = __ballot(s >= 0);
+                const int cnt = __popcll(m);
+                if (ls.n + cnt > H2_ITEMS) {
+                    ls.over = true;
+                } else if (s >= 0) {
+                    ls.items[ls.n + __popcll(m & below)] = (unsigned)s | ((unsigned)sc->qr[i] << 13) | ((unsigned)sc->qb[i] << 19);
+                }
+                ls.n += cnt;
             }
         } else {
-            bool cand = false, partner = false;
-            int c = 0, r = 0;
+            int s = -1, r = 0;
             if (i < n) {
-                const int s = h2_find<EXS>(t.key, w);
-                if (s >= 0) {
-                    r = sc->qr[i];
-                    const unsigned c16 = h2_cnt_get(t.cnt, s);
-                    if (c16 & 0x8000u) {
-                        atomicAdd(&sc->rowT[r], 1);
-                        partner = true;
-                    } else {
-                        c = (int)(c16 & 0x7FFFu) - 1;
-                        if (c > 0) {
-                            atomicAdd(&sc->rowPos[r], 1);
-                            atomicMax(&sc->rowMx[r], c);
-                            cand = true;
-                        }
-                    }
-                }
+                s = h2_find<EXS>(t.key, w);
+                r = sc->qr[i];
             }
-            const unsigned long long mC = __ballot(cand), mT = __ballot(partner);
-            if (mC != 0ull && tbase >= 0) {  // uniform
-                const int nc = __popcll(mC);
-                if (al.c_end - al.c_cur < nc) {
-                    h2_void_candidates(tk, al.c_cur, al.c_end);
-                    al.c_cur = h2_pool_grab(tk.n_cand, H2_CHUNK_C);
-                    al.c_end = al.c_cur + H2_CHUNK_C;
-                }
-                const int c0 = al.c_cur;
-                al.c_cur += nc;
-                if (c0 < 0 || (int64_t)c0 + nc > tk.cand_cap) {
-                    if (lane == 0) {
-                        if (c0 < 0) tk.res->h2_status = 1;
-                        else atomicCAS(&tk.res->h2_status, 0, 2);  // the pool is too small: the host grows it and runs the pass again
-                    }
-                } else if (cand) {
-                    tk.cand[c0 + __popcll(mC & below)] = make_int4((int)w, c, tbase + (int)sc->trank[r], 0);
-                }
-            }
-            if (mT != 0ull) {  // uniform
-                if (partner) {
-                    const int idx = pln + __popcll(mT & below);
-                    if (idx < H2_PLCAP) {
-                        sc->plt[idx] = w;
-                        sc->plr[idx] = (unsigned char)r;
-                    }
-                }
-                pln += __popcll(mT);
-            }
+            h2_settle<L1, EXS>(t, sc, i < n, s, r, w, pln, tk, al, tbase);
         }
     }
     if (PHASE == 2 && lane == 0) sc->pln = pln;
@@ -1078,14 +1137,37 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Ta
     n = 0;
 }
 
+// the third step from the list: the items of batch `bidx` (they are batch-monotone: the second sweep's queue is first in, first out)
+template <int L1, int EXS>
+__device__ inline void h2_settle_items(const H2Tab t, H2Scratch *sc, const H2List &ls, int &lcur, int bidx, const H2Tasks tk, H2Alloc &al,
+                                       int tbase) {
+    const int lane = threadIdx.x & 63;
+    int pln = sc->pln;  // uniform
+#pragma unroll 1
+    while (true) {
+        const int i = lcur + lane;
+        const unsigned item = i < ls.n ? ls.items[i] : 0xFFFFFFFFu;
+        const bool mine = i < ls.n && (int)(item >> 19) == bidx;
+        const int cnt = __popcll(__ballot(mine));
+        if (cnt == 0) break;  // uniform
+        const int s = (int)(item & 0x1FFFu), r = (int)((item >> 13) & 63u);
+        const unsigned w = mine ? t.key[s] : 0u;
+        h2_settle<L1, EXS>(t, sc, mine, mine ? s : -1, r, w, pln, tk, al, tbase);
+        lcur += cnt;
+        if (cnt < 64) break;
+    }
+    if (lane == 0) sc->pln = pln;
+    h2_wave_sync();
+}
+
 // third sweep, start of a batch of rows: row accumulators, partner list, a task per row present
-__device__ inline void h2_batch_begin(const H2Tasks tk, H2Alloc &al, H2Scratch *sc, int k, int &tbase, int &trow) {
+__device__ inline void h2_batch_begin(const H2Tasks tk, H2Alloc &al, H2Scratch *sc, int k, int &tbase, int &trow, int rev = -1) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     sc->rowT[lane] = 0;
     sc->rowPos[lane] = 0;
     sc->rowMx[lane] = 0;
-    sc->rowRev[lane] = -1;
+    sc->rowRev[lane] = rev;  // (-1: found by the sweep that follows; list mode: what the second sweep found)
     if (lane == 0) sc->pln = 0;
     int dummy_c, dummy_p;
     const unsigned long long rows = __ballot(k >= 0);  // a task per row of the batch
@@ -1176,11 +1258,13 @@ __device__ inline void h2_batch_end(const View &g, const H2Tasks tk, H2Alloc &al
 // between the sweeps (round 4: the split class spent most of every sweep waiting for them).
 template <int L1, int EXS, int NW, bool PARTS, int PHASE>
 __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
-                                 const H2Tab t, H2Scratch *sc, uint4 *rec, int k0, int2 rk0) {
+                                 const H2Tab t, H2Scratch *sc, uint4 *rec, int k0, int2 rk0, H2List &ls) {
     const int lane = threadIdx.x & 63;
     const int wid = (int)(threadIdx.x >> 6);
     const unsigned long long below = (1ull << lane) - 1ull;
     int qn = 0;  // queued items (uniform)
+    int lcur = 0;  // third step from the list: next item (uniform)
+    if (PHASE == 0 && ru.y > 64 * NW * H2_REV_BATCHES) ls.over = true;  // more batches than the list's row array holds
 #ifdef H2_PROF
     long long t_prof = (long long)__builtin_amdgcn_s_memtime();
     H2Scratch *s = sc;
@@ -1206,21 +1290,38 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
         int poff_lane;
         const int P = h2_prefix(np, poff_lane);
         if (P == 0) continue;  // uniform: no row in this wave's share of the batch
+        const int bidx = base / (64 * NW);
+        int tbase = -1, trow = 0;  // third sweep: the tasks of this batch's rows (tbase uniform; trow: this lane's row)
+        if (PHASE == 2 && !ls.over) {
+            // the third step from the second sweep's list: no row is streamed, no entry tested or looked up again
+            h2_batch_begin(tk, al, sc, k, tbase, trow, ls.revs[bidx * 64 + lane]);
+            h2_wave_sync();
+            H2_STAMP(8)
+            h2_settle_items<L1, EXS>(t, sc, ls, lcur, bidx, tk, al, tbase);
+            H2_STAMP(9)
+            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
+            h2_wave_sync();  // the scratch is rewritten by the next batch
+            H2_STAMP(11)
+            continue;
+        }
+        if (PHASE == 0 && !ls.over) ls.revs[bidx * 64 + lane] = -1;
         sc->desc[lane] = rk;
         sc->poff[lane] = poff_lane;
         if (lane == 0) sc->poff[64] = P;
-        int tbase = -1, trow = 0;  // third sweep: the tasks of this batch's rows (tbase uniform; trow: this lane's row)
         if (PHASE == 2) h2_batch_begin(tk, al, sc, k, tbase, trow);
         h2_wave_sync();
         if (PHASE == 2) H2_STAMP(8)
+        const bool listing = PHASE == 1 && !ls.over;  // uniform
         auto flags = [&](const int4 w, unsigned vm, int r, int a) -> unsigned {
             const unsigned kk[4] = {(unsigned)w.x, (unsigned)w.y, (unsigned)w.z, (unsigned)w.w};
             const unsigned isu = h2_eq4(kk, (unsigned)u) & vm;
             if (PHASE == 2 && isu) sc->rowRev[r] = a + __ffs((int)isu) - 1;
+            if (listing && isu) ls.revs[bidx * 64 + r] = a + __ffs((int)isu) - 1;  // (where u sits in that row: the third step's)
             unsigned valid = vm & ~isu;
             // (third sweep: no partition test — a key of another partition is simply not in the table, and the flagged
-            //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole)
-            if (PARTS && PHASE != 2) {
+            //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole.
+            //  The same holds for the second sweep while it lists for the third step: its drain tells the partitions apart.)
+            if (PARTS && PHASE != 2 && !listing) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
                     if (h2_part(kk[jj], nparts) != part) valid &= ~(1u << jj);
@@ -1234,19 +1335,20 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
         h2_for_pieces_queued<(PARTS ? H2_QL : H2_Q)>(g.col, sc->desc, sc->poff, poff_lane, P, qn, flags,
                              [&](int idx, unsigned key, int r) {
                                  sc->qw[idx] = key;
-                                 if (PHASE == 2) sc->qr[idx] = (unsigned char)r;
+                                 if (PHASE != 0) sc->qr[idx] = (unsigned char)r;
+                                 if (PHASE == 1) sc->qb[idx] = (unsigned char)bidx;
                              },
-                             [&]() { h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, tbase); });
+                             [&]() { h2_drain<L1, EXS, PHASE, PARTS>(t, sc, qn, tk, al, tbase, ls, part, nparts); });
         if (PHASE == 2) H2_STAMP(9)
         if (PHASE == 2) {
-            h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, tbase);  // the row totals are read next
+            h2_drain<L1, EXS, PHASE, PARTS>(t, sc, qn, tk, al, tbase, ls, part, nparts);  // the row totals are read next
             H2_STAMP(10)
             h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
         }
         h2_wave_sync();  // the scratch is rewritten by the next batch
         if (PHASE == 2) H2_STAMP(11)
     }
-    if (qn > 0) h2_drain<L1, EXS, PHASE>(t, sc, qn, tk, al, -1);  // (after the loop: a wave's last batches may be empty; PHASE 1 only)
+    if (qn > 0) h2_drain<L1, EXS, PHASE, PARTS>(t, sc, qn, tk, al, -1, ls, part, nparts);  // (after the loop: a wave's last batches may be empty; PHASE 1 only)
 }
 
 // A unit whose rows fit one batch (at most 64 per wave) and whose pieces fit NPB per lane: rows, descriptors and pieces
@@ -1256,7 +1358,7 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
 constexpr int H2_NPB = 12;
 template <int L1, int EXS, int NW, bool PARTS>
 __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
-                                    const H2Tab t, H2Scratch *sc, uint4 *rec, bool &ok) {
+                                    const H2Tab t, H2Scratch *sc, uint4 *rec, bool &ok, H2List &ls) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NT = 64 * NW, NP = H2_NPB;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -1339,29 +1441,23 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
     }
     __syncthreads();
     H2_STAMP(1 + (PARTS ? 4 : 0))
-    // sweeps B and C: flagged entries are queued, the drain has one call site per sweep
+    // Sweep B: flagged entries are queued, the drain has one call site.  It lists its exact-path entries (slot and row) and
+    // where u sits in each row; the third step is then one pass over that list (h2_settle_items) — unless the list overflowed:
+    // that wave streams its rows for the third sweep (h2_stream, the path of the units that do not fit the registers).
     int qn = 0, tbase = -1, trow = 0;
-#pragma unroll 1
-    for (int phase = 1; phase <= 2; ++phase) {
+    sc->rowRev[lane] = -1;
+    h2_wave_sync();
+    {
         unsigned fl[NP];
-        if (phase == 2) {
-            h2_batch_begin(tk, al, sc, k, tbase, trow);
-            H2_STAMP(12)
-        }
-        h2_wave_sync();
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             fl[q] = 0u;
             if (64 * q >= P) continue;  // uniform
             const unsigned kk[4] = {(unsigned)w[q].x, (unsigned)w[q].y, (unsigned)w[q].z, (unsigned)w[q].w};
-            unsigned valid = (unsigned)(meta[q] >> 4) & 0xFu;
-            if (phase == 2) {
-                // (third sweep: no partition test — a key of another partition is simply not in the table, and the flagged
-                //  members of N(u), which are in every partition's table, must all be met: T and the partner lists are whole)
-                const unsigned vm = (unsigned)meta[q] & 0xFu, isu = h2_eq4(kk, (unsigned)u) & vm;
-                if (isu) sc->rowRev[(int)((meta[q] >> 8) & 0xFFull)] = (int)(meta[q] >> 16) + __ffs((int)isu) - 1;
-                valid = vm & ~isu;
-            }
+            const unsigned valid = (unsigned)(meta[q] >> 4) & 0xFu;
+            // (where u sits in the row: the third step's, found while the pieces are at hand)
+            const unsigned isu = h2_eq4(kk, (unsigned)u) & (unsigned)meta[q] & 0xFu;
+            if (isu) sc->rowRev[(int)((meta[q] >> 8) & 0xFFull)] = (int)(meta[q] >> 16) + __ffs((int)isu) - 1;
             fl[q] = h2_again4<L1>(t.b2, kk, valid);
         }
 #pragma unroll 1
@@ -1384,26 +1480,33 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
                         const int idx = qn + __popcll(m & below);
                         sc->qw[idx] = kk[jj];
                         sc->qr[idx] = (unsigned char)((meta[q] >> 8) & 0xFFull);
+                        sc->qb[idx] = 0;
                         fl[q] &= ~(1u << jj);
                     }
                     qn += __popcll(m);
                 }
             }
-            if (qn > 0) {
-                if (phase == 1) h2_drain<L1, EXS, 1>(t, sc, qn, tk, al, -1);
-                else h2_drain<L1, EXS, 2>(t, sc, qn, tk, al, tbase);
-            }
+            if (qn > 0) h2_drain<L1, EXS, 1, PARTS>(t, sc, qn, tk, al, -1, ls, part, nparts);
             if (!stop) break;
         }
-        if (phase == 1) {
-            __syncthreads();
-            H2_STAMP(2 + (PARTS ? 4 : 0))
-            ok = *t.full == 0;  // uniform
-            if (!ok) break;
-        } else {
+    }
+    __syncthreads();
+    H2_STAMP(2 + (PARTS ? 4 : 0))
+    ok = *t.full == 0;  // uniform
+    if (ok) {
+        if (!ls.over) {  // uniform over the wave
+            int lcur = 0;
+            const int myrev = sc->rowRev[lane];
+            h2_wave_sync();
+            h2_batch_begin(tk, al, sc, k, tbase, trow, myrev);
+            H2_STAMP(12)
+            h2_wave_sync();
+            h2_settle_items<L1, EXS>(t, sc, ls, lcur, 0, tk, al, tbase);
             H2_STAMP(13)
             h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
             H2_STAMP(15)
+        } else {
+            h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec, k, rk, ls);
         }
     }
     __syncthreads();  // the tables are rewritten by the next unit
@@ -1413,13 +1516,13 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
 // one unit: node u, key partition `part` of `nparts`, by NW waves sharing the tables `t`; false: the table filled up
 template <int L1, int EXS, int NW, bool PARTS>
 __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int part, int nparts,
-                               const H2Tab t, H2Scratch *sc, uint4 *rec) {
+                               const H2Tab t, H2Scratch *sc, uint4 *rec, H2List &ls) {
     const int tid = (int)threadIdx.x;
     constexpr int NT = 64 * NW;
 #ifndef H2_NO_FAST
     if constexpr (!PARTS) {  // (with 16 waves per unit the registers it needs spill: measured slower for the split class)
         bool ok_fast = true;
-        if (h2_node_fast<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, sc, rec, ok_fast)) return ok_fast;
+        if (h2_node_fast<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, sc, rec, ok_fast, ls)) return ok_fast;
     }
 #endif
 #ifdef H2_PROF
@@ -1463,14 +1566,14 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
     }
     __syncthreads();
     H2_STAMP(8 - 8 + (PARTS ? 4 : 0))
-    h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0);
+    h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0, ls);
     __syncthreads();
     H2_STAMP(1 + (PARTS ? 4 : 0))
-    h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0);
+    h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0, ls);
     __syncthreads();
     H2_STAMP(2 + (PARTS ? 4 : 0))
     const bool ok = *t.full == 0;  // uniform
-    if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0);
+    if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0, ls);
     __syncthreads();  // the tables are rewritten by the next unit
     H2_STAMP(3 + (PARTS ? 4 : 0))
     return ok;
@@ -1509,7 +1612,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)
             ok = row_ok(g, ru, 38, u, (int)it) && ru.y > 0 && ru.y <= H2_MAXDEG;
         }
         if (!ok) continue;
-        if (!h2_node<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, &sc_all[wid], rec)) {
+        H2List ls = h2_list_of(tk.lists, NW);  // (fresh per unit)
+        if (!h2_node<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, &sc_all[wid], rec, ls)) {
             if (threadIdx.x == 0) {  // every partition of the node is redone (the retry starts from zeroed records)
                 if (is_retry) {
                     rt.res->h2_status = 1;
@@ -1742,7 +1846,10 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
     }
 }
 
-__global__ void k_h2_clear(DevResult *res) {
+// (round 4: also zeroes the weights — a fill launch of its own before)
+__global__ void __launch_bounds__(256) k_h2_clear(DevResult *res, int32_t *weight, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) weight[i] = 0;
+    if (blockIdx.x != 0) return;
     if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
     if (threadIdx.x < H2_NB) {
         res->h2_bucket[threadIdx.x] = 0;
@@ -1940,6 +2047,13 @@ static int ensure_h2(dcr_graph *g) {
     DCR_TRY(dev_regrow(&g->h2_task, &g->h2_task_cap, 2 * std::max<int64_t>(g->cap_total + 4096, g->h2_want[0])));
     DCR_TRY(dev_regrow(&g->h2_cand, &g->h2_cand_cap, 2 * std::max<int64_t>(2 * g->cap_total + 65536, g->h2_want[1])));
     DCR_TRY(dev_regrow(&g->h2_part, &g->h2_part_cap, 2 * std::max<int64_t>(g->cap_total + 65536, g->h2_want[2])));
+    // the third step's per-wave lists: the split class (one workgroup of 16 waves per CU; the retry launch reuses its part)
+    // and class M (three workgroups of 4 waves per CU)
+    static const bool use_lists = !(getenv("DCR_H2_LISTS") && atoi(getenv("DCR_H2_LISTS")) == 0);
+    if (use_lists) {
+        const int cus = g->num_cu > 0 ? g->num_cu : 256;
+        DCR_TRY(dev_regrow(&g->h2_lists, &g->h2_lists_cap, (int64_t)cus * (16 + 12) * H2_LIST_WORDS));
+    }
     return DCR_OK;
 }
 
@@ -1995,18 +2109,20 @@ static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, con
     if (!is_retry) most = most * h2_share(C == 3 ? 1 : 0, g->n) / 100;
     if (grid > most) grid = most;
     if (grid < 1) grid = 1;
+    H2Tasks tkl = tk;
+    if (grid > (int64_t)g->num_cu * (C == 3 ? 3 : 1)) tkl.lists = nullptr;  // (more workgroups than the list pool has places for)
     hipLaunchKernelGGL((k_h2_block<h2_l1(C), h2_exs(C), h2_waves(C), PARTS>), dim3((unsigned)grid), dim3(64 * h2_waves(C)), 0,
-                       st, vw, tk, units, count, cap, g->h2_rec, rt, is_retry);
+                       st, vw, tkl, units, count, cap, g->h2_rec, rt, is_retry);
 }
 
 int launch_curvature_pass_h2(dcr_graph *g) {
-    DCR_TRY(ensure_h2(g));
     if (g->num_cu <= 0) {
         g->num_cu = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0)
             g->num_cu = prop.multiProcessorCount;
     }
+    DCR_TRY(ensure_h2(g));
     View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, nullptr, (int32_t)g->n, 0, nullptr};
     H2Lists L;
     for (int c = 0; c < H2_CLASSES; ++c) {
@@ -2017,15 +2133,19 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     const H2Retry rt{g->h2_retry, g->h2_retry_cap, g->h2_weight, g->dres};
     const int64_t tcap = g->h2_task_cap / 2, ccap = g->h2_cand_cap / 2, pcap = g->h2_part_cap / 2;
     DevResult *dr = g->dres;
+    unsigned *lists_L = g->h2_lists, *lists_M = g->h2_lists ? g->h2_lists + (int64_t)g->num_cu * 16 * H2_LIST_WORDS : nullptr;
     H2Tasks tk{g->h2_task, g->h2_cand, g->h2_part, tcap, ccap, pcap, &dr->h2_ntask[0], &dr->h2_ncand[0], &dr->h2_npart[0],
-               &dr->h2_ncand_done[0], g->dres, g->h2_weight, 0u};  // pool 0: the split class and the retry launch
+               &dr->h2_ncand_done[0], g->dres, g->h2_weight, 0u, lists_L};  // pool 0: the split class and the retry launch
     const H2Tasks tkM{g->h2_task + tcap, g->h2_cand + ccap, g->h2_part + pcap, tcap, ccap, pcap, &dr->h2_ntask[1], &dr->h2_ncand[1],
-                      &dr->h2_npart[1], &dr->h2_ncand_done[1], g->dres, g->h2_weight, 0u};  // pool 1: class M
-    hipLaunchKernelGGL(k_h2_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
+                      &dr->h2_npart[1], &dr->h2_ncand_done[1], g->dres, g->h2_weight, 0u, lists_M};  // pool 1: class M
+    {
+        const int64_t cb = (g->n + 255) / 256;
+        hipLaunchKernelGGL(k_h2_clear, dim3((unsigned)(cb < 1 ? 1 : cb > 2048 ? 2048 : cb)), dim3(256), 0, g->stream, g->dres, g->h2_weight,
+                           g->n);
+    }
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
     const int64_t sblocks = (g->cap_total + 255) / 256;
     const H2EdgeSet es{g->h2_eset, g->h2_eset_bits, g->h2_bloom, g->h2_bloom_bits};
-    DCR_HIP(hipMemsetAsync(g->h2_weight, 0, sizeof(int32_t) * (size_t)(g->n > 0 ? g->n : 1), g->stream));
     if (sblocks > 0) hipLaunchKernelGGL(k_h2_weight, dim3((unsigned)sblocks), dim3(256), 0, g->stream, vw, g->h2_weight);
     const int64_t pblocks = (g->n + H2_PLAN_THREADS - 1) / H2_PLAN_THREADS;
     if (pblocks > 0) {

@@ -232,6 +232,8 @@ struct dcr_graph {
     uint4 *h2_task = nullptr;         // triangle step pools (dcr_bfc_h2.hip)
     int4 *h2_cand = nullptr;
     int32_t *h2_part = nullptr;
+    unsigned *h2_lists = nullptr;     // per-wave lists of the block classes' third step (dcr_bfc_h2.hip: H2List)
+    int64_t h2_lists_cap = 0;
     int64_t h2_task_cap = 0, h2_cand_cap = 0, h2_part_cap = 0;
     int64_t h2_want[3] = {0, 0, 0};   // pool sizes a pass asked for (tasks, candidates, partners)
     unsigned *h2_bloom = nullptr;     // one bit per edge (prefilter of the edge set)
