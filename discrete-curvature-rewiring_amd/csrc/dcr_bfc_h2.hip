@@ -1890,7 +1890,7 @@ __global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int4 *units
 #define H2_FINAL_Q 1
 #endif
 #ifndef H2_FINAL_BLOCKS
-#define H2_FINAL_BLOCKS 4096
+#define H2_FINAL_BLOCKS 1024   // (x 4 waves = 4,096 pairs of partial extrema: the reduction that follows is one workgroup)
 #endif
 // Launched twice per pass: `when` = 0 right behind the class kernels, BESIDE the retry launch, and it does the work iff the retry
 // list is empty (the usual case: the three retry kernels are then 27 us of empty launches that used to sit on the critical

@@ -88,10 +88,10 @@ __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_tot
     if (threadIdx.x == 0) partial[blockIdx.x] = ext_make(best_v, best_s);
 }
 
-__global__ void __launch_bounds__(256) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
-                                                       DevResult *res) {
-    __shared__ double shv[4];
-    __shared__ int shs[4];
+__global__ void __launch_bounds__(1024) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
+                                                        DevResult *res) {
+    __shared__ double shv[16];
+    __shared__ int shs[16];
     double best_v = 0.0;
     int best_s = -1;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(256) k_argmax_final(const Ext *partial, int np
     if (threadIdx.x == 0) res->imp_argmax = best_s;
 }
 
+static inline int nparts_threads(int nparts) { return nparts > 1024 ? 1024 : nparts > 256 ? 512 : 256; }  // threads of the one-workgroup reduction
 constexpr int ARGEXT_BLOCKS = 1024;  // (8192 blocks: 92 us instead of 33 on S100k, the per-block reduction dominates)
 
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_t st) {
@@ -154,7 +155,7 @@ int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_argext_edges, dim3((unsigned)blocks), dim3(256), 0, st, vw, g->cap_total, g->curv,
                        want_max, excl_u, excl_v, g->dres, (Ext *)g->red_scratch);
-    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, st, vw, (const Ext *)g->red_scratch, (int)blocks,
+    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(nparts_threads((int)blocks)), 0, st, vw, (const Ext *)g->red_scratch, (int)blocks,
                        want_max, g->dres);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
@@ -165,7 +166,7 @@ int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st) {
     g->amax_valid = false;  // the ext fields of the result block are about to be overwritten
     RowView vw{g->rowinfo, g->col, g->slot_row};
     const Ext *parts = (const Ext *)g->ext_part + (want_max ? EXT_PART_BLOCKS : 0);
-    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(256), 0, st, vw, parts, g->ext_part_n, want_max, g->dres);
+    hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(nparts_threads(g->ext_part_n)), 0, st, vw, parts, g->ext_part_n, want_max, g->dres);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int 
 __global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int x, int y, unsigned mask, int words, int curv_type,
                                                          DevResult *res) {
     extern __shared__ uint32_t bits[];
-    __shared__ int cnt_sh, c1_sh, cls_sh, last_sh;
+    __shared__ int cnt_sh, c1_sh, last_sh;
     __shared__ int shi[16 * 4];
     ImpStats *stp = B.st;
     const int dx = stp->dx, dy = stp->dy;
@@ -482,59 +483,62 @@ __global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int
     const int2 rx = g.rowinfo[x], ry = g.rowinfo[y];
     const int i = a < dx ? g.col[rx.x + a] : x;
     for (int w = threadIdx.x; w < words; w += blockDim.x) bits[w] = 0u;
+    // class of row a: 2 = the other endpoint, 1 = also in row y (a triangle node), 0 = in row x only.  Every thread looks i up
+    // itself (one address: a broadcast) — behind one thread and a barrier the whole workgroup waited for two dependent reads.
+    int cls = 3, b_i = -1;  // b_i: position of i in row y + [y] (the pair (i, i) is ruled out: sdrf_no_cuda.py:35, i != j)
+    if (i == y) {
+        cls = 2;
+        b_i = dy;
+    } else if (i == x) {
+        b_i = pos_x_in_y;
+    } else {
+        const int h = g_find(B.keys, mask, i);
+        if (h >= 0) b_i = B.posy[h];
+        if (a < dx) cls = b_i >= 0 ? 1 : 0;
+    }
     if (threadIdx.x == 0) {
         cnt_sh = 0;
         c1_sh = 0;
-        // class of row a: 2 = the other endpoint, 1 = also in row y (a triangle node), 0 = in row x only
-        int cls = 3;
-        if (a < dx) {
-            if (i == y) cls = 2;
-            else {
-                const int h = g_find(B.keys, mask, i);
-                cls = (h >= 0 && B.posy[h] >= 0) ? 1 : 0;
-            }
-            B.clsx[a] = cls;
-        }
-        cls_sh = cls;
+        if (a < dx) B.clsx[a] = cls;
     }
-    // classes of a share of row y (every position is settled by exactly one workgroup)
+    __syncthreads();
+    const bool counting = curv_type == DCR_CURV_BFC && cls == 0;
+    const int2 ri = g.rowinfo[i];
+    int c = 0;
+    for (int base = 0; base < ri.y; base += 4 * 256) {  // four look-ups in flight per thread (a hub's row is 1,400 entries)
+        int w[4], h[4];
+        bool in[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = base + 256 * q + (int)threadIdx.x;
+            in[q] = t < ri.y;
+            w[q] = in[q] ? g.col[ri.x + t] : -1;
+            in[q] = in[q] && w[q] != x && w[q] != y;  // (the endpoints are not in the table)
+        }
+        g_find4(B.keys, mask, w, in, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int b = -1;
+            if (w[q] == y && base + 256 * q + (int)threadIdx.x < ri.y) b = dy;
+            else if (w[q] == x && base + 256 * q + (int)threadIdx.x < ri.y) b = pos_x_in_y;
+            else if (in[q] && h[q] >= 0) {
+                b = B.posy[h[q]];
+                if (counting && b >= 0 && B.posx[h[q]] < 0) {  // in N(y) only
+                    ++c;
+                    atomicAdd(&B.c2[b], 1);
+                }
+            }
+            if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
+        }
+    }
+    if (threadIdx.x == 0 && b_i >= 0) atomicOr(&bits[b_i >> 5], 1u << (b_i & 31));  // i == j
+    // classes of a share of row y (every position is settled by exactly one workgroup; nothing in this kernel reads them)
     for (int b = a + (int)threadIdx.x * (int)gridDim.x; b < dy; b += (int)blockDim.x * (int)gridDim.x) {
         const int k = g.col[ry.x + b];
         if (k != x) {
             const int h = g_find(B.keys, mask, k);
             B.clsy[b] = (h >= 0 && B.posx[h] >= 0) ? 1 : 0;
         }
-    }
-    __syncthreads();
-    const bool counting = curv_type == DCR_CURV_BFC && cls_sh == 0;
-    const int2 ri = g.rowinfo[i];
-    int c = 0;
-    for (int t = threadIdx.x; t < ri.y; t += blockDim.x) {
-        const int w = g.col[ri.x + t];
-        int b = -1;
-        if (w == y) b = dy;
-        else if (w == x) b = pos_x_in_y;
-        else {
-            const int h = g_find(B.keys, mask, w);
-            if (h >= 0) {
-                b = B.posy[h];
-                if (counting && b >= 0 && B.posx[h] < 0) {  // in N(y) only
-                    ++c;
-                    atomicAdd(&B.c2[b], 1);
-                }
-            }
-        }
-        if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
-    }
-    if (threadIdx.x == 0) {  // i == j
-        int b = -1;
-        if (i == y) b = dy;
-        else if (i == x) b = pos_x_in_y;
-        else {
-            const int h = g_find(B.keys, mask, i);
-            if (h >= 0) b = B.posy[h];
-        }
-        if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
     }
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&c1_sh, c);
