@@ -810,8 +810,10 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     // recorded in the dirty flags (dcr_graph_add_edge / _remove_edge / dcr_sdrf_tail do that)
     const bool incremental = want_incremental && g->curv_valid && g->curv_type_last == curv_type && g->dirty_tracked;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev0, g->stream));
+    g->h2_cleared_dirty = false;
     DCR_TRY(launch_curvature_pass(g, curv_type, incremental));
-    DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+    // (the two-hop launch zeroes the flags in its first kernel: one fill launch less at the tail of every pass)
+    if (!(g->last_engine == 0 && g->h2_cleared_dirty)) DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
     g->dirty_tracked = true;
     g->pending_edits = 0;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));
@@ -819,8 +821,16 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     DCR_TRY(sync_result(g));
     if (g->last_engine == 0) {
         for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
-        for (int grow = 0; grow < 4 && g->hres->h2_status == 2 && g->hres->misc[0] == 0 && h2_grow_pools(g); ++grow) {
-            // the pools of its triangle step were too small (dense neighbourhoods): run it again with what it asked for
+        for (int again = 0; again < 6 && g->hres->misc[0] == 0; ++again) {
+            if (g->hres->h2_status == 3) {
+                // launched without its retry stage, and some node's tables filled up: nothing was written; from now on every
+                // pass of this graph carries the stage
+                g->h2_expect_retry = true;
+            } else if (g->hres->h2_status == 2 && h2_grow_pools(g)) {
+                // the pools of its triangle step were too small (dense neighbourhoods): run it again with what it asked for
+            } else {
+                break;
+            }
             g->ext_part_valid = false;
             DCR_TRY(launch_curvature_pass(g, curv_type, false));
             if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));

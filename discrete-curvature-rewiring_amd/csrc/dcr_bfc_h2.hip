@@ -1671,11 +1671,14 @@ __device__ inline int h2_probe_partners(const H2EdgeSet es, int w, const int32_t
 // Launched twice: `second` = 0 as soon as the block classes have finished (beside the wave classes, which list nothing),
 // for the candidates there are then; `second` = 1 after the retry launch for what that one listed.  (The split is read
 // from / left in the result block: h2_ncand_done is only written by the kernel that marks the first launch's end.)
-__global__ void k_h2_triangles_mark(H2Tasks tk) { *tk.n_done = *tk.n_cand; }
+// (Round 4: the first launch of a pool takes the candidates there are and records their number itself — a one-thread kernel did
+//  that before, and behind the split class on the main stream it took 20-50 us to get a wave.)
 __global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status, int second) {
-    if (*status != 0) return;
+    const int cand_now = *tk.n_cand;  // (stable: the kernels that list into this pool are through)
     const int first = second ? *tk.n_done : 0;
-    const int total = second ? *tk.n_cand : *tk.n_done;
+    const int total = cand_now;
+    if (!second && blockIdx.x == 0 && threadIdx.x == 0) *tk.n_done = cand_now;  // read by the retry stage's launch only
+    if (*status != 0) return;
     if (total <= first || first < 0 || total > tk.cand_cap) return;  // (beyond the pool: the pass is run again with larger pools)
     const int lane = threadIdx.x & 63;
     for (int64_t base = first + (((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll); base < total; base += (int64_t)gridDim.x * 256) {
@@ -1847,8 +1850,11 @@ __global__ void __launch_bounds__(H2_PLAN_THREADS) k_h2_plan(View g, const int32
 }
 
 // (round 4: also zeroes the weights — a fill launch of its own before)
-__global__ void __launch_bounds__(256) k_h2_clear(DevResult *res, int32_t *weight, int64_t n) {
+__global__ void __launch_bounds__(256) k_h2_clear(DevResult *res, int32_t *weight, int64_t n, unsigned *dirty_words, int64_t n_dirty_words) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) weight[i] = 0;
+    // (the incremental pass's per-node flags: a full pass recomputes every edge, so they can go now — a fill launch at the
+    //  tail of every pass before)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_dirty_words; i += (int64_t)gridDim.x * 256) dirty_words[i] = 0u;
     if (blockIdx.x != 0) return;
     if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
     if (threadIdx.x < H2_NB) {
@@ -1892,12 +1898,15 @@ __global__ void __launch_bounds__(256) k_h2_retry_zero(View g, const int4 *units
 #ifndef H2_FINAL_BLOCKS
 #define H2_FINAL_BLOCKS 1024   // (x 4 waves = 4,096 pairs of partial extrema: the reduction that follows is one workgroup)
 #endif
-// Launched twice per pass: `when` = 0 right behind the class kernels, BESIDE the retry launch, and it does the work iff the retry
-// list is empty (the usual case: the three retry kernels are then 27 us of empty launches that used to sit on the critical
-// path in front of it); `when` = 1 behind the retry launch, doing the work iff there was something to retry.
+// `when` = 0: the pass was launched WITHOUT its retry stage (no pass of this graph has needed it so far: three launches and a
+// stream join less on the critical path of every pass); should the retry list turn out not to be empty, nothing is written,
+// status 3 is left and the host runs the pass again with the stage.  `when` = 1: behind the retry stage, unconditionally.
 __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, double *curv, const int32_t *status, Ext *part_min,
                                                   Ext *part_max, const int32_t *retry_count, int when) {
-    if ((*retry_count > 0) != (when != 0)) return;  // uniform (the count is final once the class kernels are through)
+    if (when == 0 && *retry_count > 0) {  // uniform (the count is final once the class kernels are through)
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicCAS(const_cast<int32_t *>(status), 0, 3);
+        return;
+    }
     double lo_v = 0.0, hi_v = 0.0;
     int lo_s = -1, hi_s = -1;
     const bool live = *status == 0;  // (else some records are missing: the whole pass is redone by the node-centric kernels)
@@ -2140,8 +2149,11 @@ int launch_curvature_pass_h2(dcr_graph *g) {
                       &dr->h2_npart[1], &dr->h2_ncand_done[1], g->dres, g->h2_weight, 0u, lists_M};  // pool 1: class M
     {
         const int64_t cb = (g->n + 255) / 256;
+        // (dirty: n bytes, allocated in whole words? — only the whole words are zeroed here, the caller's fill takes the rest)
+        const bool whole = g->n % 4 == 0;
         hipLaunchKernelGGL(k_h2_clear, dim3((unsigned)(cb < 1 ? 1 : cb > 2048 ? 2048 : cb)), dim3(256), 0, g->stream, g->dres, g->h2_weight,
-                           g->n);
+                           g->n, reinterpret_cast<unsigned *>(g->dirty), whole ? g->n / 4 : (int64_t)0);
+        g->h2_cleared_dirty = whole;
     }
     static const bool serial = getenv("DCR_SERIAL_BINS") != nullptr;
     const int64_t sblocks = (g->cap_total + 255) / 256;
@@ -2204,25 +2216,32 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     }
     g->h2_eset_valid = true;
     g->h2_eset_pending = 0;
+    // The tail.  Without a retry stage (the usual case) everything below runs on the MAIN stream, behind the split class that is
+    // already there: its candidates' triangle step, class M's when M is through, the closing kernel when the wave classes are —
+    // the critical path (split class -> triangle steps -> closing kernel) crosses no stream.  (Round 3 had the triangle steps on
+    // a stream of their own and the main stream joined five streams before the closing kernel: two hops of 15-30 us each.)
+    const bool retry_stage = g->h2_expect_retry;
+    if (!serial && !retry_stage) sT = g->stream;
     if (!serial) {
         DCR_HIP(hipEventRecord(g->ev_aux, sa));
-        DCR_HIP(hipEventRecord(g->ev_join[0], sL));
         DCR_HIP(hipEventRecord(g->ev_join[1], sM));
-        DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[0], 0));
+        if (sT != sL) {
+            DCR_HIP(hipEventRecord(g->ev_join[0], sL));
+            DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[0], 0));
+        }
         DCR_HIP(hipStreamWaitEvent(sT, g->ev_aux, 0));
     }
     // the split class's candidates as soon as IT is done (beside class M and the wave classes), class M's when M is
-    hipLaunchKernelGGL(k_h2_triangles_mark, dim3(1), dim3(1), 0, sT, tk);
     hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 4)), dim3(256), 0, sT, es, tk, g->h2_rec, status, 0);
     if (!serial) DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[1], 0));
-    hipLaunchKernelGGL(k_h2_triangles_mark, dim3(1), dim3(1), 0, sT, tkM);
     hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sT, es, tkM, g->h2_rec, status, 0);
     if (!serial) {
-        DCR_HIP(hipEventRecord(g->ev_join[3], sT));
+        if (sT != g->stream) DCR_HIP(hipEventRecord(g->ev_join[3], sT));
         DCR_HIP(hipEventRecord(g->ev_join[2], sS0));
         DCR_HIP(hipEventRecord(g->ev_aux2, sS1));
         DCR_HIP(hipEventRecord(g->ev_fork, sS2));
-        for (hipEvent_t ev : {g->ev_join[3], g->ev_join[2], g->ev_aux2, g->ev_fork}) DCR_HIP(hipStreamWaitEvent(g->stream, ev, 0));
+        if (sT != g->stream) DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[3], 0));
+        for (hipEvent_t ev : {g->ev_join[2], g->ev_aux2, g->ev_fork}) DCR_HIP(hipStreamWaitEvent(g->stream, ev, 0));
     }
     if (!g->ext_part) {
         Ext *p = nullptr;
@@ -2233,23 +2252,16 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     if (fblocks > H2_FINAL_BLOCKS) fblocks = H2_FINAL_BLOCKS;
     if (fblocks > EXT_PART_BLOCKS / 4) fblocks = EXT_PART_BLOCKS / 4;  // (a pair of partial extrema per WAVE)
     if (fblocks < 1) fblocks = 1;
-    // the closing kernel, optimistically beside the retry launch (it steps aside when there is something to retry)
-    if (!serial) {
-        DCR_HIP(hipEventRecord(g->ev_aux, g->stream));
-        DCR_HIP(hipStreamWaitEvent(sT, g->ev_aux, 0));
+    if (retry_stage) {
+        // nodes whose tables filled up in their class: zero their records, redo them with worst-case partitions
+        hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
+                           g->h2_rec);
+        tk.retry_flag = 0x80000000u;
+        launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
+        hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 2)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status, 1);
     }
-    hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fblocks), dim3(256), 0, sT, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
-                       (Ext *)g->ext_part + EXT_PART_BLOCKS, &g->dres->h2_retry, 0);
-    if (!serial) DCR_HIP(hipEventRecord(g->ev_join[3], sT));
-    // nodes whose tables filled up in their class: zero their records, redo them with worst-case partitions
-    hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
-                       g->h2_rec);
-    tk.retry_flag = 0x80000000u;
-    launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
-    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 2)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status, 1);
-    if (!serial) DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[3], 0));
     hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fblocks), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
-                       (Ext *)g->ext_part + EXT_PART_BLOCKS, &g->dres->h2_retry, 1);
+                       (Ext *)g->ext_part + EXT_PART_BLOCKS, &g->dres->h2_retry, retry_stage ? 1 : 0);
     g->ext_part_n = (int)fblocks * 4;
     g->ext_part_valid = true;  // (dropped again by the caller if the pass reports a failure, and by every edit)
     DCR_HIP(hipGetLastError());

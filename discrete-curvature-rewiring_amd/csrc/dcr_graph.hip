@@ -17,6 +17,16 @@ namespace dcr {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
+// Events that order the streams of a pass against each other.  A device-scope release when recorded (hipEventReleaseToDevice,
+// -DDCR_EVENT_DEVICE_SCOPE) instead of the default system-scope fence was measured: the gap between the split class and its
+// triangle step shrank from 50 to 6 us on the timeline, and the pass got 4 % SLOWER (1.053 against 1.004 ms on S100k, 10.75
+// against 10.44 on S1M, four interleaved rounds: profiles/r04_event_scope_ab.txt).  The default stays.
+#ifdef DCR_EVENT_DEVICE_SCOPE
+#define DCR_EVENT_FLAGS (hipEventDisableTiming | hipEventReleaseToDevice)
+#else
+#define DCR_EVENT_FLAGS (hipEventDisableTiming)
+#endif
+
 static inline int32_t slack_for(int32_t deg) {
     int32_t s = deg / 4;
     return s < 8 ? 8 : s;
@@ -444,8 +454,8 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_HIP(hipStreamCreate(&g->stream));
     DCR_HIP(hipEventCreate(&g->ev0));
     DCR_HIP(hipEventCreate(&g->ev1));
-    DCR_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-    DCR_HIP(hipEventCreateWithFlags(&g->ev_aux, hipEventDisableTiming));
+    DCR_HIP(hipEventCreateWithFlags(&g->ev_fork, DCR_EVENT_FLAGS));
+    DCR_HIP(hipEventCreateWithFlags(&g->ev_aux, DCR_EVENT_FLAGS));
     DCR_HIP(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
     // side[2] carries the finest-grained kernel of a pass (the smallest degree class): lowest priority, so that the
     // kernels with long units get their workgroups resident first and the fine-grained one fills in and finishes last
@@ -453,10 +463,10 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
     for (int b = 0; b < NBINS - 1; ++b) {
         DCR_HIP(hipStreamCreateWithPriority(&g->side[b], hipStreamNonBlocking, b == 2 ? prio_low : prio_high));
-        DCR_HIP(hipEventCreateWithFlags(&g->ev_join[b], hipEventDisableTiming));
+        DCR_HIP(hipEventCreateWithFlags(&g->ev_join[b], DCR_EVENT_FLAGS));
     }
     for (int b = 0; b < 2; ++b) DCR_HIP(hipStreamCreateWithPriority(&g->low[b], hipStreamNonBlocking, prio_low));
-    DCR_HIP(hipEventCreateWithFlags(&g->ev_aux2, hipEventDisableTiming));
+    DCR_HIP(hipEventCreateWithFlags(&g->ev_aux2, DCR_EVENT_FLAGS));
     DCR_TRY(dev_alloc(&g->rowinfo, n));
     DCR_TRY(dev_alloc(&g->rowcap, n));
     DCR_TRY(alloc_layout(g, tot));

@@ -87,7 +87,9 @@ struct DevResult {
     int32_t edit_n;
     int32_t edit_log[3 * 8];
     int32_t h2_retry;   // units on the retry list (nodes whose tables filled up in their class, redone by the largest class)
-    int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels)
+    int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels);
+                        // 2: the triangle step's pools were too small (run again with larger ones); 3: the pass was launched
+                        // without its retry stage and some node needed it (run again with the stage)
 };
 
 // Incremental pass: which edges an edit can have changed.  BFC(a,b) is a function of deg a, deg b, N(a) ∩ N(b) and the
@@ -245,6 +247,8 @@ struct dcr_graph {
     int64_t h2_weight_cap = 0;
     unsigned long long *h2_eset = nullptr;  // every undirected edge as one 64-bit key (open addressing), rebuilt per pass
     int h2_eset_bits = 0;
+    bool h2_expect_retry = false;      // some pass of this graph had nodes on the retry list: the retry stage is launched with every pass
+    bool h2_cleared_dirty = false;     // the last two-hop launch zeroed the incremental pass's node flags itself
     bool h2_eset_valid = false;        // the set holds the graph's edges as of the last two-hop pass; later edits are in the journal
     int h2_eset_pending = 0;           // upper bound of the edits journaled since (host-side count of the edit launches)
     int64_t h2_eset_tombs = 0;         // upper bound of the tombstones in the set (removals applied since the last rebuild)
