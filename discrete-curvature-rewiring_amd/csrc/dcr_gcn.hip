@@ -820,21 +820,50 @@ static void launch_act_linear_fwd(bool train, bool eval, const float *x, const f
 // epoch, as three kernels.  The gradient is -g / m at the picked entries and zero elsewhere, as the stock kernels give it.
 namespace dcr {
 
-__global__ void __launch_bounds__(1024) k_picked_mean_fwd(const float *__restrict__ lp, int64_t ld, const int64_t *__restrict__ y,
-                                                           int64_t m, int C, float *__restrict__ out) {
-    __shared__ double red[1024];
+// Round 4: many workgroups, each a fixed slice of the rows, and the LAST one to finish adds the slices' sums in slice order
+// (deterministic).  As one workgroup of 1,024 threads every thread walked ~100 rows of the bench's training split one
+// dependent pair of loads after the other: 92 us per epoch for a 100k-element gather.  The partial sums live in a buffer of
+// the library (one per device and process: calls are expected on one stream at a time, as the epoch's graph issues them).
+constexpr int PICKED_BLOCKS = 256;
+__device__ double picked_partial[PICKED_BLOCKS];
+__device__ unsigned picked_ticket;
+
+__global__ void __launch_bounds__(256) k_picked_mean_fwd(const float *__restrict__ lp, int64_t ld, const int64_t *__restrict__ y,
+                                                          int64_t m, int C, float *__restrict__ out) {
+    __shared__ double red[256];
+    __shared__ int last_sh;
+    const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
     double a = 0.0;
-    for (int64_t i = threadIdx.x; i < m; i += 1024) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         const int64_t t = y[i];
         if (t >= 0 && t < C) a += (double)lp[i * ld + t];
     }
     red[threadIdx.x] = a;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = (float)(-red[0] / (double)m);
+    if (threadIdx.x == 0) {
+        picked_partial[blockIdx.x] = red[0];
+        __threadfence();
+        last_sh = atomicAdd(&picked_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    red[threadIdx.x] = (int)threadIdx.x < (int)gridDim.x
+                           ? __hip_atomic_load(&picked_partial[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(-red[0] / (double)m);
+        picked_ticket = 0u;  // (for the next call)
+    }
 }
 
 __global__ void __launch_bounds__(256) k_picked_mean_bwd(const int64_t *__restrict__ y, int64_t m, int C, const float *__restrict__ g,
@@ -877,7 +906,10 @@ __global__ void __launch_bounds__(256) k_count_argmax_equal(const float *__restr
 extern "C" int dcr_nll_picked_mean_fwd_f32_dev(const float *lp, int64_t ld, const int64_t *y, int64_t m, int classes, float *out_loss,
                                                void *hip_stream) {
     if (!lp || !y || !out_loss || m <= 0 || classes < 1 || ld < classes) DCR_FAIL(DCR_EINVAL, "bad nll arguments");
-    hipLaunchKernelGGL(dcr::k_picked_mean_fwd, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, lp, ld, y, m, classes, out_loss);
+    int64_t blocks = (m + 255) / 256;
+    if (blocks > dcr::PICKED_BLOCKS) blocks = dcr::PICKED_BLOCKS;
+    hipLaunchKernelGGL(dcr::k_picked_mean_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, lp, ld, y, m, classes,
+                       out_loss);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
