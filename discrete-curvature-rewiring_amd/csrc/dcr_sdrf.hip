@@ -390,38 +390,46 @@ __device__ inline void imp_close_stats(ImpBuf B, int curv_type, int *shi) {
     __syncthreads();
 }
 
-// K4: class B (i == x, j = y_nb[b] in DY) for waves [0,dy), class C (j == y, i = x_nb[a] in DX) for waves [dy,dy+dx).
+// K4: class B (i == x, j = y_nb[b] in DY) for workgroups [0,dy), class C (j == y, i = x_nb[a] in DX) for [dy,dy+dx).
+// (Round 4: a workgroup per element, its four waves sharing the row — a wave per element left the kernel waiting 22 us for
+//  the one wave that streams a hub's 1,400-entry row.)
 __global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int y, unsigned mask, int curv_type) {
+    __shared__ int dec_sh, maxadj_sh;
     const ImpStats st = *B.st;
     const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wv = blockIdx.x;
     if (wv >= st.dx + st.dy) return;
     const bool isB = wv < st.dy;
     const int p = isB ? wv : wv - st.dy;
     const int cls = isB ? B.clsy[p] : B.clsx[p];
     double *out = isB ? B.impb : B.impc;
     if (cls != 0) {
-        if (lane == 0) out[p] = 0.0;
+        if (threadIdx.x == 0) out[p] = 0.0;
         return;
     }
     if (curv_type != DCR_CURV_BFC) {
         // 4 - d1 - d2 (+3T): one degree grows, one triangle appears (classical_curvatures.py:14-28)
         const double d = curv_type == DCR_CURV_1D ? -1.0 : curv_type == DCR_CURV_AUGMENTED ? 2.0 : 1.0;
-        if (lane == 0) out[p] = d;
+        if (threadIdx.x == 0) out[p] = d;
         return;
     }
+    if (threadIdx.x == 0) {
+        dec_sh = 0;
+        maxadj_sh = 0;
+    }
+    __syncthreads();
     const int2 rown = g.rowinfo[isB ? y : x];
     const int node = g.col[rown.x + p];  // j for class B, i for class C
     const int2 rn = g.rowinfo[node];
     const int32_t *cnt_other = isB ? B.c1 : B.c2;  // counters of the side that loses edges
     const int max_other = isB ? st.max1 : st.max2;
     int n_dec0 = 0, n_maxadj = 0;
-    for (int base = 0; base < rn.y; base += 256) {
+    for (int base = 0; base < rn.y; base += 4 * 256) {
         int w[4], h[4];
         bool in[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int t = base + 64 * q + lane;
+            const int t = base + 256 * q + (int)threadIdx.x;
             in[q] = t < rn.y;
             w[q] = in[q] ? g.col[rn.x + t] : -1;
         }
@@ -442,7 +450,14 @@ __global__ void __launch_bounds__(256) k_imp_bc(RowView g, ImpBuf B, int x, int 
             n_maxadj += __popcll(__ballot(mxa));
         }
     }
-    if (lane != 0) return;
+    if (lane == 0) {  // (the per-wave totals are uniform over the wave: one lane adds them)
+        if (n_dec0) atomicAdd(&dec_sh, n_dec0);
+        if (n_maxadj) atomicAdd(&maxadj_sh, n_maxadj);
+    }
+    __syncthreads();
+    n_dec0 = dec_sh;
+    n_maxadj = maxadj_sh;
+    if (threadIdx.x != 0) return;
     int s1, s2, m1, m2, d1, d2;
     if (isB) {
         const int cb = B.c2[p];
@@ -558,7 +573,9 @@ __global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int
     if (threadIdx.x == 0) {
         B.rowcount[a] = cnt_sh;
         if (a < dx) B.c1[a] = counting ? c1_sh : 0;
+#ifndef DCR_IMP_NOFENCE  // (timing-only build: is it the fences?)
         __threadfence();  // this workgroup's results, then its ticket
+#endif
         last_sh = atomicAdd(&stp->done_rows, 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
@@ -953,7 +970,7 @@ static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_
     hipLaunchKernelGGL(k_imp_rows_count, dim3(rows), dim3(256), (size_t)words * 4, g->stream, vw, B, x, y, mask, words, curv_type,
                        g->dres);
     if (dx + dy > 0)
-        hipLaunchKernelGGL(k_imp_bc, dim3((dx + dy + 3) / 4), dim3(256), 0, g->stream, vw, B, x, y, mask, curv_type);
+        hipLaunchKernelGGL(k_imp_bc, dim3(dx + dy), dim3(256), 0, g->stream, vw, B, x, y, mask, curv_type);
     hipLaunchKernelGGL(k_imp_emit, dim3(rows), dim3(256), 0, g->stream, vw, B, x, y, words, curv_type, g->imp_out,
                        g->imp_ci, g->imp_cj, ts);
     g->imp_table_dirty = false;
