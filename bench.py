@@ -183,12 +183,19 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     n_tr, n_va = int(train_mask.sum()), int(val_mask.sum())
     flops = 2.0 * 2.0 * n * F * H / world
     nnz_sel = 2.0 * (n_tr + n_va) / n * (ei_np.shape[1] + n)   # non-zeros of the selected rows (forward) and columns (backward)
-    byts = (n * H * 4 * (1 + 1 + 2) + n * C * 4 * 3 + 2 * n * H / 8 + nnz_sel * (C * 4 + 8)) / world
+    from models.gcn import first_layer_fused_ok
+    one_kernel_first = first_layer_fused_ok(x, model.act_fn, model.layers[0], model.layers[1].lin)
+    # (layer-1 output: written once, read + rewritten as its gradient by the fused backward; read once more by the activation
+    #  forward only where the first layer is not the one-kernel form, csrc/dcr_gcn_first.hip)
+    byts = (n * H * 4 * (1 + (0 if one_kernel_first else 1) + 2) + n * C * 4 * 3 + 2 * n * H / 8 + nnz_sel * (C * 4 + 8)) / world
     floor_ms = (flops / (F32_MATRIX_PEAK_TFLOPS * 1e12) + byts / (HBM_PEAK_GBPS * 1e9)) * 1e3
     res['epoch_floor_ms'] = floor_ms
     res['epoch_floor_frac'] = floor_ms / res['ms_per_epoch']
     res['epoch_floor_definition'] = ('layer-1 forward + weight-gradient contractions (2 x 2 N F H flop) at 157.3 TFLOP/s f32 MFMA, plus '
                                      'the bytes of the fused activation kernels and of the row-selected aggregations at 8 TB/s')
+    res['first_layer'] = ('one kernel: (A_hat X) W1^T + b1, ReLU + dropout and the second layer\'s lin on the matrix cores '
+                          '(dcr_first_layer_fwd_f32_dev; DCR_FIRST_FUSED=0: GEMM library + dcr_act_linear_fwd_f32_dev)'
+                          if one_kernel_first else 'GEMM library + dcr_act_linear_fwd_f32_dev')
     res['adam'] = ('torch fused (one kernel per group; DCR_FUSED_ADAM=0: stock foreach implementation, the experiment drivers\' default)'
                    if getattr(opt, 'defaults', {}).get('fused') else 'torch stock (foreach), capturable')
     res['last_aggregation'] = ('evaluated at the rows the epoch reads (training rows for the loss, validation rows for the accuracy: '

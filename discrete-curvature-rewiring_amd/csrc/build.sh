@@ -7,9 +7,9 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -Wall -Wno-unused-function"
 OBJS=""
 PIDS=""
-for f in dcr_graph dcr_bfc dcr_bfc_nc dcr_bfc_h2 dcr_bfc_dense dcr_bfc_giant dcr_sdrf dcr_gcn dcr_gemm; do
+for f in dcr_graph dcr_bfc dcr_bfc_nc dcr_bfc_h2 dcr_bfc_dense dcr_bfc_giant dcr_sdrf dcr_gcn dcr_gcn_first dcr_gemm; do
   [ -f $f.hip ] || continue
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ dcr_internal.h -nt $f.o ] || [ dcr_bfc_common.h -nt $f.o ] || [ ../../include/dcr.h -nt $f.o ]; then
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ dcr_internal.h -nt $f.o ] || [ dcr_bfc_common.h -nt $f.o ] || [ dcr_philox.h -nt $f.o ] || [ ../../include/dcr.h -nt $f.o ]; then
     rm -f $f.o                      # a failed compile must not leave the previous object for the link
     $HIPCC $FLAGS -c $f.hip -o $f.o &
     PIDS="$PIDS $!"

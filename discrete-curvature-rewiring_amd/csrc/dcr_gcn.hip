@@ -7,6 +7,7 @@
 // the dense contraction (X·Wᵀ) is done before this kernel on the matrix cores by the GEMM library.
 #include <cstdint>
 #include "dcr_internal.h"
+#include "dcr_philox.h"
 
 namespace dcr {
 
@@ -291,28 +292,6 @@ extern "C" int dcr_spmm_csr_rows2_f32_dev(const int64_t *rowptr, const int32_t *
 // byte mask (4.9 GB of traffic per training step at 1M x 128; this is 2.1 GB).  Random numbers: Philox-4x32-10 keyed by
 // (seed, call offset), counter = element-quad index, so a run is reproducible for a given torch seed.
 namespace dcr {
-
-__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (uint32_t)p1;
-    c[3] = (uint32_t)p0;
-    c[0] = n0;
-    c[2] = n2;
-}
-
-__device__ inline void philox4x32_10(uint64_t index, uint64_t offset, uint64_t seed, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = c[j];
-}
 
 // thread t owns elements 4t .. 4t+3; wave w stores the four keep-ballots of its 256 elements in bits[4w .. 4w+3]
 __global__ void __launch_bounds__(256) k_relu_dropout_fwd(const float *__restrict__ x, float *__restrict__ y,

@@ -14,6 +14,7 @@ hand-written HIP kernel ``dcr_spmm_csr_f32_dev`` (csrc/dcr_gcn.hip), wrapped in
 an autograd Function whose backward is the same kernel on Âᵀ.
 """
 import ctypes
+import os
 import math
 from typing import List
 
@@ -540,6 +541,83 @@ def act_then_linear(x, act_fn, dropout, lin, want_train=True, want_eval=False):
     return z_tr, z_ev
 
 
+class _FirstLayerFn(torch.autograd.Function):
+    """The first layer's GEMM on Â·X, bias, ReLU (+ dropout) and the second layer's lin in ONE kernel on the matrix cores
+    (csrc/dcr_gcn_first.hip, dcr_first_layer_fwd_f32_dev): models/gcn.py:36-42 from ``x`` of the first GCNConv to the
+    second GCNConv's ``lin`` output, for the training operand, the evaluation operand or both.  The hidden activation
+    never leaves the registers; the pre-activation is written once for the backward pass (training) or not at all.
+    Backward: the fused MFMA pass of _ActLinearFn (dx, db1 = column sums of dx, dW2), then dW1 = dxᵀ·(Â·X)."""
+
+    @staticmethod
+    def forward(ctx, ax, w1, b1, w2, p, want_train, want_eval):
+        from dcr import _lib
+        ax, w1, w2 = ax.contiguous(), w1.contiguous(), w2.contiguous()
+        n, feats = ax.shape
+        hidden, classes = w1.shape[0], w2.shape[0]
+        stream = torch.cuda.current_stream(ax.device).cuda_stream
+        if want_train and want_eval:
+            both = torch.empty((n, 2 * classes), dtype=ax.dtype, device=ax.device)
+            z_tr, z_ev = both[:, :classes], both[:, classes:]
+        else:
+            z_tr = torch.empty((n, classes), dtype=ax.dtype, device=ax.device) if want_train else None
+            z_ev = torch.empty((n, classes), dtype=ax.dtype, device=ax.device) if want_eval else None
+        ldz = 2 * classes if (want_train and want_eval) else classes
+        bits = ctr = pre = None
+        if want_train:
+            words = ctypes.c_int64()
+            _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n * hidden, ctypes.byref(words)))
+            bits = torch.empty(max(words.value, 1), dtype=torch.int64, device=ax.device)
+            ctr = _dropout_counter(ax.device)
+            pre = torch.empty((n, hidden), dtype=ax.dtype, device=ax.device)
+        _lib.check(_lib.lib().dcr_first_layer_fwd_f32_dev(
+            ax.data_ptr(), feats, w1.data_ptr(), None if b1 is None else b1.data_ptr(), w2.data_ptr(),
+            None if pre is None else pre.data_ptr(), z_tr.data_ptr() if want_train else None,
+            z_ev.data_ptr() if want_eval else None, ldz, bits.data_ptr() if want_train else None, n, feats, hidden, classes,
+            float(p), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None, ctypes.c_void_p(stream)))
+        if want_train:
+            ctr.add_(1)
+            ctx.save_for_backward(ax, w2)
+            ctx.pre, ctx.bits, ctx.p, ctx.has_bias = pre, bits, float(p), b1 is not None
+        if want_eval:
+            ctx.mark_non_differentiable(z_ev)
+        return z_tr, z_ev
+
+    @staticmethod
+    def backward(ctx, g_tr, g_ev):
+        from dcr import _lib
+        ax, w2 = ctx.saved_tensors
+        pre = ctx.pre
+        g_tr = g_tr.contiguous()
+        stream = torch.cuda.current_stream(g_tr.device).cuda_stream
+        n, hidden = pre.shape
+        gx = torch.empty_like(pre)
+        gw2 = torch.empty_like(w2)
+        colsum = torch.empty(hidden, dtype=torch.float32, device=pre.device)
+        need = ctypes.c_int64()
+        _lib.check(_lib.lib().dcr_act_linear_bwd_fused_workspace(n, hidden, ctypes.byref(need)))
+        ws = torch.empty(max(need.value, 1), dtype=torch.float32, device=pre.device)
+        _lib.check(_lib.lib().dcr_act_linear_bwd_fused_f32_dev(g_tr.data_ptr(), w2.data_ptr(), ctx.bits.data_ptr(), pre.data_ptr(),
+                                                               gx.data_ptr(), gw2.data_ptr(), colsum.data_ptr(), ws.data_ptr(),
+                                                               need.value, n, hidden, w2.shape[0], ctx.p, ctypes.c_void_p(stream)))
+        gw1 = None
+        if ctx.needs_input_grad[1]:
+            tall = n >= 64 * max(ax.shape[1], hidden)   # (as _LinearFn.backward)
+            gw1 = atb_hip(gx, ax) if tall else gx.t() @ ax
+        gb1 = colsum if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return None, gw1, gb1, (gw2 if ctx.needs_input_grad[3] else None), None, None, None
+
+
+def first_layer_fused_ok(ax, act_fn, first, lin2):
+    """Whether dcr_first_layer_fwd_f32_dev takes this shape: ReLU, fp32 on the MI355X, the input width a multiple of 16
+    with W1 fitting the LDS of a CU, hidden width 64 / 128, at most 16 classes.  ``DCR_FIRST_FUSED=0`` switches it off."""
+    if not (_AGG_BACKEND == 'hip' and ax.is_cuda and ax.dtype == torch.float32 and ax.dim() == 2 and isinstance(act_fn, ReLU)):
+        return False
+    if os.environ.get('DCR_FIRST_FUSED', '1') == '0' or ax.data_ptr() % 16:
+        return False
+    from dcr import _lib
+    return bool(_lib.lib().dcr_first_layer_fits(int(ax.shape[1]), int(first.lin.weight.shape[0]), int(lin2.weight.shape[0])))
+
+
 class _Linear(torch.nn.Module):
     """torch_geometric.nn.dense.linear.Linear(in, out, bias=False, weight_initializer='glorot')."""
 
@@ -661,6 +739,30 @@ class GCN(torch.nn.Module):
         for conv in self.layers:
             conv.reset_parameters()
 
+    def _fused_first(self, data, want_train, want_eval):
+        """(z_train, z_eval) of the SECOND layer's lin straight from Â·X (one kernel, _FirstLayerFn), or None when the
+        shapes, the mode or the backend ask for the separate kernels: each operand then takes the route it would take alone,
+        so training, evaluation and the one-pass epoch see the same numbers whichever of them asks."""
+        first, second = self.layers[0], self.layers[1]
+        x = data.x
+        if not (first.propagate_input_first and not x.requires_grad and x.dtype == torch.float32 and x.is_cuda):
+            return None
+        p = self.dropout.p
+        if want_train and not (self.dropout.training and 0.0 < p < 1.0):
+            return None
+        grads = torch.is_grad_enabled() and any(q.requires_grad for q in list(first.parameters()) + [second.lin.weight])
+        if want_eval and not want_train and grads:
+            return None                                   # evaluation mode WITH a gradient: the stock modules
+        csr = first.norm_csr(data.edge_index, data.edge_attr, x.shape[0])
+        ax = first.propagated_input(x, csr)
+        if not first_layer_fused_ok(ax, self.act_fn, first, second.lin):
+            return None
+        if want_train:
+            return _FirstLayerFn.apply(ax, first.lin.weight, first.bias, second.lin.weight, p, True, want_eval)
+        with torch.no_grad():
+            return _FirstLayerFn.apply(ax, first.lin.weight.detach(), None if first.bias is None else first.bias.detach(),
+                                       second.lin.weight.detach(), 0.0, False, True)
+
     supports_rows = True   # forward(data, rows=...) / forward_pair(data, rows_train=..., rows_eval=...)
 
     def forward(self, data, rows=None):
@@ -670,17 +772,24 @@ class GCN(torch.nn.Module):
         # index order — what ``model(data)[rows]`` holds, value for value; the last aggregation is evaluated at those
         # rows and nowhere else.
         layers = list(self.layers)
-        h = layers[0](data.x, data.edge_index, edge_weight=data.edge_attr)
-        if rows is not None and len(layers) == 1:
-            h = h[rows] if rows.dtype == torch.bool else h.index_select(0, rows)
+        z_first = self._fused_first(data, self.training, not self.training) if len(layers) > 1 else None
+        if z_first is None:
+            h = layers[0](data.x, data.edge_index, edge_weight=data.edge_attr)
+            if rows is not None and len(layers) == 1:
+                h = h[rows] if rows.dtype == torch.bool else h.index_select(0, rows)
         for conv in layers[1:]:
-            csr = conv.norm_csr(data.edge_index, data.edge_attr, h.shape[0])
-            if self.training:
-                z, _ = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=False)
-            elif torch.is_grad_enabled() and h.requires_grad:
-                z = conv.lin(self.dropout(self.act_fn(h)))   # evaluation mode WITH a gradient (not on the training path)
+            if z_first is not None:          # first layer, activation and this layer's lin came out of one kernel
+                z, n_nodes = z_first[0 if self.training else 1], z_first[0 if self.training else 1].shape[0]
+                z_first = None
             else:
-                _, z = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
+                n_nodes = h.shape[0]
+                if self.training:
+                    z, _ = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=False)
+                elif torch.is_grad_enabled() and h.requires_grad:
+                    z = conv.lin(self.dropout(self.act_fn(h)))   # evaluation mode WITH a gradient (not on the training path)
+                else:
+                    _, z = act_then_linear(h, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
+            csr = conv.norm_csr(data.edge_index, data.edge_attr, n_nodes)
             if rows is not None and conv is layers[-1]:
                 sel = conv.row_selection(rows, csr)
                 h = sel.expanded(aggregate_rows(z, conv.bias, csr, sel))
@@ -700,15 +809,19 @@ class GCN(torch.nn.Module):
             raise ValueError('rows_train and rows_eval go together')
         last = len(self.layers) - 1
         first = self.layers[0]
-        o_tr = first(data.x, data.edge_index, edge_weight=data.edge_attr)
-        o_ev = o_tr.detach()
+        z_first = self._fused_first(data, True, True) if last > 0 else None
+        if z_first is None:
+            o_tr = first(data.x, data.edge_index, edge_weight=data.edge_attr)
+            o_ev = o_tr.detach()
         for depth, conv in enumerate(list(self.layers)[1:], start=1):
-            if o_ev.data_ptr() == o_tr.data_ptr():       # the same pre-activation (first hidden layer): one pass for both
+            if z_first is not None:                      # first layer, activation and this layer's lin out of one kernel
+                (z_tr, z_ev), z_first = z_first, None
+            elif o_ev.data_ptr() == o_tr.data_ptr():     # the same pre-activation (first hidden layer): one pass for both
                 z_tr, z_ev = act_then_linear(o_tr, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=True)
             else:                                        # (dropout is the identity in evaluation mode)
                 z_tr, _ = act_then_linear(o_tr, self.act_fn, self.dropout, conv.lin, want_train=True, want_eval=False)
                 _, z_ev = act_then_linear(o_ev, self.act_fn, self.dropout, conv.lin, want_train=False, want_eval=True)
-            csr = conv.norm_csr(data.edge_index, data.edge_attr, o_tr.shape[0])
+            csr = conv.norm_csr(data.edge_index, data.edge_attr, z_tr.shape[0])
             if rows_train is not None and depth == last:
                 sel_tr, sel_ev = conv.row_selection(rows_train, csr), conv.row_selection(rows_eval, csr)
                 o_tr, o_ev = _AggregateRowsPair.apply(z_tr, z_ev, conv.bias, csr, sel_tr, sel_ev)

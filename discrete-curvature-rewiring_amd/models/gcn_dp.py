@@ -23,7 +23,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from models.gcn import (GCN, RowSelection, act_then_linear, aggregate, aggregate_rows, gcn_norm_csr, relu_dropout, spmm, spmm_pair,
+from models.gcn import (GCN, RowSelection, _FirstLayerFn, first_layer_fused_ok, act_then_linear, aggregate, aggregate_rows, gcn_norm_csr, relu_dropout, spmm, spmm_pair,
                         spmm_rows)
 
 
@@ -225,14 +225,25 @@ class ShardedGCN(torch.nn.Module):
         ``rows_train`` / ``rows_eval`` (RowSelection, both or neither): those rows of the two outputs only."""
         layers = list(self.gcn.layers)
         first = layers[0]
+        z_first = None
         if first.propagate_input_first and not x_local.requires_grad:
-            o_tr = first.lin(self.propagated_input_local(x_local), first.bias)
+            ax = self.propagated_input_local(x_local)
+            drop = self.gcn.dropout
+            if (len(layers) > 1 and drop.training and 0.0 < drop.p < 1.0
+                    and first_layer_fused_ok(ax, self.gcn.act_fn, first, layers[1].lin)):
+                # (Â_p·X)·W1ᵀ + b1, the activation and the second layer's lin in one kernel (models/gcn.py, _FirstLayerFn)
+                z_first = _FirstLayerFn.apply(ax, first.lin.weight, first.bias, layers[1].lin.weight, drop.p, True, True)
+            else:
+                o_tr = first.lin(ax, first.bias)
         else:
             z = _GatherRows.apply(first.lin(x_local), self.n, self.per, self.group)
             o_tr = aggregate(z, first.bias, self.csr)
-        o_ev = o_tr.detach()
+        if z_first is None:
+            o_ev = o_tr.detach()
         for layer in layers[1:]:
-            if o_ev.data_ptr() == o_tr.data_ptr():
+            if z_first is not None:
+                (z_tr, z_ev), z_first = z_first, None
+            elif o_ev.data_ptr() == o_tr.data_ptr():
                 z_tr, z_ev = act_then_linear(o_tr, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=True, want_eval=True)
             else:
                 z_tr, _ = act_then_linear(o_tr, self.gcn.act_fn, self.gcn.dropout, layer.lin, want_train=True, want_eval=False)

@@ -267,6 +267,20 @@ int dcr_act_linear_bwd_workspace(int64_t n_rows, int hidden, int64_t *floats);
 int dcr_act_linear_bwd_colsum_f32_dev(const float *dz_dev, const float *w_dev, const uint64_t *bits_dev, float *dx_dev,
                                       float *colsum_dev, float *ws_dev, int64_t ws_floats, int64_t n_rows, int hidden, int classes,
                                       double p, void *hip_stream);
+/* The first GCNConv (models/gcn.py:36, on a precomputed Â·X), the activation and dropout after it (models/gcn.py:38-42) and the
+ * second GCNConv's lin in ONE kernel on the matrix cores (csrc/dcr_gcn_first.hip):
+ *     pre = ax · W1ᵀ + b1   [n_rows x hidden]   (written when pre_dev != NULL: the backward pass reads it)
+ *     z_train = dropout_p(relu(pre)) · W2ᵀ,  z_eval = relu(pre) · W2ᵀ   [n_rows x classes, row stride ldz]; either may be NULL
+ * Keep bits, Philox stream and the order of operations of the second contraction are those of dcr_act_linear_fwd_f32_dev on
+ * the same pre, so dcr_act_linear_bwd_fused_f32_dev(dz, W2, bits, pre, ...) is its backward.  b1_dev may be NULL.  Shapes:
+ * dcr_first_layer_fits(in_features, hidden, classes) != 0 (in_features a multiple of 16 with W1 fitting one CU's LDS, hidden 64 or
+ * 128, classes <= 16); others return DCR_EINVAL — the caller keeps the GEMM library + dcr_act_linear_fwd_f32_dev for them. */
+int dcr_first_layer_fits(int in_features, int hidden, int classes);
+int dcr_first_layer_fwd_f32_dev(const float *ax_dev, int64_t ldx, const float *w1_dev, const float *b1_dev, const float *w2_dev,
+                                float *pre_dev, float *z_train_dev, float *z_eval_dev, int64_t ldz, uint64_t *bits_dev, int64_t n_rows,
+                                int in_features, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
+                                const uint64_t *offset_dev, void *hip_stream);
+
 /* The whole backward of dcr_act_linear_fwd_f32_dev's training operand in one pass over x, on the matrix cores: dx as above,
  * colsum_dev[hidden] = its column sums, dw_dev[classes x hidden] = dz^T · h with h = keep ? x / (1 - p) : 0 rebuilt from x and
  * the keep bits (the forward call may then pass h_train_dev = NULL and store no activation).  Replaces the weight-gradient

@@ -608,3 +608,138 @@ def test_activation_fused_into_the_next_contraction(hidden, classes, n):
     want_gpre = torch.where(keep1, (gz.double() @ w.double()).float() / (1 - p), torch.zeros_like(pre)).double()
     assert (b1.grad.double() - want_gpre.sum(0)).abs().max().item() < 1e-3 * max(1.0, float(n) ** 0.5)
     assert (w1.grad.double() - want_gpre.t() @ a.double()).abs().max().item() < 1e-2 * max(1.0, float(n) ** 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('feats,hidden,classes,n', [(256, 128, 16, 5003), (48, 64, 6, 2120), (16, 128, 7, 65), (32, 64, 16, 1),
+                                                    (320, 64, 3, 40000)])
+def test_first_layer_activation_and_next_lin_in_one_kernel(feats, hidden, classes, n):
+    """dcr_first_layer_fwd_f32_dev (models/gcn.py:36-42 from the first GCNConv's x to the second GCNConv's lin, on Â·X): the
+    pre-activation against a float64 contraction; both outputs, the keep bits and every gradient EQUAL to what
+    dcr_act_linear_fwd_f32_dev / its backward make of that same pre-activation (same Philox stream, same order of operations);
+    pair, train-only and eval-only calls agree bit for bit; the weight gradient of the first layer against float64."""
+    import ctypes
+    from dcr import _lib
+    from models import gcn
+    from models.gcn import _ActLinearFn, _FirstLayerFn
+    gcn.set_aggregate_backend('hip')
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    ax = torch.randn(n, feats, device=dev, generator=g)
+    w1 = torch.randn(hidden, feats, device=dev, generator=g) * (feats ** -0.5)
+    b1 = torch.randn(hidden, device=dev, generator=g) * 0.1
+    w2 = torch.randn(classes, hidden, device=dev, generator=g) * 0.1
+    assert _lib.lib().dcr_first_layer_fits(feats, hidden, classes) == 1
+    p = 0.4
+    ctr = gcn._dropout_counter(dev)
+    c0 = ctr.clone()
+    # the kernel by its C entry point: pre, bits, both outputs
+    words = ctypes.c_int64()
+    _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n * hidden, ctypes.byref(words)))
+    bits = torch.zeros(words.value, dtype=torch.int64, device=dev)
+    pre = torch.empty(n, hidden, device=dev)
+    both = torch.empty(n, 2 * classes, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    _lib.check(_lib.lib().dcr_first_layer_fwd_f32_dev(ax.data_ptr(), feats, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), pre.data_ptr(),
+                                                      both.data_ptr(), both.data_ptr() + 4 * classes, 2 * classes, bits.data_ptr(), n, feats,
+                                                      hidden, classes, p, seed, 0, ctr.data_ptr(), st))
+    want_pre = (ax.double() @ w1.double().t() + b1.double())
+    assert (pre.double() - want_pre).abs().max().item() < 2e-5 * max(1.0, want_pre.abs().max().item())
+    xr = pre.clone().requires_grad_(True)
+    w2r = w2.clone().requires_grad_(True)
+    ctr.copy_(c0)
+    z_tr, z_ev = _ActLinearFn.apply(xr, w2r, p, True, True)                  # the two-kernel route on the SAME pre-activation
+    assert torch.equal(both[:, :classes], z_tr.detach()) and torch.equal(both[:, classes:], z_ev)
+    ctr.copy_(c0)
+    w1f, b1f, w2f = (t.clone().requires_grad_(True) for t in (w1, b1, w2))
+    f_tr, f_ev = _FirstLayerFn.apply(ax, w1f, b1f, w2f, p, True, True)
+    assert torch.equal(f_tr.detach(), z_tr.detach()) and torch.equal(f_ev, z_ev) and not f_ev.requires_grad
+    gz = torch.randn(n, classes, device=dev, generator=g)
+    z_tr.backward(gz)
+    f_tr.backward(gz)
+    assert torch.equal(w2f.grad, w2r.grad)
+    gpre = xr.grad                                                            # d loss / d pre of the two-kernel route
+    assert torch.equal(b1f.grad, gpre._dcr_colsum[2]) if hasattr(gpre, '_dcr_colsum') else True
+    assert (b1f.grad.double() - gpre.double().sum(0)).abs().max().item() < 1e-3 * max(1.0, float(n) ** 0.5)
+    assert (w1f.grad.double() - gpre.double().t() @ ax.double()).abs().max().item() < 1e-2 * max(1.0, float(n) ** 0.5)
+    ctr.copy_(c0)
+    only_tr = _FirstLayerFn.apply(ax, w1, b1, w2, p, True, False)[0]
+    only_ev = _FirstLayerFn.apply(ax, w1, b1, w2, 0.0, False, True)[1]
+    assert torch.equal(only_tr, f_tr.detach()) and torch.equal(only_ev, f_ev)
+    no_bias = _FirstLayerFn.apply(ax, w1, None, w2, 0.0, False, True)[1]
+    want = (torch.relu(ax.double() @ w1.double().t()) @ w2.double().t())
+    assert (no_bias.double() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    # shapes outside the kernel's reach are refused, not approximated
+    assert _lib.lib().dcr_first_layer_fits(3703, 64, 6) == 0 and _lib.lib().dcr_first_layer_fits(24, 64, 6) == 0
+    assert _lib.lib().dcr_first_layer_fits(512, 128, 16) == 0 and _lib.lib().dcr_first_layer_fits(256, 96, 16) == 0
+    rc = _lib.lib().dcr_first_layer_fwd_f32_dev(ax.data_ptr(), 24, w1.data_ptr(), None, w2.data_ptr(), None, None, both.data_ptr(),
+                                                classes, None, n, 24, hidden, classes, 0.0, 0, 0, None, st)
+    assert rc != 0
+
+
+@pytest.mark.gpu
+def test_model_with_the_one_kernel_first_layer_equals_the_separate_kernels(monkeypatch):
+    """GCN.forward / forward_pair on a shape the one-kernel first layer takes (32 features, hidden 64): logits and gradients
+    within float32 rounding of the route through the GEMM library + dcr_act_linear_fwd_f32_dev (DCR_FIRST_FUSED=0), and of the
+    dense float64 restatement; training, evaluation and the one-pass epoch see the same numbers."""
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from models import gcn
+    from models.gcn import GCN, dense_reference_logits
+    gcn.set_aggregate_backend('hip')
+    dev = torch.device('cuda', 0)
+    ei, n = synthetic.powerlaw_graph(3000, 4, seed=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 32, generator=g)
+    y = torch.randint(0, 5, (n,), generator=g)
+    data = Data(x=x.to(dev), edge_index=torch.from_numpy(ei).to(dev), y=y.to(dev), num_nodes=n)
+    torch.manual_seed(0)
+    model = GCN(Dataset(data, 5), hidden=[64], dropout=0.5).to(dev)
+    with torch.no_grad():
+        model.layers[0].bias.uniform_(-0.1, 0.1)
+    calls = {'n': 0}
+    real = gcn._FirstLayerFn.apply
+
+    def counting(*a):
+        calls['n'] += 1
+        return real(*a)
+    monkeypatch.setattr(gcn._FirstLayerFn, 'apply', staticmethod(counting))
+    ctr = gcn._dropout_counter(dev)
+    start = ctr.clone()
+
+    def run(fused):
+        monkeypatch.setenv('DCR_FIRST_FUSED', '1' if fused else '0')
+        ctr.copy_(start)                                  # the same dropout masks in both runs
+        model.zero_grad()
+        model.eval()
+        with torch.no_grad():
+            ev = model(data)
+        model.train()
+        c0 = ctr.clone()
+        tr = model(data)
+        loss = torch.nn.functional.nll_loss(tr, data.y)
+        loss.backward()
+        grads = [q.grad.clone() for q in model.parameters()]
+        ctr.copy_(c0)
+        p_tr, p_ev = model.forward_pair(data)
+        ctr.copy_(c0)
+        rows = torch.arange(0, n, 7, device=dev)
+        r_tr, r_ev = model.forward_pair(data, rows_train=rows, rows_eval=rows)
+        return ev, tr.detach(), grads, p_tr.detach(), p_ev, r_tr.detach(), r_ev, rows
+
+    before = calls['n']
+    ev1, tr1, g1, ptr1, pev1, rtr1, rev1, rows = run(True)
+    assert calls['n'] == before + 4                       # eval, train, pair, pair with rows
+    ev0, tr0, g0, ptr0, pev0, _, _, _ = run(False)
+    assert calls['n'] == before + 4
+    assert torch.equal(ptr1, tr1) and torch.equal(pev1, ev1)
+    assert torch.equal(rtr1, tr1[rows]) and torch.equal(rev1, ev1[rows])
+    assert (ev1 - ev0).abs().max().item() < 1e-5
+    # (a pre-activation within rounding of zero may land on the other side of the ReLU: a handful of elements out of 192,000)
+    assert (tr1 - tr0).abs().max().item() < 1e-4
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+    model.eval()
+    want = dense_reference_logits(model, data.x, data.edge_index, n)
+    assert (ev1.double() - want).abs().max().item() < 1e-5
