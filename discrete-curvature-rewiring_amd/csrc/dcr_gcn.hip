@@ -773,6 +773,10 @@ __global__ void __launch_bounds__(256) k_parts_finish(const float *__restrict__ 
     }
 }
 
+void launch_parts_finish(const float *part, int64_t n_parts, int stride, int split, int columns, float *out0, float *out1, hipStream_t st) {
+    hipLaunchKernelGGL(k_parts_finish, dim3((unsigned)columns), dim3(256), 0, st, part, n_parts, stride, split, out0, out1);
+}
+
 template <int HM>
 static void launch_act_linear_fwd(bool train, bool eval, const float *x, const float *w, float *h_train, float *z_train, float *z_eval,
                                   int64_t ldz, unsigned long long *bits, int64_t n_rows, int C, float scale, uint32_t threshold, uint64_t seed,

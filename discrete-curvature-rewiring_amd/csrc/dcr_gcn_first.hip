@@ -290,6 +290,242 @@ static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ld
     return DCR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the above in ONE kernel: from dz = d loss / d z_train [N x C] to dW1 [H x F], db1 [H] and dW2 [C x H], with the
+// gradient of the pre-activation, dpre = keep ? (dz · W2) / (1 - p) : 0  [N x H], living only in registers.  Before:
+// dcr_act_linear_bwd_fused_f32_dev wrote dpre (512 MB at 1M x 128), dcr_atb_f32_dev read it back for dW1 = dpreᵀ · (Â·X) with
+// every operand fragment fetched from global memory by every wave that needs it (0.21-0.28 + 0.67 ms).  The first layer's
+// input needs no gradient (Â·X is a constant), so dpre has no other reader.
+//
+// A workgroup of 8 waves (one per CU, two waves per SIMD) walks a contiguous range of 16-row units, two per stage;
+// v_mfma_f32_16x16x4_f32, lane (i = lane & 15, g = lane >> 4); hidden "tile" (b, q) = the 16 columns 64b + 4i + q (as in
+// k_act_linear_bwd_fused); a wave owns one of the H/16 tiles (hidden 64: two waves per tile, half of the features each):
+//   dpre tile:  A[row i][k = g] = dz[row i][class 4g + s] (MFMA step s), B[k = g][n = i] = W2[class 4g + s][col(i)] (registers);
+//               D register r = dpre[row 4g + r][col(i)], masked with the keep bit of (row, column) and scaled;
+//   db1:        column sums of the D registers;
+//   dW2 tile:   A[class i][k = g] = dz[row 4g + r][class i], B[k = g][n = i] = h[row 4g + r][col(i)], h = keep ? pre·scale : 0
+//               (step r): the same (row, column) and the same keep bit as D register r;
+//   dW1 tiles:  A[m = i][k = g] = dpre[row 4g + r][col(i)] = D register r AS IT STANDS (step r: no shuffle, no LDS),
+//               B[k = g][n = i] = (Â·X)[row 4g + r][64J + 4i + q'] — one ds_read_b128 of the unit's Â·X rows in LDS gives the
+//               four q' of a J; 16 (J, q') feature tiles x 4 accumulator registers stay in registers for the whole range.
+// The 32 rows of Â·X of the NEXT stage travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: a plain copy, 1 KiB per
+// wave-instruction, conflict-free for the reads above as it lies) while the matrix cores work on this one; dz, keep bits and
+// pre of the next stage travel to registers meanwhile.  One barrier per stage.  Per 16 rows and wave: 64 + 4 + 4 MFMAs.
+// The workgroups' partial dW1 / dW2 / db1 are added in workgroup order by the slab reduction kernels: deterministic.
+constexpr int BWD_WAVES = 8, BWD_UR = 2;   // waves per workgroup (one workgroup per CU); 16-row units per stage
+constexpr int BWD_TILE = BWD_UR * 16 * 256;   // floats of one staging buffer (256 feature columns)
+
+// Two staging buffers as two DISTINCT objects: an LDS-DMA load is a pending LDS write on the vector-memory counter, and the
+// compiler puts s_waitcnt vmcnt(0) before every ds_read that may alias it — reads of one buffer of a single array would wait
+// for the copy into the other, i.e. no overlap at all (measured: 1.0 ms instead of 0.6).  The stage loop is unrolled by two so
+// that every access names its buffer statically.  (+ the reach of a partial 64-column group past the last row)
+__shared__ __attribute__((aligned(16))) float bwd_buf_a[BWD_TILE + 64];
+__shared__ __attribute__((aligned(16))) float bwd_buf_b[BWD_TILE + 64];
+
+template <int HM>
+__global__ void __launch_bounds__(64 * BWD_WAVES) k_first_layer_bwd(const float *__restrict__ dz, const float *__restrict__ w2,
+                                                                    const unsigned long long *__restrict__ bits, const float *__restrict__ pre,
+                                                                    const float *__restrict__ ax, int64_t ldx, int64_t n_rows, int F, int C,
+                                                                    float scale, float *__restrict__ part1, float *__restrict__ part2,
+                                                                    int64_t stages_per_wg) {
+    // wave w: hidden tile tt = w % HM; with fewer tiles than waves (hidden 64) the waves of a tile split the feature groups J
+    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR, SETS = 4 / RPW, NSPLIT = BWD_WAVES / HM, JPW = 4 / NSPLIT, UR = BWD_UR;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: what depends on it branches uniformly)
+    const int fb0 = blockIdx.y * 256;
+    const int FB = F - fb0 < 256 ? F - fb0 : 256;   // feature columns of this block (a multiple of 16)
+    const int tt = wave % HM, jh = NSPLIT == 1 ? 0 : wave / HM, tb = tt >> 2, tq = tt & 3, col = 64 * tb + 4 * i + tq;
+    float w2r[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) w2r[s4] = 4 * g + s4 < C ? w2[(int64_t)(4 * g + s4) * H + col] : 0.f;
+    f32x4 acc1[4 * JPW], dw2 = {0.f, 0.f, 0.f, 0.f};
+    float cs = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4 * JPW; ++nt) acc1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t n_units = (n_rows + 15) / 16, n_stages = (n_units + UR - 1) / UR;
+    const int64_t s0 = (int64_t)blockIdx.x * stages_per_wg;
+    const int64_t s1 = s0 + stages_per_wg < n_stages ? s0 + stages_per_wg : n_stages;
+
+    struct LaneData {
+        float dza[4], dzt[4], prev[4];
+        uint2 bw[SETS];
+    };
+    // the stage's UR x 16 rows x FB columns of Â·X, row after row, into a buffer: wave-instruction k copies the 16-byte chunks
+    // 64k .. 64k + 63; this lane's chunk of instruction k = wave + 8n sits at float offset coff[n] from the stage's first row
+    constexpr int MAXI = UR * 256 / 16 / BWD_WAVES;   // instructions per wave and stage at 256 columns
+    const int cpr = FB / 4, n_inst = UR * FB / 16;
+    int coff[MAXI], ccol[MAXI];
+#pragma unroll
+    for (int n = 0; n < MAXI; ++n) {
+        const int c = 64 * (wave + BWD_WAVES * n) + lane, row = c / cpr;
+        ccol[n] = 4 * (c - row * cpr);
+        coff[n] = row * (int)ldx + ccol[n];
+    }
+    auto stage = [&](int64_t st, float *dst, bool whole) {
+        const int64_t row0 = st * (UR * 16);
+        const float *src = ax + row0 * ldx + fb0;
+        // rows past the end (ragged last stage): a finite copy of the stage's first row, multiplied by dpre = 0.  coff grows with
+        // the row (ldx >= FB), so "row past the end" is "coff at or past the first such row's offset": no second set of loads.
+        const int lim = whole ? 0x7fffffff : (int)(n_rows - row0) * (int)ldx;
+#pragma unroll
+        for (int n = 0; n < MAXI; ++n) {
+            const int k = wave + BWD_WAVES * n;
+            if (k < n_inst)   // (uniform)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (coff[n] < lim ? coff[n] : ccol[n])),
+                                                 (__attribute__((address_space(3))) void *)(dst + 256 * k), 16, 0, 0);
+        }
+    };
+    // per-lane operands: offsets from the unit's first row, once; the loads of a whole stage carry no predicates
+    const int oa = i * C + 4 * g, ob = 4 * g * C + i, op = 4 * g * H + col, obw = (4 * g / RPW) * 4 + tq;
+    const bool cb = i < C;
+    // ONE set of load instructions for whole and ragged stages (two sets under an if / else write the same registers, and the
+    // compiler then waits for every load in flight — the LDS-DMA included — before the second set, whichever ran): a ragged
+    // stage only clamps its indices into the arrays; rows past the end are switched off where the operands are used (live_a,
+    // live_b in compute).  In a whole stage a class index past C reads the next row's gradients: finite numbers that meet
+    // W2 = 0 in the dpre MFMA and, in the dW2 MFMA, fill rows >= C of the tile, which the reduction never reads.
+    auto load_lane = [&](int64_t st, int uu, LaneData &L, bool whole) {
+        const int64_t row0 = (st * UR + uu) * 16;
+        const int64_t rbase = row0 < n_rows ? row0 : 0;   // (a unit wholly past the end reads the first rows: switched off in use)
+        const float *dzu = dz + rbase * C, *preu = pre + rbase * H;
+        const uint2 *bu = reinterpret_cast<const uint2 *>(bits) + (rbase / RPW) * 4;
+        const int64_t left = n_rows - rbase;   // rows from rbase to the end (>= 1)
+        const int big = 0x7fffffff;
+        const int lim_dz = whole || left * C > big ? big : (int)(left * C) - 1;
+        const int lim_pre = whole || left * H > big ? big : (int)(left * H) - 1;
+        const int lim_bw = whole || left > big / 8 ? big : (int)((left + RPW - 1) / RPW) * 4 - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) L.dza[s4] = dzu[min(oa + s4, lim_dz)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            L.dzt[r] = dzu[min(ob + r * C, lim_dz)];
+            L.prev[r] = preu[min(op + r * H, lim_pre)];
+        }
+#pragma unroll
+        for (int h = 0; h < SETS; ++h) L.bw[h] = bu[min(obw + 4 * h, lim_bw)];
+    };
+    // (a stage is "whole" when a row follows it: no row of it is past the end, and a class index past C still reads memory of dz)
+    auto whole_stage = [&](int64_t st) { return (st + 1) * (UR * 16) < n_rows; };
+    const int bitpos = 16 * tb + i;
+    const int xoff = 4 * g * FB + 4 * i + 64 * JPW * jh;   // this lane's float offset into a unit's rows (row 4g, group JPW·jh)
+    // the matrix-core work of one stage on the rows in `xs`: per unit the dpre tile (+ db1, dW2) — after which the unit's
+    // per-lane operands are dead and the SAME registers take those of the next stage's unit (no second register set) — then 4
+    // steps r of JPW reads and 4 JPW MFMAs in halves; the reads of one half are issued before the MFMAs of the half before
+    // (scheduling barriers pin that order: left alone, the scheduler hoists every read of the stage to its top and spills)
+    constexpr int JH = JPW / 2;   // feature groups per half step
+    auto compute = [&](const float *xs, LaneData (&L)[UR], int64_t st, int64_t st_next) {
+        float4 xa[JH], xb[JH];
+        auto read = [&](float4 (&x)[JH], int hs) {   // half step hs = 8 uu + 2 r + half
+            const float *xp = xs + (hs >> 3) * 16 * FB + xoff + ((hs >> 1) & 3) * FB + (hs & 1) * (64 * JH);
+            // (every group J of the 256-column block is read and multiplied, also past FB: those bytes are other rows of the
+            //  buffer, the products land in accumulator columns that are never stored, and MFMA columns do not mix)
+#pragma unroll
+            for (int J = 0; J < JH; ++J) x[J] = *reinterpret_cast<const float4 *>(xp + 64 * J);
+        };
+        auto mfmas = [&](const float4 (&x)[JH], float a, int half) {
+#pragma unroll
+            for (int J = 0; J < JH; ++J) {
+                const float xq[4] = {x[J].x, x[J].y, x[J].z, x[J].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nt = 4 * (JH * half + J) + q;
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xq[q], acc1[nt], 0, 0, 0);
+                }
+            }
+        };
+        read(xa, 0);
+#pragma unroll
+        for (int uu = 0; uu < UR; ++uu) {
+            float dpre[4], at[4], hv[4];
+            const int64_t row0 = (st * UR + uu) * 16;
+            const int64_t left64 = n_rows - row0;
+            const int left = left64 < 0 ? 0 : left64 > 16 ? 16 : (int)left64;   // rows of the unit before the end (uniform)
+            const bool live_a = i < left;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) d = __builtin_amdgcn_mfma_f32_16x16x4f32(live_a ? L[uu].dza[s4] : 0.f, w2r[s4], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sh = (r % RPW) * LPR;                      // bit (r % RPW)·LPR + 16 tb + i of the 64-bit word
+                const uint32_t half = (sh >> 5) ? L[uu].bw[r / RPW].y : L[uu].bw[r / RPW].x;
+                const bool keep = (half >> ((sh & 31) + bitpos)) & 1u;
+                dpre[r] = keep ? d[r] * scale : 0.f;
+                cs += dpre[r];
+                at[r] = (4 * g + r < left && cb) ? L[uu].dzt[r] : 0.f;
+                hv[r] = keep ? L[uu].prev[r] * scale : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st_next >= 0) load_lane(st_next, uu, L[uu], whole_stage(st_next));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                read(xb, 8 * uu + 2 * r + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(xa, dpre[r], 0);
+                // (the four dependent MFMAs of dW2 ride in the stream of independent ones, one per step)
+                if (jh == 0) dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[r], hv[r], dw2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (8 * uu + 2 * r + 2 < 8 * UR) read(xa, 8 * uu + 2 * r + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(xb, dpre[r], 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    LaneData cur[UR];
+    if (s0 < s1) {
+        stage(s0, bwd_buf_a, whole_stage(s0));
+#pragma unroll
+        for (int uu = 0; uu < UR; ++uu) load_lane(s0, uu, cur[uu], whole_stage(s0));
+    }
+    for (int64_t st = s0; st < s1; st += 2) {
+        __syncthreads();   // the copy into a has landed (every wave's), and nobody still reads b
+        if (st + 1 < s1) stage(st + 1, bwd_buf_b, whole_stage(st + 1));
+        compute(bwd_buf_a, cur, st, st + 1 < s1 ? st + 1 : -1);
+        if (st + 1 >= s1) break;
+        __syncthreads();   // b has landed, nobody still reads a
+        if (st + 2 < s1) stage(st + 2, bwd_buf_a, whole_stage(st + 2));
+        compute(bwd_buf_b, cur, st + 1, st + 2 < s1 ? st + 2 : -1);
+    }
+
+    // the workgroup's parts.  acc1[4J + q'] register r = dW1[64 tb + 4 (4g + r) + tq][fb0 + 64 (JPW jh + J) + 4i + q']
+    float *o1 = part1 + (int64_t)blockIdx.x * H * F;
+#pragma unroll
+    for (int J = 0; J < JPW; ++J) {
+        const int f = 64 * (JPW * jh + J) + 4 * i;
+        if (f < FB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hc = 64 * tb + 4 * (4 * g + r) + tq;
+                *reinterpret_cast<float4 *>(o1 + (int64_t)hc * F + fb0 + f) =
+                    make_float4(acc1[4 * J][r], acc1[4 * J + 1][r], acc1[4 * J + 2][r], acc1[4 * J + 3][r]);
+            }
+        }
+    }
+    if (blockIdx.y == 0 && jh == 0) {   // [H column sums | dW2, class-major, 16 rows]: register r of dw2 = dW2[class 4g + r][col(i)]
+        float *o2 = part2 + (int64_t)blockIdx.x * 17 * H;
+        float c = cs;
+        c += __shfl_xor(c, 16, 64);
+        c += __shfl_xor(c, 32, 64);
+        if (g == 0) o2[col] = c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o2[H + (4 * g + r) * H + col] = dw2[r];
+    }
+}
+
+static int64_t first_layer_bwd_blocks(int64_t n_rows) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+    }
+    const int64_t n_stages = ((n_rows + 15) / 16 + BWD_UR - 1) / BWD_UR;
+    int64_t blocks = cus;                // one workgroup of 8 waves per CU (2 x 32 KB of LDS at 256 features)
+    if (blocks > n_stages) blocks = n_stages;
+    return blocks < 1 ? 1 : blocks;
+}
+
 }  // namespace dcr
 
 using namespace dcr;
@@ -322,4 +558,46 @@ extern "C" int dcr_first_layer_fwd_f32_dev(const float *ax, int64_t ldx, const f
                                                    in_features, classes, scale, threshold, seed, offset, offset_dev, st);
     return launch_first_layer<4, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
                                                in_features, classes, scale, threshold, seed, offset, offset_dev, st);
+}
+
+extern "C" int dcr_first_layer_bwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats) {
+    if (!floats || n_rows < 0 || in_features < 16 || (in_features % 16) != 0 || (hidden != 64 && hidden != 128))
+        DCR_FAIL(DCR_EINVAL, "bad first_layer_bwd_workspace arguments");
+    *floats = first_layer_bwd_blocks(n_rows) * ((int64_t)hidden * in_features + 17 * hidden);
+    return DCR_OK;
+}
+
+extern "C" int dcr_first_layer_bwd_f32_dev(const float *dz, const float *w2, const uint64_t *bits, const float *pre, const float *ax, int64_t ldx,
+                                           float *dw1, float *db1, float *dw2, float *ws, int64_t ws_floats, int64_t n_rows, int in_features,
+                                           int hidden, int classes, double p, void *hip_stream) {
+    if (!dz || !w2 || !bits || !pre || !ax || !dw1 || !db1 || !dw2 || !ws || n_rows < 0 || ldx < in_features || !(p >= 0.0 && p < 1.0))
+        DCR_FAIL(DCR_EINVAL, "bad first_layer_bwd arguments");
+    if (in_features < 16 || (in_features % 16) != 0 || (hidden != 64 && hidden != 128) || classes < 1 || classes > 16)
+        DCR_FAIL(DCR_EINVAL, "first_layer_bwd: in_features a multiple of 16, hidden 64 or 128, at most 16 classes");
+    if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)ws & 15)) DCR_FAIL(DCR_EINVAL, "first_layer_bwd: 16-byte aligned tensors and row stride expected");
+    const int64_t blocks = first_layer_bwd_blocks(n_rows);
+    const int64_t per1 = (int64_t)hidden * in_features;
+    if (ws_floats < blocks * (per1 + 17 * hidden)) DCR_FAIL(DCR_EINVAL, "first_layer_bwd: workspace too small (dcr_first_layer_bwd_workspace)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (n_rows == 0) {
+        DCR_HIP(hipMemsetAsync(dw1, 0, sizeof(float) * per1, st));
+        DCR_HIP(hipMemsetAsync(db1, 0, sizeof(float) * hidden, st));
+        DCR_HIP(hipMemsetAsync(dw2, 0, sizeof(float) * hidden * classes, st));
+        return DCR_OK;
+    }
+    const int64_t n_stages = ((n_rows + 15) / 16 + dcr::BWD_UR - 1) / dcr::BWD_UR;
+    const int64_t upw = (n_stages + blocks - 1) / blocks;
+    float *part1 = ws, *part2 = ws + blocks * per1;
+    const float scale = (float)(1.0 / (1.0 - p));
+    const dim3 grid((unsigned)blocks, (unsigned)((in_features + 255) / 256));
+    if (hidden == 128)
+        hipLaunchKernelGGL((dcr::k_first_layer_bwd<8>), grid, dim3(64 * dcr::BWD_WAVES), 0, st, dz, w2, (const unsigned long long *)bits, pre, ax, ldx, n_rows,
+                           in_features, classes, scale, part1, part2, upw);
+    else
+        hipLaunchKernelGGL((dcr::k_first_layer_bwd<4>), grid, dim3(64 * dcr::BWD_WAVES), 0, st, dz, w2, (const unsigned long long *)bits, pre, ax, ldx, n_rows,
+                           in_features, classes, scale, part1, part2, upw);
+    dcr::launch_slab_reduce(part1, dw1, per1, in_features, in_features, (int)blocks, st);
+    dcr::launch_parts_finish(part2, blocks, 17 * hidden, hidden, hidden * (1 + classes), db1, dw2, st);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
 }

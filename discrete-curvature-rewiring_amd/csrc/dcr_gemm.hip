@@ -140,6 +140,12 @@ static AtbPlan atb_plan(int64_t K, int64_t M, int64_t N) {
     return p;
 }
 
+// C[i / N][i % N] = sum over the splits of part[z][i], in slab order (k_atb_reduce) — for the kernels of other files that leave
+// K-slab partial tiles (csrc/dcr_gcn_first.hip)
+void launch_slab_reduce(const float *part, float *C, int64_t mn, int N, int64_t ldc, int splits, hipStream_t st) {
+    hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, st, part, C, mn, N, ldc, splits);
+}
+
 }  // namespace dcr
 
 using namespace dcr;

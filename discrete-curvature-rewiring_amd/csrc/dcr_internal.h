@@ -337,6 +337,9 @@ void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit);  // flag t
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_t st = nullptr);  // st: default the library stream
 // the same from the per-block extrema of the last two-hop pass (g->ext_part_valid), without sweeping the edges again
 int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st = nullptr);
+// reductions of per-workgroup partial results shared by the GCN kernels (csrc/dcr_gemm.hip, csrc/dcr_gcn.hip)
+void launch_slab_reduce(const float *part, float *C, int64_t mn, int N, int64_t ldc, int splits, hipStream_t st);
+void launch_parts_finish(const float *part, int64_t n_parts, int stride, int split, int columns, float *out0, float *out1, hipStream_t st);
 int process_giant_edges(dcr_graph *g, int curv_type);  // dcr_bfc_giant.hip; syncs once
 int process_hub_edges(dcr_graph *g, int curv_type, bool incremental);  // dcr_bfc_giant.hip; syncs once
 int giant_edge(dcr_graph *g, int u, int v, int du, int dv, int64_t slot, int curv_type, bool need_cycles, int64_t *d_out6);  // result in DevResult after the next sync

@@ -546,7 +546,8 @@ class _FirstLayerFn(torch.autograd.Function):
     (csrc/dcr_gcn_first.hip, dcr_first_layer_fwd_f32_dev): models/gcn.py:36-42 from ``x`` of the first GCNConv to the
     second GCNConv's ``lin`` output, for the training operand, the evaluation operand or both.  The hidden activation
     never leaves the registers; the pre-activation is written once for the backward pass (training) or not at all.
-    Backward: the fused MFMA pass of _ActLinearFn (dx, db1 = column sums of dx, dW2), then dW1 = dxᵀ·(Â·X)."""
+    Backward: one kernel too (dcr_first_layer_bwd_f32_dev: dW1, db1, dW2 with the pre-activation's gradient in registers);
+    ``DCR_FIRST_BWD_FUSED=0``: the fused MFMA pass of _ActLinearFn (dx, db1, dW2), then dW1 = dxᵀ·(Â·X)."""
 
     @staticmethod
     def forward(ctx, ax, w1, b1, w2, p, want_train, want_eval):
@@ -590,6 +591,22 @@ class _FirstLayerFn(torch.autograd.Function):
         g_tr = g_tr.contiguous()
         stream = torch.cuda.current_stream(g_tr.device).cuda_stream
         n, hidden = pre.shape
+        if os.environ.get('DCR_FIRST_BWD_FUSED', '1') != '0' and ax.is_contiguous():
+            # one kernel (dcr_first_layer_bwd_f32_dev): the gradient of the pre-activation stays in registers between the
+            # contraction with W2 that forms it and the contraction with Â·X that consumes it
+            feats = ax.shape[1]
+            gw1 = torch.empty((hidden, feats), dtype=torch.float32, device=pre.device)
+            gw2 = torch.empty_like(w2)
+            gb1 = torch.empty(hidden, dtype=torch.float32, device=pre.device)
+            need = ctypes.c_int64()
+            _lib.check(_lib.lib().dcr_first_layer_bwd_workspace(n, feats, hidden, ctypes.byref(need)))
+            ws = torch.empty(max(need.value, 1), dtype=torch.float32, device=pre.device)
+            _lib.check(_lib.lib().dcr_first_layer_bwd_f32_dev(g_tr.data_ptr(), w2.data_ptr(), ctx.bits.data_ptr(), pre.data_ptr(),
+                                                              ax.data_ptr(), feats, gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(),
+                                                              ws.data_ptr(), need.value, n, feats, hidden, w2.shape[0], ctx.p,
+                                                              ctypes.c_void_p(stream)))
+            return (None, gw1 if ctx.needs_input_grad[1] else None, gb1 if (ctx.has_bias and ctx.needs_input_grad[2]) else None,
+                    gw2 if ctx.needs_input_grad[3] else None, None, None, None)
         gx = torch.empty_like(pre)
         gw2 = torch.empty_like(w2)
         colsum = torch.empty(hidden, dtype=torch.float32, device=pre.device)

@@ -281,6 +281,17 @@ int dcr_first_layer_fwd_f32_dev(const float *ax_dev, int64_t ldx, const float *w
                                 int in_features, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
                                 const uint64_t *offset_dev, void *hip_stream);
 
+/* Backward of dcr_first_layer_fwd_f32_dev's training operand in ONE kernel (the backward of models/gcn.py:36-42 for the first
+ * two layers' dense parts): from dz = d loss / d z_train [n_rows x classes, contiguous] to
+ *     dw1 [hidden x in_features] = dpreᵀ · ax,  db1 [hidden] = column sums of dpre,  dw2 [classes x hidden] = dzᵀ · dropout(relu(pre)),
+ * with dpre = keep ? (dz · W2) / (1 - p) : 0 never written to memory (the first layer's input needs no gradient).  bits, pre:
+ * as dcr_first_layer_fwd_f32_dev left them.  ws_dev: dcr_first_layer_bwd_workspace floats.  in_features a multiple of 16, hidden
+ * 64 or 128, classes <= 16.  Partial results are added in a fixed order: deterministic. */
+int dcr_first_layer_bwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats);
+int dcr_first_layer_bwd_f32_dev(const float *dz_dev, const float *w2_dev, const uint64_t *bits_dev, const float *pre_dev,
+                                const float *ax_dev, int64_t ldx, float *dw1_dev, float *db1_dev, float *dw2_dev, float *ws_dev,
+                                int64_t ws_floats, int64_t n_rows, int in_features, int hidden, int classes, double p, void *hip_stream);
+
 /* The whole backward of dcr_act_linear_fwd_f32_dev's training operand in one pass over x, on the matrix cores: dx as above,
  * colsum_dev[hidden] = its column sums, dw_dev[classes x hidden] = dz^T · h with h = keep ? x / (1 - p) : 0 rebuilt from x and
  * the keep bits (the forward call may then pass h_train_dev = NULL and store no activation).  Replaces the weight-gradient

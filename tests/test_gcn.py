@@ -613,11 +613,12 @@ def test_activation_fused_into_the_next_contraction(hidden, classes, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize('feats,hidden,classes,n', [(256, 128, 16, 5003), (48, 64, 6, 2120), (16, 128, 7, 65), (32, 64, 16, 1),
                                                     (320, 64, 3, 40000)])
-def test_first_layer_activation_and_next_lin_in_one_kernel(feats, hidden, classes, n):
+def test_first_layer_activation_and_next_lin_in_one_kernel(feats, hidden, classes, n, monkeypatch):
     """dcr_first_layer_fwd_f32_dev (models/gcn.py:36-42 from the first GCNConv's x to the second GCNConv's lin, on Â·X): the
-    pre-activation against a float64 contraction; both outputs, the keep bits and every gradient EQUAL to what
-    dcr_act_linear_fwd_f32_dev / its backward make of that same pre-activation (same Philox stream, same order of operations);
-    pair, train-only and eval-only calls agree bit for bit; the weight gradient of the first layer against float64."""
+    pre-activation against a float64 contraction; both outputs and the keep bits EQUAL to what dcr_act_linear_fwd_f32_dev makes
+    of that same pre-activation (same Philox stream, same order of operations); pair, train-only and eval-only calls agree bit
+    for bit; the gradients — from the one-kernel backward (dcr_first_layer_bwd_f32_dev) and from the separate kernels — against
+    float64 contractions of the two-kernel route's d loss / d pre."""
     import ctypes
     from dcr import _lib
     from models import gcn
@@ -657,12 +658,18 @@ def test_first_layer_activation_and_next_lin_in_one_kernel(feats, hidden, classe
     assert torch.equal(f_tr.detach(), z_tr.detach()) and torch.equal(f_ev, z_ev) and not f_ev.requires_grad
     gz = torch.randn(n, classes, device=dev, generator=g)
     z_tr.backward(gz)
-    f_tr.backward(gz)
-    assert torch.equal(w2f.grad, w2r.grad)
     gpre = xr.grad                                                            # d loss / d pre of the two-kernel route
-    assert torch.equal(b1f.grad, gpre._dcr_colsum[2]) if hasattr(gpre, '_dcr_colsum') else True
-    assert (b1f.grad.double() - gpre.double().sum(0)).abs().max().item() < 1e-3 * max(1.0, float(n) ** 0.5)
-    assert (w1f.grad.double() - gpre.double().t() @ ax.double()).abs().max().item() < 1e-2 * max(1.0, float(n) ** 0.5)
+    tol = max(1.0, float(n) ** 0.5)
+    for one_kernel in ('1', '0'):                                             # dcr_first_layer_bwd_f32_dev / the separate kernels
+        monkeypatch.setenv('DCR_FIRST_BWD_FUSED', one_kernel)
+        for t in (w1f, b1f, w2f):
+            t.grad = None
+        f_tr.backward(gz, retain_graph=True)
+        if one_kernel == '0':
+            assert torch.equal(w2f.grad, w2r.grad)
+        assert (w2f.grad.double() - w2r.grad.double()).abs().max().item() < 1e-3 * tol
+        assert (b1f.grad.double() - gpre.double().sum(0)).abs().max().item() < 1e-3 * tol
+        assert (w1f.grad.double() - gpre.double().t() @ ax.double()).abs().max().item() < 1e-2 * tol
     ctr.copy_(c0)
     only_tr = _FirstLayerFn.apply(ax, w1, b1, w2, p, True, False)[0]
     only_ev = _FirstLayerFn.apply(ax, w1, b1, w2, 0.0, False, True)[1]

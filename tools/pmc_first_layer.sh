@@ -6,13 +6,13 @@ cd /tmp && export TMPDIR=/tmp
 run() {
   n=$1; shift
   rm -rf /tmp/pmcf_$n
-  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmcf_$n -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_first_layer.py > /dev/null 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmcf_$n -o p -- python3 $GRAFT_REPO_ROOT/tools/${PROBE:-probe_first_layer.py} > /dev/null 2>&1
   python3 - /tmp/pmcf_$n/p_counter_collection.csv <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for row in csv.DictReader(open(sys.argv[1])):
     k = row['Kernel_Name']
-    if 'k_first_layer' not in k and 'k_act_linear' not in k and 'Cijk' not in k: continue
+    if 'k_first_layer' not in k and 'k_act_linear' not in k and 'k_atb' not in k and 'Cijk' not in k: continue
     k = k.split('(')[0].replace('void dcr::', '')[:40]
     acc[k][row['Counter_Name']] += float(row['Counter_Value']); disp[k].add(row['Dispatch_Id'])
 for k in sorted(acc):
