@@ -185,9 +185,11 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     nnz_sel = 2.0 * (n_tr + n_va) / n * (ei_np.shape[1] + n)   # non-zeros of the selected rows (forward) and columns (backward)
     from models.gcn import first_layer_fused_ok
     one_kernel_first = first_layer_fused_ok(x, model.act_fn, model.layers[0], model.layers[1].lin)
-    # (layer-1 output: written once, read + rewritten as its gradient by the fused backward; read once more by the activation
-    #  forward only where the first layer is not the one-kernel form, csrc/dcr_gcn_first.hip)
-    byts = (n * H * 4 * (1 + (0 if one_kernel_first else 1) + 2) + n * C * 4 * 3 + 2 * n * H / 8 + nnz_sel * (C * 4 + 8)) / world
+    one_kernel_bwd = one_kernel_first and os.environ.get('DCR_FIRST_BWD_FUSED', '1') != '0'
+    # (layer-1 output: written once and read once by the backward pass; where the first layer is not the one-kernel form,
+    #  csrc/dcr_gcn_first.hip, it is read once more by the activation forward, and its gradient is written and read back)
+    byts = (n * H * 4 * (1 + (0 if one_kernel_first else 1) + (1 if one_kernel_bwd else 2)) + n * C * 4 * 3 + 2 * n * H / 8
+            + nnz_sel * (C * 4 + 8)) / world
     floor_ms = (flops / (F32_MATRIX_PEAK_TFLOPS * 1e12) + byts / (HBM_PEAK_GBPS * 1e9)) * 1e3
     res['epoch_floor_ms'] = floor_ms
     res['epoch_floor_frac'] = floor_ms / res['ms_per_epoch']
@@ -196,6 +198,9 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     res['first_layer'] = ('one kernel: (A_hat X) W1^T + b1, ReLU + dropout and the second layer\'s lin on the matrix cores '
                           '(dcr_first_layer_fwd_f32_dev; DCR_FIRST_FUSED=0: GEMM library + dcr_act_linear_fwd_f32_dev)'
                           if one_kernel_first else 'GEMM library + dcr_act_linear_fwd_f32_dev')
+    res['first_layer_backward'] = ('one kernel: dW1, db1, dW2 with the pre-activation gradient in registers (dcr_first_layer_bwd_f32_dev; '
+                                   'DCR_FIRST_BWD_FUSED=0: dcr_act_linear_bwd_fused_f32_dev + dcr_atb_f32_dev)'
+                                   if one_kernel_bwd else 'dcr_act_linear_bwd_fused_f32_dev + dcr_atb_f32_dev')
     res['adam'] = ('torch fused (one kernel per group; DCR_FUSED_ADAM=0: stock foreach implementation, the experiment drivers\' default)'
                    if getattr(opt, 'defaults', {}).get('fused') else 'torch stock (foreach), capturable')
     res['last_aggregation'] = ('evaluated at the rows the epoch reads (training rows for the loss, validation rows for the accuracy: '

@@ -312,7 +312,10 @@ static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ld
 // wave-instruction, conflict-free for the reads above as it lies) while the matrix cores work on this one; dz, keep bits and
 // pre of the next stage travel to registers meanwhile.  One barrier per stage.  Per 16 rows and wave: 64 + 4 + 4 MFMAs.
 // The workgroups' partial dW1 / dW2 / db1 are added in workgroup order by the slab reduction kernels: deterministic.
-constexpr int BWD_WAVES = 8, BWD_UR = 2;   // waves per workgroup (one workgroup per CU); 16-row units per stage
+#ifndef DCR_BWD_UR
+#define DCR_BWD_UR 2
+#endif
+constexpr int BWD_WAVES = 8, BWD_UR = DCR_BWD_UR;   // waves per workgroup (one workgroup per CU); 16-row units per stage
 constexpr int BWD_TILE = BWD_UR * 16 * 256;   // floats of one staging buffer (256 feature columns)
 
 // Two staging buffers as two DISTINCT objects: an LDS-DMA load is a pending LDS write on the vector-memory counter, and the
