@@ -2231,10 +2231,20 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         }
         DCR_HIP(hipStreamWaitEvent(sT, g->ev_aux, 0));
     }
-    // the split class's candidates as soon as IT is done (beside class M and the wave classes), class M's when M is
+    // the split class's candidates as soon as IT is done (beside class M and the wave classes), class M's when M is — on M's own
+    // stream: behind the split class's triangle step (292 us beside the other classes, 60 alone) it started 90 us after M's end
+    // and sat on the critical path (DCR_H2_TRI_OWN=0: the round-4 order)
+    static const bool tri_own = !(getenv("DCR_H2_TRI_OWN") && atoi(getenv("DCR_H2_TRI_OWN")) == 0);
     hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 4)), dim3(256), 0, sT, es, tk, g->h2_rec, status, 0);
-    if (!serial) DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[1], 0));
-    hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sT, es, tkM, g->h2_rec, status, 0);
+    if (!serial && tri_own) {
+        DCR_HIP(hipStreamWaitEvent(sM, g->ev_aux, 0));
+        hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sM, es, tkM, g->h2_rec, status, 0);
+        DCR_HIP(hipEventRecord(g->ev_join[1], sM));
+        DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[1], 0));
+    } else {
+        if (!serial) DCR_HIP(hipStreamWaitEvent(sT, g->ev_join[1], 0));
+        hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, sT, es, tkM, g->h2_rec, status, 0);
+    }
     if (!serial) {
         if (sT != g->stream) DCR_HIP(hipEventRecord(g->ev_join[3], sT));
         DCR_HIP(hipEventRecord(g->ev_join[2], sS0));

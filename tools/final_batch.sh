@@ -12,5 +12,9 @@ INC=1 bash tools/timeline_step.sh r04_incremental > /dev/null 2>&1
 DCR_SERIAL_BINS=1 REPS=10 bash tools/prof_pass.sh r04_serial > /dev/null 2>&1
 REPS=10 bash tools/prof_pass.sh r04_concurrent > /dev/null 2>&1
 bash tools/prof_gcn.sh r04 > /dev/null 2>&1
+bash tools/clock_first_layer.sh > gpurun_out/r04_first_layer_clock.txt 2>&1
+PROBE=probe_first_bwd.py bash tools/clock_first_layer.sh >> gpurun_out/r04_first_layer_clock.txt 2>&1
+bash tools/pmc_first_layer.sh r04_first_layer_fwd > /dev/null 2>&1
+PROBE=probe_first_bwd.py bash tools/pmc_first_layer.sh r04_first_layer_bwd > /dev/null 2>&1
 python -m pytest tests/ -q -m gpu > gpurun_out/r04_gputests.log 2>&1; tail -2 gpurun_out/r04_gputests.log
 tail -c 400 gpurun_out/r04_bench.json.log
