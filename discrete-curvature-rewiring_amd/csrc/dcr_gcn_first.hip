@@ -30,7 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DCR_FIRST_NR
 #define DCR_FIRST_NR 2   // 16-row units a wave carries at once
 #endif
-constexpr int FIRST_WAVES = 8;
+#ifndef DCR_FIRST_WAVES
+#define DCR_FIRST_WAVES 8
+#endif
+constexpr int FIRST_WAVES = DCR_FIRST_WAVES;
 
 struct FirstArgs {
     const float *ax; int64_t ldx;
