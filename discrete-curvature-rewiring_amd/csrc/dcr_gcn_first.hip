@@ -315,50 +315,89 @@ static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ld
 // wave-instruction, conflict-free for the reads above as it lies) while the matrix cores work on this one; dz, keep bits and
 // pre of the next stage travel to registers meanwhile.  One barrier per stage.  Per 16 rows and wave: 64 + 4 + 4 MFMAs.
 // The workgroups' partial dW1 / dW2 / db1 are added in workgroup order by the slab reduction kernels: deterministic.
+// Shape of a workgroup: BWD_WAVES waves, BWD_UR 16-row units per stage, BWD_WGS workgroups per CU.  Round-4 measurements on the
+// bench shape: 8 waves x 1 workgroup, 2 units per stage 0.735 ms; 4 waves x 2 workgroups, 1 unit per stage (a wave owns two hidden
+// tiles: half the LDS reads per MFMA, and a workgroup at its barrier leaves the CU to the other one): see DESIGN §4.3.
+#ifndef DCR_BWD_WAVES
+#define DCR_BWD_WAVES 8
+#endif
 #ifndef DCR_BWD_UR
 #define DCR_BWD_UR 2
 #endif
-constexpr int BWD_WAVES = 8, BWD_UR = DCR_BWD_UR;   // waves per workgroup (one workgroup per CU); 16-row units per stage
+constexpr int BWD_WAVES = DCR_BWD_WAVES, BWD_UR = DCR_BWD_UR, BWD_WGS = 8 / BWD_WAVES;
 constexpr int BWD_TILE = BWD_UR * 16 * 256;   // floats of one staging buffer (256 feature columns)
 
 // Two staging buffers as two DISTINCT objects: an LDS-DMA load is a pending LDS write on the vector-memory counter, and the
 // compiler puts s_waitcnt vmcnt(0) before every ds_read that may alias it — reads of one buffer of a single array would wait
 // for the copy into the other, i.e. no overlap at all (measured: 1.0 ms instead of 0.6).  The stage loop is unrolled by two so
 // that every access names its buffer statically.  (+ the reach of a partial 64-column group past the last row)
+#ifdef DCR_BWD_PROF   // (diagnostic build: wave-cycles per section, tools/probe_first_bwd.py prints them)
+__device__ unsigned long long bwd_prof[8];
+#define BWD_STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[slot] += t_ - prof_t; prof_t = t_; } while (0)
+#else
+#define BWD_STAMP(slot) do { } while (0)
+#endif
+// (+ 64 / + 16: the reach of a partial 64-column group past the last row of Â·X, of a class index past C past the last row of dz)
+constexpr int BWD_PRE = BWD_UR * 16 * 128, BWD_DZ = BWD_UR * 16 * 16 + 16, BWD_BITS = BWD_UR * 16 * 4;   // floats / floats / uint2
 __shared__ __attribute__((aligned(16))) float bwd_buf_a[BWD_TILE + 64];
 __shared__ __attribute__((aligned(16))) float bwd_buf_b[BWD_TILE + 64];
+__shared__ __attribute__((aligned(16))) float bwd_pre_a[BWD_PRE];
+__shared__ __attribute__((aligned(16))) float bwd_pre_b[BWD_PRE];
+__shared__ __attribute__((aligned(16))) float bwd_dz_a[BWD_DZ];
+__shared__ __attribute__((aligned(16))) float bwd_dz_b[BWD_DZ];
+__shared__ __attribute__((aligned(16))) uint2 bwd_bits_a[BWD_BITS];
+__shared__ __attribute__((aligned(16))) uint2 bwd_bits_b[BWD_BITS];
 
 template <int HM>
-__global__ void __launch_bounds__(64 * BWD_WAVES) k_first_layer_bwd(const float *__restrict__ dz, const float *__restrict__ w2,
-                                                                    const unsigned long long *__restrict__ bits, const float *__restrict__ pre,
-                                                                    const float *__restrict__ ax, int64_t ldx, int64_t n_rows, int F, int C,
-                                                                    float scale, float *__restrict__ part1, float *__restrict__ part2,
-                                                                    int64_t stages_per_wg) {
-    // wave w: hidden tile tt = w % HM; with fewer tiles than waves (hidden 64) the waves of a tile split the feature groups J
-    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR, SETS = 4 / RPW, NSPLIT = BWD_WAVES / HM, JPW = 4 / NSPLIT, UR = BWD_UR;
+__global__ void __launch_bounds__(64 * BWD_WAVES, BWD_WGS) k_first_layer_bwd(const float *__restrict__ dz, const float *__restrict__ w2,
+                                                                             const unsigned long long *__restrict__ bits,
+                                                                             const float *__restrict__ pre, const float *__restrict__ ax,
+                                                                             int64_t ldx, int64_t n_rows, int F, int C, float scale,
+                                                                             float *__restrict__ part1, float *__restrict__ part2,
+                                                                             int64_t stages_per_wg) {
+    // wave w owns the TPW hidden tiles w·TPW ..; with fewer tiles than waves (TPW = 1, NSPLIT waves per tile) the waves of a
+    // tile split the feature groups J
+    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR, SETS = 4 / RPW, UR = BWD_UR, NT = 64 * BWD_WAVES;
+    constexpr int TPW = HM >= BWD_WAVES ? HM / BWD_WAVES : 1, NSPLIT = HM >= BWD_WAVES ? 1 : BWD_WAVES / HM, JPW = 4 / NSPLIT;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: what depends on it branches uniformly)
+#ifdef DCR_BWD_PROF
+    unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
     const int fb0 = blockIdx.y * 256;
     const int FB = F - fb0 < 256 ? F - fb0 : 256;   // feature columns of this block (a multiple of 16)
-    const int tt = wave % HM, jh = NSPLIT == 1 ? 0 : wave / HM, tb = tt >> 2, tq = tt & 3, col = 64 * tb + 4 * i + tq;
-    float w2r[4];
+    const int jh = NSPLIT == 1 ? 0 : wave / HM;
+    int tb[TPW], tq[TPW], col[TPW], bitpos[TPW];
+    float w2r[TPW][4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) w2r[s4] = 4 * g + s4 < C ? w2[(int64_t)(4 * g + s4) * H + col] : 0.f;
-    f32x4 acc1[4 * JPW], dw2 = {0.f, 0.f, 0.f, 0.f};
-    float cs = 0.f;
+    for (int j = 0; j < TPW; ++j) {
+        const int tt = NSPLIT == 1 ? wave * TPW + j : wave % HM;
+        tb[j] = tt >> 2;
+        tq[j] = tt & 3;
+        col[j] = 64 * tb[j] + 4 * i + tq[j];
+        bitpos[j] = 16 * tb[j] + i;
 #pragma unroll
-    for (int nt = 0; nt < 4 * JPW; ++nt) acc1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s4 = 0; s4 < 4; ++s4) w2r[j][s4] = 4 * g + s4 < C ? w2[(int64_t)(4 * g + s4) * H + col[j]] : 0.f;
+    }
+    f32x4 acc1[TPW][4 * JPW], dw2[TPW];
+    float cs[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        dw2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs[j] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4 * JPW; ++nt) acc1[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int64_t n_units = (n_rows + 15) / 16, n_stages = (n_units + UR - 1) / UR;
     const int64_t s0 = (int64_t)blockIdx.x * stages_per_wg;
     const int64_t s1 = s0 + stages_per_wg < n_stages ? s0 + stages_per_wg : n_stages;
 
-    struct LaneData {
-        float dza[4], dzt[4], prev[4];
-        uint2 bw[SETS];
-    };
-    // the stage's UR x 16 rows x FB columns of Â·X, row after row, into a buffer: wave-instruction k copies the 16-byte chunks
-    // 64k .. 64k + 63; this lane's chunk of instruction k = wave + 8n sits at float offset coff[n] from the stage's first row
-    constexpr int MAXI = UR * 256 / 16 / BWD_WAVES;   // instructions per wave and stage at 256 columns
+    // Everything a stage reads travels global -> LDS by LDS-DMA, as plain copies: its UR x 16 rows of Â·X (FB columns, row after
+    // row), of pre (H columns), of dz (C columns) and their keep words.  (Round 4, first version: dz in two layouts, pre and the
+    // keep words went to registers by per-lane loads — 18-24 dword loads per unit and wave, each touching 4-16 cache lines,
+    // issued by every wave for the same rows: the stamped build showed 35-46 % of a wave's life in those "fronts", the texture
+    // path saturated by line touches, not by bytes.)  Wave-instruction k of a copy moves the 16-byte chunks 64k .. 64k + 63.
+    constexpr int MAXI = UR * 256 / 16 / BWD_WAVES;   // Â·X instructions per wave and stage at 256 columns
     const int cpr = FB / 4, n_inst = UR * FB / 16;
     int coff[MAXI], ccol[MAXI];
 #pragma unroll
@@ -367,155 +406,211 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) k_first_layer_bwd(const float 
         ccol[n] = 4 * (c - row * cpr);
         coff[n] = row * (int)ldx + ccol[n];
     }
-    auto stage = [&](int64_t st, float *dst, bool whole) {
+    constexpr int PRE_INST = UR * 16 * H / 256, PRE_PER_WAVE = (PRE_INST + BWD_WAVES - 1) / BWD_WAVES;
+    const int dz_chunks = UR * 4 * C, bits_chunks = UR * 32 / RPW;   // 16-byte chunks of the dz rows / of the keep words
+    constexpr int N_PIECES = MAXI + PRE_PER_WAVE + 2;   // copy instructions a wave issues per stage, at most
+    // piece n of the copies of stage st (n = 0 .. N_PIECES - 1): issued one per pair of sub-steps INSIDE the stage before, between
+    // its MFMAs — eight waves issuing their 6-7 copies together right behind the barrier left the matrix cores idle meanwhile
+    // (9 % of a wave's life in the stamped build)
+    auto stage_piece = [&](int n, int64_t st, float *xdst, float *pdst, float *ddst, uint2 *bdst, bool whole) {
         const int64_t row0 = st * (UR * 16);
-        const float *src = ax + row0 * ldx + fb0;
-        // rows past the end (ragged last stage): a finite copy of the stage's first row, multiplied by dpre = 0.  coff grows with
-        // the row (ldx >= FB), so "row past the end" is "coff at or past the first such row's offset": no second set of loads.
-        const int lim = whole ? 0x7fffffff : (int)(n_rows - row0) * (int)ldx;
-#pragma unroll
-        for (int n = 0; n < MAXI; ++n) {
-            const int k = wave + BWD_WAVES * n;
-            if (k < n_inst)   // (uniform)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (coff[n] < lim ? coff[n] : ccol[n])),
-                                                 (__attribute__((address_space(3))) void *)(dst + 256 * k), 16, 0, 0);
+        if (whole) {
+            if (n < MAXI) {
+                const int k = wave + BWD_WAVES * n;
+                if (k < n_inst)   // (uniform)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ax + row0 * ldx + fb0 + coff[n]),
+                                                     (__attribute__((address_space(3))) void *)(xdst + 256 * k), 16, 0, 0);
+            } else if (n < MAXI + PRE_PER_WAVE) {
+                const int k = wave + BWD_WAVES * (n - MAXI);
+                if (k < PRE_INST)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pre + row0 * H + 256 * k + 4 * lane),
+                                                     (__attribute__((address_space(3))) void *)(pdst + 256 * k), 16, 0, 0);
+            } else if (n == MAXI + PRE_PER_WAVE) {
+                // dz and the keep words: a few hundred bytes each, by the waves that have the fewest pre pieces
+                for (int k = BWD_WAVES - 1 - wave; 64 * k < dz_chunks; k += BWD_WAVES)
+                    if (64 * k + lane < dz_chunks)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dz + row0 * C + 256 * k + 4 * lane),
+                                                         (__attribute__((address_space(3))) void *)(ddst + 256 * k), 16, 0, 0);
+            } else if (n == MAXI + PRE_PER_WAVE + 1) {
+                if (wave == (BWD_WAVES > 2 ? BWD_WAVES - 3 : 0) && lane < bits_chunks)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const uint2 *>(bits) + (row0 / RPW) * 4 + 2 * lane),
+                        (__attribute__((address_space(3))) void *)bdst, 16, 0, 0);
+            }
         }
     };
-    // per-lane operands: offsets from the unit's first row, once; the loads of a whole stage carry no predicates
-    const int oa = i * C + 4 * g, ob = 4 * g * C + i, op = 4 * g * H + col, obw = (4 * g / RPW) * 4 + tq;
-    const bool cb = i < C;
-    // ONE set of load instructions for whole and ragged stages (two sets under an if / else write the same registers, and the
-    // compiler then waits for every load in flight — the LDS-DMA included — before the second set, whichever ran): a ragged
-    // stage only clamps its indices into the arrays; rows past the end are switched off where the operands are used (live_a,
-    // live_b in compute).  In a whole stage a class index past C reads the next row's gradients: finite numbers that meet
-    // W2 = 0 in the dpre MFMA and, in the dW2 MFMA, fill rows >= C of the tile, which the reduction never reads.
-    auto load_lane = [&](int64_t st, int uu, LaneData &L, bool whole) {
-        const int64_t row0 = (st * UR + uu) * 16;
-        const int64_t rbase = row0 < n_rows ? row0 : 0;   // (a unit wholly past the end reads the first rows: switched off in use)
-        const float *dzu = dz + rbase * C, *preu = pre + rbase * H;
-        const uint2 *bu = reinterpret_cast<const uint2 *>(bits) + (rbase / RPW) * 4;
-        const int64_t left = n_rows - rbase;   // rows from rbase to the end (>= 1)
-        const int big = 0x7fffffff;
-        const int lim_dz = whole || left * C > big ? big : (int)(left * C) - 1;
-        const int lim_pre = whole || left * H > big ? big : (int)(left * H) - 1;
-        const int lim_bw = whole || left > big / 8 ? big : (int)((left + RPW - 1) / RPW) * 4 - 1;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) L.dza[s4] = dzu[min(oa + s4, lim_dz)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            L.dzt[r] = dzu[min(ob + r * C, lim_dz)];
-            L.prev[r] = preu[min(op + r * H, lim_pre)];
+    // the ragged last stage (once per launch, one workgroup): plain loads, rows past the end as zeros
+    auto ragged_fill = [&](int64_t st, float *xdst, float *pdst, float *ddst, uint2 *bdst) {
+        const int64_t row0 = st * (UR * 16);
+        for (int e = threadIdx.x; e < UR * 16 * FB; e += NT) {
+            const int row = e / FB, c = e - row * FB;
+            xdst[e] = row0 + row < n_rows ? ax[(row0 + row) * ldx + fb0 + c] : 0.f;
         }
-#pragma unroll
-        for (int h = 0; h < SETS; ++h) L.bw[h] = bu[min(obw + 4 * h, lim_bw)];
+        for (int e = threadIdx.x; e < UR * 16 * H; e += NT) pdst[e] = row0 + e / H < n_rows ? pre[row0 * H + e] : 0.f;
+        for (int e = threadIdx.x; e < UR * 16 * C; e += NT) ddst[e] = row0 + e / C < n_rows ? dz[row0 * C + e] : 0.f;
+        for (int e = threadIdx.x; e < UR * 16 / RPW * 4; e += NT)
+            bdst[e] = row0 + (e / 4) * RPW < n_rows ? reinterpret_cast<const uint2 *>(bits)[(row0 / RPW) * 4 + e] : make_uint2(0u, 0u);
     };
-    // (a stage is "whole" when a row follows it: no row of it is past the end, and a class index past C still reads memory of dz)
+    // (a stage is "whole" when a row follows it: no row of it is past the end, and every 16-byte chunk copied lies inside its array)
     auto whole_stage = [&](int64_t st) { return (st + 1) * (UR * 16) < n_rows; };
-    const int bitpos = 16 * tb + i;
+    const bool cb = i < C;
+    const bool c4 = (C & 3) == 0;
     const int xoff = 4 * g * FB + 4 * i + 64 * JPW * jh;   // this lane's float offset into a unit's rows (row 4g, group JPW·jh)
-    // the matrix-core work of one stage on the rows in `xs`: per unit the dpre tile (+ db1, dW2) — after which the unit's
-    // per-lane operands are dead and the SAME registers take those of the next stage's unit (no second register set) — then 4
-    // steps r of JPW reads and 4 JPW MFMAs in halves; the reads of one half are issued before the MFMAs of the half before
-    // (scheduling barriers pin that order: left alone, the scheduler hoists every read of the stage to its top and spills)
-    constexpr int JH = JPW / 2;   // feature groups per half step
-    auto compute = [&](const float *xs, LaneData (&L)[UR], int64_t st, int64_t st_next) {
+    // the matrix-core work of one stage: per unit the dpre tiles (+ db1) from the unit's dz, keep words and pre in LDS, then 4
+    // steps r of JPW reads and 4 JPW TPW MFMAs in parts; the reads of one part are issued before the MFMAs of the part before,
+    // and the four dependent MFMAs of dW2 ride in that stream, one per step (scheduling barriers pin the order: left alone,
+    // the scheduler hoists every read of the stage to its top and spills)
+    constexpr int JH = (TPW > 1 || JPW < 4) ? 1 : 2;   // feature groups per read: each read feeds 4 JH TPW MFMAs
+    constexpr int NP = JPW / JH, S = UR * 4 * NP;     // parts per step r; sub-steps per stage
+    auto compute = [&](const float *xs, const float *ps, const float *ds, const uint2 *bs, int64_t st, int64_t st_next, float *nx, float *np_,
+                       float *nd, uint2 *nb) {
+        const bool nwhole = st_next >= 0 && whole_stage(st_next);
         float4 xa[JH], xb[JH];
-        auto read = [&](float4 (&x)[JH], int hs) {   // half step hs = 8 uu + 2 r + half
-            const float *xp = xs + (hs >> 3) * 16 * FB + xoff + ((hs >> 1) & 3) * FB + (hs & 1) * (64 * JH);
+        float dpre[TPW][4], at[4], hv[TPW][4];
+        auto read = [&](float4 (&x)[JH], int k) {   // sub-step k = (4 uu + r) NP + part
+            const float *xp = xs + (k / (4 * NP)) * 16 * FB + xoff + ((k / NP) & 3) * FB + (k % NP) * (64 * JH);
             // (every group J of the 256-column block is read and multiplied, also past FB: those bytes are other rows of the
             //  buffer, the products land in accumulator columns that are never stored, and MFMA columns do not mix)
 #pragma unroll
             for (int J = 0; J < JH; ++J) x[J] = *reinterpret_cast<const float4 *>(xp + 64 * J);
         };
-        auto mfmas = [&](const float4 (&x)[JH], float a, int half) {
+        auto mfmas = [&](const float4 (&x)[JH], int k) {
+            const int r = (k / NP) & 3, part = k % NP;
 #pragma unroll
             for (int J = 0; J < JH; ++J) {
                 const float xq[4] = {x[J].x, x[J].y, x[J].z, x[J].w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nt = 4 * (JH * half + J) + q;
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xq[q], acc1[nt], 0, 0, 0);
-                }
-            }
-        };
-        read(xa, 0);
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int uu = 0; uu < UR; ++uu) {
-            float dpre[4], at[4], hv[4];
+                    for (int j = 0; j < TPW; ++j) {
+                        const int nt = 4 * (JH * part + J) + q;
+                        acc1[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpre[j][r], xq[q], acc1[j][nt], 0, 0, 0);
+                    }
+            }
+            if (part == 0 && jh == 0)   // (uniform: one wave per hidden tile keeps dW2; one of its four dependent MFMAs per step)
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) dw2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[r], hv[j][r], dw2[j], 0, 0, 0);
+        };
+        auto front = [&](int uu) {
+            BWD_STAMP(1);
             const int64_t row0 = (st * UR + uu) * 16;
             const int64_t left64 = n_rows - row0;
             const int left = left64 < 0 ? 0 : left64 > 16 ? 16 : (int)left64;   // rows of the unit before the end (uniform)
             const bool live_a = i < left;
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            // A[row i][k = g] of step s: dz[row i][class 4g + s] (a class past C: the next row's numbers or the pad, against W2 = 0)
+            float za[4];
+            const float *zr = ds + (uu * 16 + i) * C + 4 * g;
+            if (c4) {
+                const float4 t = *reinterpret_cast<const float4 *>(zr);
+                za[0] = t.x; za[1] = t.y; za[2] = t.z; za[3] = t.w;
+            } else {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) d = __builtin_amdgcn_mfma_f32_16x16x4f32(live_a ? L[uu].dza[s4] : 0.f, w2r[s4], d, 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4) za[s4] = zr[s4];
+            }
+            float zt[4], pv[TPW][4];
+            uint2 bw[TPW][SETS];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                zt[r] = ds[(uu * 16 + 4 * g + r) * C + (cb ? i : 0)];
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) pv[j][r] = ps[(uu * 16 + 4 * g + r) * H + col[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int h = 0; h < SETS; ++h) bw[j][h] = bs[((uu * 16 + 4 * g) / RPW + h) * 4 + tq[j]];
+            f32x4 d[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(live_a ? za[s4] : 0.f, w2r[j][s4], d[j], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int sh = (r % RPW) * LPR;                      // bit (r % RPW)·LPR + 16 tb + i of the 64-bit word
-                const uint32_t half = (sh >> 5) ? L[uu].bw[r / RPW].y : L[uu].bw[r / RPW].x;
-                const bool keep = (half >> ((sh & 31) + bitpos)) & 1u;
-                dpre[r] = keep ? d[r] * scale : 0.f;
-                cs += dpre[r];
-                at[r] = (4 * g + r < left && cb) ? L[uu].dzt[r] : 0.f;
-                hv[r] = keep ? L[uu].prev[r] * scale : 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (st_next >= 0) load_lane(st_next, uu, L[uu], whole_stage(st_next));
-            __builtin_amdgcn_sched_barrier(0);
+                at[r] = (4 * g + r < left && cb) ? zt[r] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                read(xb, 8 * uu + 2 * r + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(xa, dpre[r], 0);
-                // (the four dependent MFMAs of dW2 ride in the stream of independent ones, one per step)
-                if (jh == 0) dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[r], hv[r], dw2, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (8 * uu + 2 * r + 2 < 8 * UR) read(xa, 8 * uu + 2 * r + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(xb, dpre[r], 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < TPW; ++j) {
+                    const uint32_t half = (sh >> 5) ? bw[j][r / RPW].y : bw[j][r / RPW].x;
+                    const bool keep = (half >> ((sh & 31) + bitpos[j])) & 1u;
+                    dpre[j][r] = keep ? d[j][r] * scale : 0.f;
+                    cs[j] += dpre[j][r];
+                    hv[j][r] = keep ? pv[j][r] * scale : 0.f;
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            BWD_STAMP(0);
+        };
+        read(xa, 0);
+#pragma unroll
+        for (int k = 0; k < S; k += 2) {
+            if (k % (4 * NP) == 0) front(k / (4 * NP));
+            read(xb, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(xa, k);
+            if (nwhole && k / 2 < N_PIECES) stage_piece(k / 2, st_next, nx, np_, nd, nb, true);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < S) read(xa, k + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(xb, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    LaneData cur[UR];
+    static_assert(S / 2 >= N_PIECES, "a stage has fewer pairs of sub-steps than a wave has copies to issue");
     if (s0 < s1) {
-        stage(s0, bwd_buf_a, whole_stage(s0));
-#pragma unroll
-        for (int uu = 0; uu < UR; ++uu) load_lane(s0, uu, cur[uu], whole_stage(s0));
+        if (whole_stage(s0))
+            for (int n = 0; n < N_PIECES; ++n) stage_piece(n, s0, bwd_buf_a, bwd_pre_a, bwd_dz_a, bwd_bits_a, true);
+        else
+            ragged_fill(s0, bwd_buf_a, bwd_pre_a, bwd_dz_a, bwd_bits_a);
     }
     for (int64_t st = s0; st < s1; st += 2) {
-        __syncthreads();   // the copy into a has landed (every wave's), and nobody still reads b
-        if (st + 1 < s1) stage(st + 1, bwd_buf_b, whole_stage(st + 1));
-        compute(bwd_buf_a, cur, st, st + 1 < s1 ? st + 1 : -1);
+        BWD_STAMP(1);
+        __syncthreads();   // the copies into a have landed (every wave's), and nobody still reads b
+        BWD_STAMP(2);
+        compute(bwd_buf_a, bwd_pre_a, bwd_dz_a, bwd_bits_a, st, st + 1 < s1 ? st + 1 : -1, bwd_buf_b, bwd_pre_b, bwd_dz_b, bwd_bits_b);
         if (st + 1 >= s1) break;
+        if (!whole_stage(st + 1)) ragged_fill(st + 1, bwd_buf_b, bwd_pre_b, bwd_dz_b, bwd_bits_b);
+        BWD_STAMP(1);
         __syncthreads();   // b has landed, nobody still reads a
-        if (st + 2 < s1) stage(st + 2, bwd_buf_a, whole_stage(st + 2));
-        compute(bwd_buf_b, cur, st + 1, st + 2 < s1 ? st + 2 : -1);
+        BWD_STAMP(2);
+        compute(bwd_buf_b, bwd_pre_b, bwd_dz_b, bwd_bits_b, st + 1, st + 2 < s1 ? st + 2 : -1, bwd_buf_a, bwd_pre_a, bwd_dz_a, bwd_bits_a);
+        if (st + 2 < s1 && !whole_stage(st + 2)) ragged_fill(st + 2, bwd_buf_a, bwd_pre_a, bwd_dz_a, bwd_bits_a);
     }
+#ifdef DCR_BWD_PROF
+    BWD_STAMP(1);
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) atomicAdd(&bwd_prof[k], prof_acc[k]);
+#endif
 
-    // the workgroup's parts.  acc1[4J + q'] register r = dW1[64 tb + 4 (4g + r) + tq][fb0 + 64 (JPW jh + J) + 4i + q']
+    // the workgroup's parts.  acc1[j][4J + q'] register r = dW1[64 tb + 4 (4g + r) + tq][fb0 + 64 (JPW jh + J) + 4i + q']
     float *o1 = part1 + (int64_t)blockIdx.x * H * F;
 #pragma unroll
-    for (int J = 0; J < JPW; ++J) {
-        const int f = 64 * (JPW * jh + J) + 4 * i;
-        if (f < FB) {
+    for (int j = 0; j < TPW; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hc = 64 * tb + 4 * (4 * g + r) + tq;
-                *reinterpret_cast<float4 *>(o1 + (int64_t)hc * F + fb0 + f) =
-                    make_float4(acc1[4 * J][r], acc1[4 * J + 1][r], acc1[4 * J + 2][r], acc1[4 * J + 3][r]);
+        for (int J = 0; J < JPW; ++J) {
+            const int f = 64 * (JPW * jh + J) + 4 * i;
+            if (f < FB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int hc = 64 * tb[j] + 4 * (4 * g + r) + tq[j];
+                    *reinterpret_cast<float4 *>(o1 + (int64_t)hc * F + fb0 + f) =
+                        make_float4(acc1[j][4 * J][r], acc1[j][4 * J + 1][r], acc1[j][4 * J + 2][r], acc1[j][4 * J + 3][r]);
+                }
             }
         }
-    }
-    if (blockIdx.y == 0 && jh == 0) {   // [H column sums | dW2, class-major, 16 rows]: register r of dw2 = dW2[class 4g + r][col(i)]
+    if (blockIdx.y == 0 && jh == 0) {   // [H column sums | dW2, class-major, 16 rows]: register r of dw2[j] = dW2[class 4g + r][col(i)]
         float *o2 = part2 + (int64_t)blockIdx.x * 17 * H;
-        float c = cs;
-        c += __shfl_xor(c, 16, 64);
-        c += __shfl_xor(c, 32, 64);
-        if (g == 0) o2[col] = c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o2[H + (4 * g + r) * H + col] = dw2[r];
+        for (int j = 0; j < TPW; ++j) {
+            float c = cs[j];
+            c += __shfl_xor(c, 16, 64);
+            c += __shfl_xor(c, 32, 64);
+            if (g == 0) o2[col[j]] = c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o2[H + (4 * g + r) * H + col[j]] = dw2[j][r];
+        }
     }
 }
 
@@ -527,7 +622,7 @@ static int64_t first_layer_bwd_blocks(int64_t n_rows) {
             cus = 256;
     }
     const int64_t n_stages = ((n_rows + 15) / 16 + BWD_UR - 1) / BWD_UR;
-    int64_t blocks = cus;                // one workgroup of 8 waves per CU (2 x 32 KB of LDS at 256 features)
+    int64_t blocks = (int64_t)cus * BWD_WGS;
     if (blocks > n_stages) blocks = n_stages;
     return blocks < 1 ? 1 : blocks;
 }
@@ -602,6 +697,17 @@ extern "C" int dcr_first_layer_bwd_f32_dev(const float *dz, const float *w2, con
     else
         hipLaunchKernelGGL((dcr::k_first_layer_bwd<4>), grid, dim3(64 * dcr::BWD_WAVES), 0, st, dz, w2, (const unsigned long long *)bits, pre, ax, ldx, n_rows,
                            in_features, classes, scale, part1, part2, upw);
+#ifdef DCR_BWD_PROF
+    {
+        unsigned long long h[8];
+        DCR_HIP(hipStreamSynchronize(st));
+        DCR_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(dcr::bwd_prof), sizeof(h)));
+        fprintf(stderr, "[first_layer_bwd prof] wave-Mcycles: fronts (dpre, keep bits, next operands' loads) %.1f; MFMA sub-steps %.1f; barrier %.1f; "
+                "DMA issue %.1f\n", h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6);
+        unsigned long long z[8] = {0};
+        DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dcr::bwd_prof), z, sizeof(z)));
+    }
+#endif
     dcr::launch_slab_reduce(part1, dw1, per1, in_features, in_features, (int)blocks, st);
     dcr::launch_parts_finish(part2, blocks, 17 * hidden, hidden, hidden * (1 + classes), db1, dw2, st);
     DCR_HIP(hipGetLastError());
