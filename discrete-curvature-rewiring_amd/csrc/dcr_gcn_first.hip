@@ -497,7 +497,8 @@ __global__ void __launch_bounds__(64 * BWD_WAVES, BWD_WGS) k_first_layer_bwd(con
             const int64_t left64 = n_rows - row0;
             const int left = left64 < 0 ? 0 : left64 > 16 ? 16 : (int)left64;   // rows of the unit before the end (uniform)
             const bool live_a = i < left;
-            // A[row i][k = g] of step s: dz[row i][class 4g + s] (a class past C: the next row's numbers or the pad, against W2 = 0)
+            // A[row i][k = g] of step s: dz[row i][class 4g + s] (a class past C reads the next row's numbers or the pad — LDS that
+            // nobody wrote, NaN patterns included, and 0 x NaN is NaN: switched off below)
             float za[4];
             const float *zr = ds + (uu * 16 + i) * C + 4 * g;
             if (c4) {
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES, BWD_WGS) k_first_layer_bwd(con
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int j = 0; j < TPW; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(live_a ? za[s4] : 0.f, w2r[j][s4], d[j], 0, 0, 0);
+                for (int j = 0; j < TPW; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32((live_a && 4 * g + s4 < C) ? za[s4] : 0.f, w2r[j][s4], d[j], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int sh = (r % RPW) * LPR;                      // bit (r % RPW)·LPR + 16 tb + i of the 64-bit word
