@@ -676,7 +676,8 @@ extern "C" int dcr_first_layer_bwd_f32_dev(const float *dz, const float *w2, con
         DCR_FAIL(DCR_EINVAL, "bad first_layer_bwd arguments");
     if (in_features < 16 || (in_features % 16) != 0 || (hidden != 64 && hidden != 128) || classes < 1 || classes > 16)
         DCR_FAIL(DCR_EINVAL, "first_layer_bwd: in_features a multiple of 16, hidden 64 or 128, at most 16 classes");
-    if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)ws & 15)) DCR_FAIL(DCR_EINVAL, "first_layer_bwd: 16-byte aligned tensors and row stride expected");
+    if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)ws & 15) || ((uintptr_t)dz & 15) || ((uintptr_t)pre & 15) || ((uintptr_t)bits & 15))
+        DCR_FAIL(DCR_EINVAL, "first_layer_bwd: 16-byte aligned tensors and row stride expected (the stage copies move 16-byte pieces)");
     const int64_t blocks = first_layer_bwd_blocks(n_rows);
     const int64_t per1 = (int64_t)hidden * in_features;
     if (ws_floats < blocks * (per1 + 17 * hidden)) DCR_FAIL(DCR_EINVAL, "first_layer_bwd: workspace too small (dcr_first_layer_bwd_workspace)");

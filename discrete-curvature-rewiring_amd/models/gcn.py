@@ -591,7 +591,8 @@ class _FirstLayerFn(torch.autograd.Function):
         g_tr = g_tr.contiguous()
         stream = torch.cuda.current_stream(g_tr.device).cuda_stream
         n, hidden = pre.shape
-        if os.environ.get('DCR_FIRST_BWD_FUSED', '1') != '0' and ax.is_contiguous():
+        aligned = all(t.data_ptr() % 16 == 0 for t in (ax, g_tr, pre, ctx.bits))   # (the kernel's stage copies move 16-byte pieces)
+        if os.environ.get('DCR_FIRST_BWD_FUSED', '1') != '0' and ax.is_contiguous() and aligned:
             # one kernel (dcr_first_layer_bwd_f32_dev): the gradient of the pre-activation stays in registers between the
             # contraction with W2 that forms it and the contraction with Â·X that consumes it
             feats = ax.shape[1]
