@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_relu_dropout_fwd(const float *__restric
             if (e0 + j < n) v[j] = x[e0 + j];
     }
     uint32_t r[4];
-    philox4x32_10((uint64_t)t, offset, seed, r);
+    philox_quad16((uint64_t)t, offset, seed, r);
     bool keep[4];
     float o[4];
 #pragma unroll
@@ -375,8 +375,7 @@ extern "C" int dcr_relu_dropout_fwd_f32_ctr_dev(const float *x, float *y, uint64
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) DCR_FAIL(DCR_EINVAL, "relu_dropout: 16-byte aligned tensors expected");
     if (n == 0) return DCR_OK;
     const int64_t threads = (n + 3) / 4, blocks = (threads + 255) / 256;
-    const double th = p * 4294967296.0;
-    const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    const uint32_t threshold = dcr::dropout_threshold16(p);
     hipLaunchKernelGGL(k_relu_dropout_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, x, y,
                        (unsigned long long *)bits, n, (float)(1.0 / (1.0 - p)), threshold, seed, offset, offset_dev);
     DCR_HIP(hipGetLastError());
@@ -455,7 +454,7 @@ __global__ void __launch_bounds__(256) k_act_linear_fwd(const float *__restrict_
             for (int m = 0; m < HM; ++m) {
                 const int64_t t = row * LPR + 4 * m + g;
                 uint32_t r[4];
-                philox4x32_10((uint64_t)t, offset, seed, r);
+                philox_quad16((uint64_t)t, offset, seed, r);
                 float o[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -929,8 +928,7 @@ extern "C" int dcr_act_linear_fwd_f32_dev(const float *x, const float *w, float 
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (h_train && ((uintptr_t)h_train & 15)))
         DCR_FAIL(DCR_EINVAL, "act_linear: 16-byte aligned tensors expected");
     if (n_rows == 0) return DCR_OK;
-    const double th = p * 4294967296.0;
-    const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    const uint32_t threshold = dcr::dropout_threshold16(p);
     const float scale = (float)(1.0 / (1.0 - p));
     if (hidden == 128)
         dcr::launch_act_linear_fwd<8>(train, eval, x, w, h_train, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, classes, scale, threshold,

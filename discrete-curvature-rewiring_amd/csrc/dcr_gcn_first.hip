@@ -142,15 +142,36 @@ __device__ __forceinline__ void first_chunk(const FirstArgs &A, int64_t u, int64
         }
         f32x4 acc_tr = {0.f, 0.f, 0.f, 0.f}, acc_ev = {0.f, 0.f, 0.f, 0.f};
         uint32_t part[4] = {0u, 0u, 0u, 0u};  // keep bits of this lane's elements, bit 4t + g of column q's word
+        // The random words (philox_quad16: element-quad e = row·LPR + 4t + g draws call e >> 1, half e & 1).  Lanes g and g ^ 1 hold
+        // the two halves of the same calls: each draws HM / 2 of the pair's HM calls and the words change lanes through
+        // ds_bpermute (the LDS pipe) — half the Philox instructions, which on this chip are matrix-core time.
+        uint32_t rw[HM][4];
+        if (TRAIN) {
+            constexpr int HC = HM / 2;
+            const int s = g & 1;
+            uint32_t mine[HC][4], theirs[HC][4];
+#pragma unroll
+            for (int tt = 0; tt < HC; ++tt) {
+                const int64_t e = row * LPR + 4 * (HC * s + tt) + (g & ~1);   // (even: the call index is e >> 1)
+                philox4x32_10((uint64_t)(e >> 1), A.offset, A.seed, mine[tt]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) theirs[tt][q] = (uint32_t)__shfl_xor((int)mine[tt][q], 16);
+            }
+#pragma unroll
+            for (int t = 0; t < HM; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t w = (t / HC == s) ? mine[t % HC][q] : theirs[t % HC][q];
+                    rw[t][q] = (w >> (16 * s)) & 0xFFFFu;
+                }
+        }
 #pragma unroll
         for (int t = 0; t < HM; ++t) {
             const float4 wv = *reinterpret_cast<const float4 *>(w2l + 4 * ((4 * t) ^ gi));
             const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
             float o[4];
             if (TRAIN) {
-                const int64_t e = row * LPR + 4 * t + g;   // element-quad index of k_relu_dropout_fwd's numbering
-                uint32_t r[4];
-                philox4x32_10((uint64_t)e, A.offset, A.seed, r);
+                const uint32_t (&r)[4] = rw[t];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const bool keep = live[rt] && v[t][q] > 0.f && r[q] >= A.threshold;
@@ -651,8 +672,7 @@ extern "C" int dcr_first_layer_fwd_f32_dev(const float *ax, int64_t ldx, const f
     if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || (pre && ((uintptr_t)pre & 15)))
         DCR_FAIL(DCR_EINVAL, "first_layer_fwd: 16-byte aligned tensors and row stride expected");
     if (n_rows == 0) return DCR_OK;
-    const double th = p * 4294967296.0;
-    const uint32_t threshold = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    const uint32_t threshold = dcr::dropout_threshold16(p);
     const float scale = (float)(1.0 / (1.0 - p));
     hipStream_t st = (hipStream_t)hip_stream;
     if (hidden == 128)

@@ -1,5 +1,6 @@
 // Philox-4x32-10 as the fused ReLU + dropout kernels draw it (csrc/dcr_gcn.hip, csrc/dcr_gcn_first.hip): keyed by
-// (seed, call offset), counter = element-quad index.  One definition: the kernels must agree on every keep bit.
+// (seed, call offset), counter = element-quad index >> 1 (philox_quad16 below).  One definition: the kernels must agree on every
+// keep bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,6 +27,24 @@ __device__ inline void philox4x32_10(uint64_t index, uint64_t offset, uint64_t s
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] = c[j];
+}
+
+// 16 random bits per element (round 4; were 32): element-quad e draws call e >> 1 and takes the (e & 1) half of each of its four
+// words; an element is kept when its 16 bits are >= threshold16 = floor(p · 65536), so P(keep) = 1 - threshold16 / 65536: exact at
+// p = 0.5, within 2^-16 of 1 - p otherwise (the scale stays 1 / (1 - p), models/gcn.py:40-42 via torch.nn.Dropout).  Half the
+// Philox calls per element: on this chip the vector ALU's time is the f32 matrix core's time, and a kernel that
+// holds quads e and e ^ 1 in partner lanes draws each call once and exchanges the words (csrc/dcr_gcn_first.hip).
+__device__ inline void philox_quad16(uint64_t quad, uint64_t offset, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t r[4];
+    philox4x32_10(quad >> 1, offset, seed, r);
+    const uint32_t sh = (uint32_t)(quad & 1) * 16u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (r[j] >> sh) & 0xFFFFu;
+}
+
+inline uint32_t dropout_threshold16(double p) {
+    const double th = p * 65536.0;
+    return th >= 65535.0 ? 65535u : (uint32_t)th;
 }
 
 }  // namespace dcr

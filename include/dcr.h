@@ -238,7 +238,8 @@ int dcr_atb_f32_dev(const float *A_dev, const float *B_dev, float *C_dev, int64_
 /* ---- ReLU + dropout between the GCN layers (device pointers, caller's stream) ------------------------------------
  * models/gcn.py:38-42 (x = act_fn(x); x = dropout(x)) as one pass per direction: y = x > 0 and kept ? x / (1 - p) : 0,
  * the keep decisions packed one bit per element into `bits` (dcr_relu_dropout_bits_words(n) 64-bit words); backward
- * scales the incoming gradient by the same bits.  Philox-4x32-10 keyed by (seed, offset): reproducible for a seed. */
+ * scales the incoming gradient by the same bits.  Philox-4x32-10 keyed by (seed, offset): reproducible for a seed.
+ * Sixteen random bits per element: an element is kept with probability 1 - floor(p * 65536) / 65536 (exact at p = 0.5). */
 int dcr_relu_dropout_bits_words(int64_t n, int64_t *out_words);
 int dcr_relu_dropout_fwd_f32_dev(const float *x_dev, float *y_dev, uint64_t *bits_dev, int64_t n, double p, uint64_t seed,
                                  uint64_t offset, void *hip_stream);
