@@ -9,7 +9,7 @@ from dcr.graph import DcrGraph
 
 
 def bfc_edge(G, v1, v2):
-    g = as_dcr_graph(G)
+    g = as_dcr_graph(G, check=(v1, v2))
     if min(g.degree(v1), g.degree(v2)) == 1:
         return 0  # bfc_naive.py:18-19 returns the int 0
     return g.curvature_edge(v1, v2, 'bfc')
@@ -19,7 +19,7 @@ def bfc(G):
     """Curvature of every edge.  For a networkx graph the values are written to
     ``G[v1][v2]['bfc']`` as the reference does; a DcrGraph gets a ``.bfc`` dict
     keyed (v1, v2) in ``G.edges`` order."""
-    g = as_dcr_graph(G)
+    g = as_dcr_graph(G, check='all')
     eu, ev, cv = g.curvature_all('bfc')
     if isinstance(G, DcrGraph):
         G.bfc = {(u, v): c for u, v, c in zip(eu.tolist(), ev.tolist(), cv.tolist())}

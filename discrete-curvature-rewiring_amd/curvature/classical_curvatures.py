@@ -7,6 +7,8 @@ Balanced Forman curvature through the same two functions.  ``G`` is a
 ``dcr.DcrGraph`` (device-resident); a ``networkx.Graph`` is accepted and
 uploaded first.
 """
+import os
+
 from dcr.graph import DcrGraph, curv_code
 
 CURV_TYPES = ('1d', 'augmented', 'haantjes', 'bfc')
@@ -17,7 +19,8 @@ CURV_TYPES = ('1d', 'augmented', 'haantjes', 'bfc')
 # upload per call is O(E) host work per candidate.  The graph object is switched to a subclass of its own class whose
 # add_edge / remove_edge repeat the edit on the device copy (both containers append to the ends of the two rows and
 # delete in place: same adjacency order); every other mutating method drops the copy, which is then rebuilt at the next
-# call.  Edits that bypass the methods (writing into G.adj / G._adj directly) are not seen: pass refresh=True then.
+# call.  Edits that bypass the methods (writing into G.adj / G._adj directly) are caught where they change a degree that the
+# next call compares (_stale); otherwise pass refresh=True.  DCR_MIRROR=0: no mirroring at all.
 _MIRRORS = None      # WeakKeyDictionary: networkx graph -> [DcrGraph or None]
 _MIRROR_CLASS = {}   # networkx class -> its mirroring subclass
 
@@ -75,7 +78,7 @@ def _reduce_plain(self, cls, proto):
     return (cls.__new__, (cls,), state)
 
 
-def as_dcr_graph(G, device=0, refresh=False):
+def as_dcr_graph(G, device=0, refresh=False, check=None):
     """``G`` as a device-resident graph whose adjacency rows are in the SAME order as ``G.adj[u]`` for every node, so
     that ``G.edges`` order, and with it every first-extremum tie-break (sdrf_no_cuda.py:27,59,61), is networkx's.
 
@@ -84,7 +87,11 @@ def as_dcr_graph(G, device=0, refresh=False):
     the next one in the rows of both its endpoints) and replayed into the container.  Node labels must be 0..n-1 in
     insertion order, as curvature/bfc_naive.py:34-37 (positional rows of ``nx.adj_matrix``) needs them too.
 
-    A ``networkx.Graph`` is uploaded once and mirrored afterwards (see above); ``refresh=True`` uploads again.
+    A ``networkx.Graph`` is uploaded once and mirrored afterwards (see above); ``refresh=True`` uploads again, and so does
+    a mirror found stale: before it is reused the degrees of the nodes in ``check`` (the queried edge's endpoints), or — with
+    ``check='all'`` — of every node, are compared with the graph's (an edit written straight into ``G._adj`` that changes
+    none of the compared degrees is still not seen).  ``DCR_MIRROR=0`` in the environment switches mirroring off altogether:
+    an upload per call and the caller's graph keeps its class.
     """
     if isinstance(G, DcrGraph):
         return G
@@ -94,10 +101,14 @@ def as_dcr_graph(G, device=0, refresh=False):
         _MIRRORS = weakref.WeakKeyDictionary()
     m = _MIRRORS.get(G)
     if m is not None and m[0] is not None and not refresh:
-        return m[0]
+        if not _stale(G, m[0], check):
+            return m[0]
+        m[0] = None       # edited behind the mirroring methods: uploaded again below
     g = _upload(G, device)
     try:
         import networkx as nx
+        if os.environ.get('DCR_MIRROR', '1') == '0':
+            return g      # no mirror, the caller's graph keeps its class: an upload per call
         if type(G) is nx.Graph or type(G) in _MIRROR_CLASS.values():
             if type(G) is nx.Graph:
                 G.__class__ = _mirror_class(nx.Graph)
@@ -105,6 +116,23 @@ def as_dcr_graph(G, device=0, refresh=False):
     except ImportError:
         pass
     return g
+
+
+def _stale(G, g, check):
+    """Whether the device copy ``g`` disagrees with ``G`` on the degrees of the nodes named by ``check``."""
+    if check is None:
+        return False
+    adj = G._adj
+    if len(adj) != g.number_of_nodes():
+        return True
+    if isinstance(check, str):    # 'all': one pass over the rows (the callers that use it are O(E) anyway)
+        edges = sum(len(row) - (u in row) for u, row in adj.items())
+        return edges != 2 * g.number_of_edges()
+    for u in check:
+        row = adj.get(u)
+        if row is None or len(row) - (u in row) != g.degree(int(u)):
+            return True
+    return False
 
 
 def _upload(G, device=0):
@@ -144,14 +172,14 @@ def compute_curvature_edge(G, e, curv_type):
     if curv_type not in CURV_TYPES:
         raise Exception(f'Method {curv_type} not available.')
     v1, v2 = e
-    return _num(as_dcr_graph(G).curvature_edge(v1, v2, curv_type), curv_type)
+    return _num(as_dcr_graph(G, check=(v1, v2)).curvature_edge(v1, v2, curv_type), curv_type)
 
 
 def compute_curvature_graph(G, curv_type):
     """classical_curvatures.py:31-46: dict of dicts keyed [v1][v2] in ``G.edges`` orientation."""
     if curv_type not in CURV_TYPES:
         return None  # the reference falls through an ``assert True`` and returns None
-    g = as_dcr_graph(G)
+    g = as_dcr_graph(G, check='all')
     eu, ev, cv = g.curvature_all(curv_type)
     curv_dict = {}
     for u, v, c in zip(eu.tolist(), ev.tolist(), cv.tolist()):

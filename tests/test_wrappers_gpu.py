@@ -173,6 +173,23 @@ def test_networkx_graph_is_uploaded_once_and_mirrored(monkeypatch):
     assert type(pickle.loads(pickle.dumps(G))) is nx.Graph and type(copy.deepcopy(G)) is nx.Graph
     with pytest.raises(nx.NetworkXError):
         G.remove_edge(x, x + 10**6)
+    # an edit written straight into the adjacency (behind the mirroring methods): the endpoint's degree no longer matches the
+    # device copy, which is uploaded again instead of answering for the old graph (advisor, round 3)
+    i, j = cands[0]
+    G._adj[i][j] = {}
+    G._adj[j][i] = {}
+    O.add_edge(i, j)
+    assert compute_curvature_edge(G, (i, j), 'bfc') == so.curvature_edge(O, i, j, 'bfc') and len(uploads) == 3
+    del G._adj[i][j], G._adj[j][i]
+    O.remove_edge(i, j)
+    d = compute_curvature_graph(G, 'bfc')                     # (the whole-graph entry compares the edge count)
+    assert len(uploads) == 4 and all(d[u][v] == so.curvature_edge(O, u, v, 'bfc') for u, v in G.edges)
+    # DCR_MIRROR=0: no mirror, no change of class
+    monkeypatch.setenv('DCR_MIRROR', '0')
+    P = nx.Graph(G)
+    compute_curvature_edge(P, (x, y), 'bfc')
+    compute_curvature_edge(P, (x, y), 'bfc')
+    assert type(P) is nx.Graph and len(uploads) == 6
 
 
 def test_adjacency_that_is_no_undirected_graph_is_refused():
