@@ -1946,9 +1946,17 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
                 dv[q] = g.rowinfo[v[q]].y;
             }
             if (rok[q]) {
-                rcol[q] = g.col[r];
-                rrow[q] = g.slot_row[r];
+                // (the partner slot's record points back at this slot — its own sweep found u in v's row where this one found v
+                //  in u's: checked below in place of reading the partner slot's row and neighbour, two more random reads per
+                //  edge of the four this kernel made; slot 0 alone keeps the old check, a record of zeros would point at it)
                 b[q] = rec[r];  // from v's side: statistics over N(u) \ N(v) \ {v}
+                if (s0 + q * stride == 0) {
+                    rcol[q] = g.col[r];
+                    rrow[q] = g.slot_row[r];
+                } else {
+                    rcol[q] = (int64_t)b[q].w == s0 + q * stride ? u[q] : -1;
+                    rrow[q] = v[q];
+                }
             }
         }
 #pragma unroll
