@@ -52,6 +52,11 @@ constexpr int H2_MAXDEG = 5000;           // flagged neighbours live in every pa
                                           // a hub near the limit is split into many partitions, one workgroup each)
 constexpr int H2_CLASSES = 5;             // 0-2: one wave per node (<= 64 neighbours), 3-4: one workgroup per unit
 constexpr int H2_WB = 4;                  // weight buckets per class (units are laid out heaviest bucket first)
+// third word of an edge's record: the triangle count with the degree of the row's node above it (both below 2^16: H2_MAXDEG).
+// The closing kernel reads the OTHER endpoint's degree out of the partner record it fetches anyway, instead of a random read of
+// that node's row header: one random read per edge is left of the four it made in round 3.
+__device__ inline unsigned h2_rec_t(int T, int deg) { return (unsigned)T | ((unsigned)deg << 16); }
+static_assert(H2_MAXDEG < 65536, "record packing");
 constexpr int H2_SMALL_DEG = 64;
 #ifndef H2_Q
 #define H2_Q 2                            // 16-byte pieces per lane in flight in the streaming loops
@@ -618,7 +623,7 @@ __device__ inline void h2s_node(const View &g, int u, int2 ru, int k, int2 rk, H
             row_ok(g, make_int2(-1, rev), 33, u, k);  // adjacency not symmetric: report, never publish
         } else {
             const int T = __popc(s->b.adjlo[lane]) + __popc(s->b.adjhi[lane]);
-            rec[(int64_t)ru.x + lane] = make_uint4((unsigned)s->b.pos[lane], (unsigned)s->b.mx[lane], (unsigned)T, (unsigned)rev);
+            rec[(int64_t)ru.x + lane] = make_uint4((unsigned)s->b.pos[lane], (unsigned)s->b.mx[lane], h2_rec_t(T, ru.y), (unsigned)rev);
         }
     }
     h2_wave_sync();  // the arrays are rewritten by the next node
@@ -1236,13 +1241,13 @@ __device__ inline void h2_batch_end(const View &g, const H2Tasks tk, H2Alloc &al
         if (rev < 0 || rev >= g.cap_total) {
             row_ok(g, make_int2(-1, rev), 33, u, k);  // adjacency not symmetric: report, never publish
         } else if (!PARTS) {
-            rec[slot] = make_uint4((unsigned)pos, (unsigned)mx, (unsigned)T, (unsigned)rev);
+            rec[slot] = make_uint4((unsigned)pos, (unsigned)mx, h2_rec_t(T, ru.y), (unsigned)rev);
         } else {
             unsigned *r4 = reinterpret_cast<unsigned *>(rec + slot);
             if (pos) atomicAdd(&r4[0], (unsigned)pos);
             if (mx) atomicMax(&r4[1], (unsigned)mx);
             if (part == 0) {  // the flagged neighbours live in every partition's table: T and the slot are whole
-                r4[2] = (unsigned)T;
+                r4[2] = h2_rec_t(T, ru.y);
                 r4[3] = (unsigned)rev;
             }
         }
@@ -1941,15 +1946,13 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
             dv[q] = 0;
             rcol[q] = rrow[q] = -1;
             b[q] = make_uint4(0u, 0u, 0u, 0u);
-            if (want[q]) {
-                ru[q] = g.rowinfo[u[q]];
-                dv[q] = g.rowinfo[v[q]].y;
-            }
+            if (want[q]) ru[q] = g.rowinfo[u[q]];   // (consecutive slots share it; v's degree comes with the partner record)
             if (rok[q]) {
                 // (the partner slot's record points back at this slot — its own sweep found u in v's row where this one found v
                 //  in u's: checked below in place of reading the partner slot's row and neighbour, two more random reads per
                 //  edge of the four this kernel made; slot 0 alone keeps the old check, a record of zeros would point at it)
                 b[q] = rec[r];  // from v's side: statistics over N(u) \ N(v) \ {v}
+                dv[q] = (int)(b[q].z >> 16);
                 if (s0 + q * stride == 0) {
                     rcol[q] = g.col[r];
                     rrow[q] = g.slot_row[r];
@@ -1965,19 +1968,19 @@ __global__ void __launch_bounds__(256) k_h2_final(View g, const uint4 *rec, doub
             if (!want[q]) continue;
             if (s < ru[q].x || (int)(s - ru[q].x) >= ru[q].y) continue;  // slack behind the row
             double val;
-            if ((ru[q].y < dv[q] ? ru[q].y : dv[q]) == 1) {  // bfc_naive.py:18-19
+            if (ru[q].y == 1 || (rok[q] && dv[q] == 1)) {  // bfc_naive.py:18-19
                 val = 0.0;
             } else {
                 if (!rok[q] || rcol[q] != u[q] || rrow[q] != v[q]) {
                     row_ok(g, make_int2(-1, (int)a[q].w), 39, u[q], v[q]);
                     continue;
                 }
-                if (a[q].z != b[q].z) {  // both sides count the same triangles
+                if ((a[q].z & 0xFFFFu) != (b[q].z & 0xFFFFu) || (int)(a[q].z >> 16) != ru[q].y) {  // both sides count the same triangles
                     row_ok(g, make_int2(-1, (int)a[q].z), 40, u[q], v[q]);
                     continue;
                 }
                 const int gam = (int)(a[q].y > b[q].y ? a[q].y : b[q].y);
-                val = bfc_formula(ru[q].y, dv[q], (int)a[q].z, (int)b[q].x, (int)a[q].x, gam);
+                val = bfc_formula(ru[q].y, dv[q], (int)(a[q].z & 0xFFFFu), (int)b[q].x, (int)a[q].x, gam);
             }
             curv[s] = val;
             ext_take(lo_v, lo_s, val, (int)s, 0);
