@@ -804,6 +804,10 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     g->ext_part_valid = false;  // (set again by the two-hop pass's closing kernel)
     // first minimum in G.edges order, same host sync as the pass: from the closing kernel's per-block minima when it left some
     auto argmin_after_pass = [&]() -> int {
+        // (a pass of the node-centric kernels — incremental ones above all — leaves no partial extrema: ONE sweep takes both,
+        //  the stale arg-max of the removal step then is a 5 us reduction as behind the two-hop pass; DCR_ARGEXT_BOTH=0: two sweeps)
+        static const bool both = !(getenv("DCR_ARGEXT_BOTH") && atoi(getenv("DCR_ARGEXT_BOTH")) == 0);
+        if (!g->ext_part_valid && both) DCR_TRY(launch_argext_both(g));
         return g->ext_part_valid ? launch_argext_from_parts(g, 0) : launch_argext(g, 0, -1, -1);
     };
     // incremental is only sound on top of a complete buffer of the same curvature kind whose later edits were all

@@ -88,6 +88,45 @@ __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_tot
     if (threadIdx.x == 0) partial[blockIdx.x] = ext_make(best_v, best_s);
 }
 
+// both extrema in ONE sweep, left as per-workgroup partials where the two-hop pass's closing kernel leaves its per-wave ones
+// (g->ext_part): after a node-centric or incremental pass the arg-min of the loop (sdrf_no_cuda.py:27) and the stale arg-max of
+// its removal step (:57-61) were two sweeps of 13 us each
+__global__ void __launch_bounds__(256) k_argext_edges_both(RowView g, int64_t cap_total, const double *curv, Ext *part_min, Ext *part_max) {
+    __shared__ double shv[4];
+    __shared__ int shs[4];
+    double lo_v = 0.0, hi_v = 0.0;
+    int lo_s = -1, hi_s = -1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s0 < cap_total; s0 += 4 * stride) {
+        int u[4], v[4];
+        int2 ru[4];
+        bool ok[4];
+        double cv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t s = s0 + q * stride;
+            ok[q] = s < cap_total;
+            u[q] = ok[q] ? g.slot_row[s] : 0;
+            v[q] = ok[q] ? g.col[s] : -1;
+            cv[q] = ok[q] ? curv[s] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ru[q] = ok[q] ? g.rowinfo[u[q]] : make_int2(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t s = s0 + q * stride;
+            if (!ok[q] || (int)(s - ru[q].x) >= ru[q].y || v[q] <= u[q]) continue;
+            ext_take(lo_v, lo_s, cv[q], (int)s, 0);
+            ext_take(hi_v, hi_s, cv[q], (int)s, 1);
+        }
+    }
+    ext_block_reduce(lo_v, lo_s, 0, shv, shs);
+    if (threadIdx.x == 0) part_min[blockIdx.x] = ext_make(lo_v, lo_s);
+    __syncthreads();
+    ext_block_reduce(hi_v, hi_s, 1, shv, shs);
+    if (threadIdx.x == 0) part_max[blockIdx.x] = ext_make(hi_v, hi_s);
+}
+
 __global__ void __launch_bounds__(1024) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
                                                         DevResult *res) {
     __shared__ double shv[16];
@@ -158,6 +197,26 @@ int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_
     hipLaunchKernelGGL(k_argext_final, dim3(1), dim3(nparts_threads((int)blocks)), 0, st, vw, (const Ext *)g->red_scratch, (int)blocks,
                        want_max, g->dres);
     DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+// one sweep for both extrema; the partials stay valid until the next edit (as the closing kernel's of the two-hop pass)
+int launch_argext_both(dcr_graph *g, hipStream_t st) {
+    if (!st) st = g->stream;
+    if (!g->ext_part) {
+        Ext *p = nullptr;
+        DCR_TRY(dev_alloc(&p, 2 * EXT_PART_BLOCKS));
+        g->ext_part = p;
+    }
+    RowView vw{g->rowinfo, g->col, g->slot_row};
+    int64_t blocks = (g->cap_total + 255) / 256;
+    if (blocks > ARGEXT_BLOCKS) blocks = ARGEXT_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_argext_edges_both, dim3((unsigned)blocks), dim3(256), 0, st, vw, g->cap_total, g->curv, (Ext *)g->ext_part,
+                       (Ext *)g->ext_part + EXT_PART_BLOCKS);
+    DCR_HIP(hipGetLastError());
+    g->ext_part_n = (int)blocks;
+    g->ext_part_valid = true;
     return DCR_OK;
 }
 
