@@ -2,8 +2,8 @@ cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pg && EAGER=1 EPOCHS=6 timeout -k 1
 import csv
 rows = list(csv.DictReader(open('/tmp/pg/p_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# last epoch: from the last k_act_linear_fwd back to the one before
-idx = [i for i, r in enumerate(rows) if 'k_act_linear_fwd' in r['Kernel_Name']]
+# last epoch: from the last k_first_layer_fwd back to the one before
+idx = [i for i, r in enumerate(rows) if 'k_first_layer_fwd' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
