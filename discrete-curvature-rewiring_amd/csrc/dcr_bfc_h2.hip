@@ -41,6 +41,8 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "dcr_bfc_common.h"
 
@@ -360,6 +362,13 @@ __device__ inline void h2_retry_push(const H2Retry rt, int u, int d, int cls) { 
     for (int j = 0; j < nparts; ++j) rt.units[first + j] = make_int4(u, (nparts << 16) | j, 0, 0);
 }
 
+#ifdef H2_UNIT_TIMES  // diagnostic build (tools/build_variant.sh ut -DH2_UNIT_TIMES): start and duration of every block-class unit
+constexpr unsigned H2_UT_CAP = 16384;
+__device__ int4 h2_ut[H2_UT_CAP];      // {node, class | partitions << 16 | partition, s_memtime ticks, start tick}
+__device__ unsigned h2_ut_n;
+__device__ long long h2_ut_t0;
+__global__ void k_h2_ut_mark() { h2_ut_t0 = (long long)__builtin_amdgcn_s_memtime(); h2_ut_n = 0u; }
+#endif
 #ifdef H2_PROF  // diagnostic build (tools/build_variant.sh prof -DH2_PROF): wave-cycles per section of the wave classes
 __device__ unsigned long long h2_prof[32];
 #define H2_STAMP(i)                                                      \
@@ -1618,7 +1627,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)
         }
         if (!ok) continue;
         H2List ls = h2_list_of(tk.lists, NW);  // (fresh per unit)
-        if (!h2_node<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, &sc_all[wid], rec, ls)) {
+#ifdef H2_UNIT_TIMES
+        const long long ut0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        const bool unit_ok = h2_node<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, &sc_all[wid], rec, ls);
+#ifdef H2_UNIT_TIMES
+        if (threadIdx.x == 0 && !is_retry) {
+            const long long ut1 = (long long)__builtin_amdgcn_s_memtime();
+            const unsigned slot = atomicAdd(&h2_ut_n, 1u);
+            if (slot < H2_UT_CAP) h2_ut[slot] = make_int4(u, (PARTS ? 0x40000000 : 0) | (nparts << 16) | part, (int)(ut1 - ut0), (int)((ut0 - h2_ut_t0) & 0x7FFFFFFF));
+        }
+#endif
+        if (!unit_ok) {
             if (threadIdx.x == 0) {  // every partition of the node is redone (the retry starts from zeroed records)
                 if (is_retry) {
                     rt.res->h2_status = 1;
@@ -2135,6 +2155,43 @@ static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, con
                        st, vw, tkl, units, count, cap, g->h2_rec, rt, is_retry);
 }
 
+#ifdef H2_UNIT_TIMES
+static void h2_print_unit_times(dcr_graph *g) {
+    (void)hipStreamSynchronize(g->stream);
+    (void)hipDeviceSynchronize();
+    static int4 h[H2_UT_CAP];
+    unsigned n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(h2_ut_n), sizeof(n));
+    if (n > H2_UT_CAP) n = H2_UT_CAP;
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(h2_ut), sizeof(int4) * n);
+    std::vector<int2> ri(g->n);
+    std::vector<int32_t> wt(g->n);
+    (void)hipMemcpy(ri.data(), g->rowinfo, sizeof(int2) * g->n, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(wt.data(), g->h2_weight, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost);
+    for (int cls = 0; cls < 2; ++cls) {
+        std::vector<int4> v;
+        double sum = 0;
+        for (unsigned i = 0; i < n; ++i)
+            if (((h[i].y >> 30) & 1) == cls) { v.push_back(h[i]); sum += h[i].z; }
+        std::sort(v.begin(), v.end(), [](const int4 &a, const int4 &b) { return a.z > b.z; });
+        fprintf(stderr, "[h2 units] class %s: %zu units, total %.1f us of unit time (s_memtime at 100 MHz), longest:\n", cls ? "L (split)" : "M", v.size(), sum / 100.0);
+        for (size_t i = 0; i < v.size() && i < 12; ++i)
+            fprintf(stderr, "    node %6d deg %5d W %8d part %d/%d: %7.1f us, started at %7.1f us\n", v[i].x, ri[v[i].x].y, wt[v[i].x] & 0x7FFFFFFF, v[i].y & 0xFFFF,
+                    (v[i].y >> 16) & 0x3FFF, v[i].z / 100.0, v[i].w / 100.0);
+        // histogram of durations and the last end
+        double last_end = 0;
+        int hist[8] = {0};
+        for (auto &e : v) {
+            last_end = std::max(last_end, (e.w + e.z) / 100.0);
+            const double us = e.z / 100.0;
+            hist[us < 10 ? 0 : us < 20 ? 1 : us < 40 ? 2 : us < 80 ? 3 : us < 160 ? 4 : us < 320 ? 5 : 6]++;
+        }
+        fprintf(stderr, "    durations <10 / <20 / <40 / <80 / <160 / <320 / more us: %d %d %d %d %d %d %d; last unit ends at %.1f us\n", hist[0], hist[1], hist[2],
+                hist[3], hist[4], hist[5], hist[6], last_end);
+    }
+}
+#endif
+
 int launch_curvature_pass_h2(dcr_graph *g) {
     if (g->num_cu <= 0) {
         g->num_cu = 256;
@@ -2180,6 +2237,101 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     // records of split nodes are accumulated with atomics: start from zero
     hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4],
                        g->h2_rec);
+    // Round 5: a layout with FEWER streams (DCR_H2_LAYOUT="l,m,s2,s1,s0": the stream, 0 = main, 1-3 = side streams, each class
+    // kernel is launched on; kernels on one stream run one after the other).  Five persistent full-chip kernels on five streams
+    // do not run five abreast anyway (the runtime maps streams onto four hardware queues, and the split class's workgroups
+    // hold 125 KB of a CU's LDS), and every stream the closing kernel has to join costs a barrier packet of 10-15 us on the
+    // critical path (the 48-75 us hole in front of k_h2_final in the round-4 timelines).
+#ifdef H2_UNIT_TIMES
+    hipLaunchKernelGGL(k_h2_ut_mark, dim3(1), dim3(1), 0, g->stream);
+#endif
+    // Measured (profiles/r05_layouts.txt, interleaved rounds, pass ms): S100k five streams 1.020, "0,1,2,2,1" 0.962, "0,1,1,2,2"
+    // 0.962, "0,1,2,2,2" 0.984, "0,1,2,3,3" 0.983, "0,1,1,1,1" 1.094; S1M five streams 10.10, "0,1,2,2,1" 10.70 — the fixed
+    // costs do not matter there and five abreast packs the chip better.  Default: three streams below 400k nodes.
+    static const char *layout_env = getenv("DCR_H2_LAYOUT");
+    const bool layout_default = !layout_env && g->n < 400000;
+    if ((layout_default || (layout_env && strcmp(layout_env, "five") != 0)) && !serial) {
+        int lay[5] = {0, 1, 2, 2, 1};
+        int a[5];
+        if (layout_env && sscanf(layout_env, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) == 5)
+            for (int c = 0; c < 5; ++c) lay[c] = a[c] < 0 ? 0 : a[c] > 3 ? 3 : a[c];
+        hipStream_t pool[4] = {g->stream, g->side[1], g->low[0], g->low[1]};
+        hipEvent_t done[4] = {nullptr, g->ev_join[1], g->ev_join[2], g->ev_join[3]};
+        bool used[4] = {true, false, false, false};
+        DCR_HIP(hipEventRecord(g->ev_fork, g->stream));
+        auto on = [&](int c) {
+            const int si = lay[c];
+            if (!used[si]) {
+                used[si] = true;
+                (void)hipStreamWaitEvent(pool[si], g->ev_fork, 0);   // (an error surfaces at hipGetLastError below)
+            }
+            return pool[si];
+        };
+        const int64_t hint4 = g->h2_last_count[4] >= 0 ? (int64_t)g->h2_last_count[4] + 8 : g->num_cu;
+        const int64_t hint3 = g->h2_last_count[3] >= 0 ? (int64_t)g->h2_last_count[3] + 8 : 3 * (int64_t)g->num_cu;
+        static const bool keep_eset2 = !(getenv("DCR_H2_ESET_KEEP") && atoi(getenv("DCR_H2_ESET_KEEP")) == 0);
+        const bool patch2 = keep_eset2 && g->h2_eset_valid && g->h2_eset_pending <= EDIT_LOG_CAP &&
+                            g->h2_eset_tombs + g->h2_eset_pending <= ((int64_t)1 << g->h2_eset_bits) / 16;
+        // the edge set first (probed by the triangle steps only): patched by one thread on the main stream ahead of the split
+        // class, or rebuilt on the aux stream beside everything
+        bool eset_on_aux = false;
+        if (patch2) {
+            if (g->h2_eset_pending > 0) {
+                hipLaunchKernelGGL(k_h2_eset_apply, dim3(1), dim3(64), 0, g->stream, es, g->dres, status);
+                g->h2_eset_tombs += g->h2_eset_pending;
+                DCR_HIP(hipEventRecord(g->ev_fork, g->stream));   // (the side streams start behind it: their triangle steps probe the set)
+            }
+        } else {
+            DCR_HIP(hipStreamWaitEvent(g->aux, g->ev_fork, 0));
+            DCR_HIP(hipMemsetAsync(g->h2_eset, 0xFF, sizeof(unsigned long long) << g->h2_eset_bits, g->aux));
+            DCR_HIP(hipMemsetAsync(g->h2_bloom, 0, sizeof(unsigned) * (((size_t)1 << g->h2_bloom_bits) / 32), g->aux));
+            if (sblocks > 0) hipLaunchKernelGGL(k_h2_eset_build, dim3((unsigned)sblocks), dim3(256), 0, g->aux, vw, es, status, g->dres);
+            g->h2_eset_tombs = 0;
+            DCR_HIP(hipEventRecord(g->ev_aux, g->aux));
+            eset_on_aux = true;
+        }
+        g->h2_eset_valid = true;
+        g->h2_eset_pending = 0;
+        // launch order = the order of the classes in the layout string's streams: split class, M, then the wave classes
+        launch_h2_block<4, true>(g, vw, tk, rt, g->h2_units[4], &g->dres->h2_count[4], g->h2_units_cap[4], hint4, 0, on(0));
+        launch_h2_block<3, false>(g, vw, tkM, rt, g->h2_units[3], &g->dres->h2_count[3], g->h2_units_cap[3], hint3, 0, on(1));
+        // each block class's triangle step right behind it on its own stream
+        if (eset_on_aux) DCR_HIP(hipStreamWaitEvent(pool[lay[0]], g->ev_aux, 0));
+        hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 4)), dim3(256), 0, pool[lay[0]], es, tk, g->h2_rec, status, 0);
+        if (eset_on_aux && lay[1] != lay[0]) DCR_HIP(hipStreamWaitEvent(pool[lay[1]], g->ev_aux, 0));
+        hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 8)), dim3(256), 0, pool[lay[1]], es, tkM, g->h2_rec, status, 0);
+        launch_h2_small<2>(g, vw, rt, on(2));
+        launch_h2_small<1>(g, vw, rt, on(3));
+        launch_h2_small<0>(g, vw, rt, on(4));
+        for (int si = 1; si < 4; ++si)
+            if (used[si]) {
+                DCR_HIP(hipEventRecord(done[si], pool[si]));
+                DCR_HIP(hipStreamWaitEvent(g->stream, done[si], 0));
+            }
+        if (!g->ext_part) {
+            Ext *p = nullptr;
+            DCR_TRY(dev_alloc(&p, 2 * EXT_PART_BLOCKS));
+            g->ext_part = p;
+        }
+        int64_t fb = (sblocks + H2_FINAL_Q - 1) / H2_FINAL_Q;
+        if (fb > H2_FINAL_BLOCKS) fb = H2_FINAL_BLOCKS;
+        if (fb > EXT_PART_BLOCKS / 4) fb = EXT_PART_BLOCKS / 4;
+        if (fb < 1) fb = 1;
+        const bool retry2 = g->h2_expect_retry;
+        if (retry2) {
+            hipLaunchKernelGGL(k_h2_retry_zero, dim3(1024), dim3(256), 0, g->stream, vw, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap,
+                               g->h2_rec);
+            tk.retry_flag = 0x80000000u;
+            launch_h2_block<4, true>(g, vw, tk, rt, g->h2_retry, &g->dres->h2_retry, g->h2_retry_cap, 64, 1, g->stream);
+            hipLaunchKernelGGL(k_h2_triangles, dim3((unsigned)(g->num_cu * 2)), dim3(256), 0, g->stream, es, tk, g->h2_rec, status, 1);
+        }
+        hipLaunchKernelGGL(k_h2_final, dim3((unsigned)fb), dim3(256), 0, g->stream, vw, g->h2_rec, g->curv, status, (Ext *)g->ext_part,
+                           (Ext *)g->ext_part + EXT_PART_BLOCKS, &g->dres->h2_retry, retry2 ? 1 : 0);
+        g->ext_part_n = (int)fb * 4;
+        g->ext_part_valid = true;
+        DCR_HIP(hipGetLastError());
+        return DCR_OK;
+    }
     // Streams: the block classes (long units; the triangle step waits for them only) on two high-priority streams, the
     // wave classes on three low-priority ones, the edge set on a stream of its own, the triangle step on a fourth
     // high-priority stream as soon as block classes and edge set are done — beside the wave classes, which list nothing.
@@ -2287,6 +2439,9 @@ int launch_curvature_pass_h2(dcr_graph *g) {
     g->ext_part_valid = true;  // (dropped again by the caller if the pass reports a failure, and by every edit)
     DCR_HIP(hipGetLastError());
     static const bool debug = getenv("DCR_H2_DEBUG") != nullptr;
+#ifdef H2_UNIT_TIMES
+    h2_print_unit_times(g);
+#endif
 #ifdef H2_PROF
     {
         unsigned long long h[32];

@@ -57,6 +57,116 @@ __device__ __forceinline__ void first_load(const FirstArgs &A, int64_t u, int i,
     for (int rt = 0; rt < CNT; ++rt) a0[rt] = *reinterpret_cast<const float4 *>(first_row_ptr(A, u + rt, i, g));
 }
 
+// The epilogue of one 16-row unit: + b1, pre stored, then k_act_linear_fwd's body (csrc/dcr_gcn.hip) on the registers — same
+// Philox counters, same keep-bit words, same order of operations in the second contraction.  acc[t] register r of lane (i, g)
+// is the contraction for pre[row i of the unit][16t + 4g + r].  Every group of stores sits behind ONE branch (a branch per store
+// cuts the epilogue into basic blocks, each with its own LDS read and wait), and the two operands' MFMA chains (4 HM dependent
+// instructions each) are interleaved.  Shared by the kernel that keeps W1 in LDS and the K-chunked one for wide inputs.
+template <int HM, bool TRAIN, bool EVAL>
+__device__ __forceinline__ void first_epilogue(const FirstArgs &A, int64_t unit, const f32x4 (&acc)[HM], const float *w2l, const float *b1g,
+                                               int i, int g) {
+    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR;
+    const int gi = g ^ i;
+    const bool live = unit * 16 + i < A.n_rows;
+    const int64_t row = unit * 16 + i;
+    float v[HM][4];
+#pragma unroll
+    for (int t = 0; t < HM; ++t) {
+        const float4 b = *reinterpret_cast<const float4 *>(b1g + 16 * t);
+        v[t][0] = acc[t][0] + b.x; v[t][1] = acc[t][1] + b.y; v[t][2] = acc[t][2] + b.z; v[t][3] = acc[t][3] + b.w;
+    }
+    if (A.pre && live) {
+        float *dst = A.pre + row * H + 4 * g;
+#pragma unroll
+        for (int t = 0; t < HM; ++t) *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+    }
+    f32x4 acc_tr = {0.f, 0.f, 0.f, 0.f}, acc_ev = {0.f, 0.f, 0.f, 0.f};
+    uint32_t part[4] = {0u, 0u, 0u, 0u};  // keep bits of this lane's elements, bit 4t + g of column q's word
+    // The random words (philox_quad16: element-quad e = row·LPR + 4t + g draws call e >> 1, half e & 1).  Lanes g and g ^ 1 hold
+    // the two halves of the same calls: each draws HM / 2 of the pair's HM calls and the words change lanes through
+    // ds_bpermute (the LDS pipe) — half the Philox instructions, which on this chip are matrix-core time.
+    uint32_t rw[HM][4];
+    if (TRAIN) {
+        constexpr int HC = HM / 2;
+        const int s = g & 1;
+        uint32_t mine[HC][4], theirs[HC][4];
+#pragma unroll
+        for (int tt = 0; tt < HC; ++tt) {
+            const int64_t e = row * LPR + 4 * (HC * s + tt) + (g & ~1);   // (even: the call index is e >> 1)
+            philox4x32_10((uint64_t)(e >> 1), A.offset, A.seed, mine[tt]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) theirs[tt][q] = (uint32_t)__shfl_xor((int)mine[tt][q], 16);
+        }
+#pragma unroll
+        for (int t = 0; t < HM; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w = (t / HC == s) ? mine[t % HC][q] : theirs[t % HC][q];
+                rw[t][q] = (w >> (16 * s)) & 0xFFFFu;
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < HM; ++t) {
+        const float4 wv = *reinterpret_cast<const float4 *>(w2l + 4 * ((4 * t) ^ gi));
+        const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+        float o[4];
+        if (TRAIN) {
+            const uint32_t (&r)[4] = rw[t];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool keep = live && v[t][q] > 0.f && r[q] >= A.threshold;
+                o[q] = keep ? v[t][q] * A.scale : 0.f;
+                part[q] |= keep ? (1u << (4 * t + g)) : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (TRAIN) acc_tr = __builtin_amdgcn_mfma_f32_16x16x4f32(o[q], wq[q], acc_tr, 0, 0, 0);
+            if (EVAL) acc_ev = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t][q] > 0.f ? v[t][q] : 0.f, wq[q], acc_ev, 0, 0, 0);
+        }
+    }
+    if (TRAIN) {
+        unsigned long long words[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t p = part[q];
+            p |= (uint32_t)__shfl_xor((int)p, 16);
+            p |= (uint32_t)__shfl_xor((int)p, 32);
+            unsigned long long word = (unsigned long long)p << ((i % RPW) * LPR);
+            uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+#pragma unroll
+            for (int d = 1; d < RPW; d <<= 1) {
+                lo |= (uint32_t)__shfl_xor((int)lo, d);
+                hi |= (uint32_t)__shfl_xor((int)hi, d);
+            }
+            words[q] = ((unsigned long long)hi << 32) | lo;
+        }
+        if (g == 0 && (i % RPW) == 0 && live) {
+            unsigned long long *dst = A.bits + (row / RPW) * 4;   // (32-byte aligned: two 16-byte stores)
+            *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(words[0], words[1]);
+            *reinterpret_cast<ulonglong2 *>(dst + 2) = make_ulonglong2(words[2], words[3]);
+        }
+    }
+    // accumulator register r of lane (i, g) is z[row 4g + r of the unit][class i]
+    const int64_t orow = unit * 16 + 4 * g;
+    if (i < A.C) {
+        if (orow + 3 < A.n_rows) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (TRAIN) A.z_train[(orow + r) * A.ldz + i] = acc_tr[r];
+                if (EVAL) A.z_eval[(orow + r) * A.ldz + i] = acc_ev[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (orow + r < A.n_rows) {
+                    if (TRAIN) A.z_train[(orow + r) * A.ldz + i] = acc_tr[r];
+                    if (EVAL) A.z_eval[(orow + r) * A.ldz + i] = acc_ev[r];
+                }
+        }
+    }
+}
+
 // CNT consecutive 16-row units starting at unit u (all inside the wave's range): main contraction, then the epilogue.
 // a0 arrives holding the first piece of the units' rows (first_load) and leaves holding the first piece of the CNT units at
 // u_next (u_next >= 0): that load flies under the epilogue.
@@ -67,7 +177,6 @@ __device__ __forceinline__ void first_load(const FirstArgs &A, int64_t u, int i,
 template <int HM, int CNT, bool TRAIN, bool EVAL>
 __device__ __forceinline__ void first_chunk(const FirstArgs &A, int64_t u, int64_t u_next, const float *w1l, const float *w2l, const float *b1g,
                                             int FS, int i, int g, float4 (&a0)[CNT]) {
-    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR;
     const int n_m = A.F / 16, gi = g ^ i;
     f32x4 acc[CNT][HM];
 #pragma unroll
@@ -75,10 +184,8 @@ __device__ __forceinline__ void first_chunk(const FirstArgs &A, int64_t u, int64
 #pragma unroll
         for (int t = 0; t < HM; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *ap[CNT], *apn[CNT];
-    bool live[CNT];
 #pragma unroll
     for (int rt = 0; rt < CNT; ++rt) {
-        live[rt] = (u + rt) * 16 + i < A.n_rows;
         ap[rt] = first_row_ptr(A, u + rt, i, g);
         apn[rt] = u_next >= 0 ? first_row_ptr(A, u_next + rt, i, g) : ap[rt];
     }
@@ -123,109 +230,9 @@ __device__ __forceinline__ void first_chunk(const FirstArgs &A, int64_t u, int64
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // epilogue, 16 rows at a time: + b1, pre stored, then k_act_linear_fwd's body on the registers.  Every group of stores
-    // sits behind ONE branch (a branch per store cuts the epilogue into basic blocks, each with its own LDS read and wait),
-    // and the two operands' MFMA chains (4 HM dependent instructions each) are interleaved.
+    // epilogue, 16 rows at a time (first_epilogue)
 #pragma unroll
-    for (int rt = 0; rt < CNT; ++rt) {
-        const int64_t row = (u + rt) * 16 + i;
-        float v[HM][4];
-#pragma unroll
-        for (int t = 0; t < HM; ++t) {
-            const float4 b = *reinterpret_cast<const float4 *>(b1g + 16 * t);
-            v[t][0] = acc[rt][t][0] + b.x; v[t][1] = acc[rt][t][1] + b.y; v[t][2] = acc[rt][t][2] + b.z; v[t][3] = acc[rt][t][3] + b.w;
-        }
-        if (A.pre && live[rt]) {
-            float *dst = A.pre + row * H + 4 * g;
-#pragma unroll
-            for (int t = 0; t < HM; ++t) *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
-        }
-        f32x4 acc_tr = {0.f, 0.f, 0.f, 0.f}, acc_ev = {0.f, 0.f, 0.f, 0.f};
-        uint32_t part[4] = {0u, 0u, 0u, 0u};  // keep bits of this lane's elements, bit 4t + g of column q's word
-        // The random words (philox_quad16: element-quad e = row·LPR + 4t + g draws call e >> 1, half e & 1).  Lanes g and g ^ 1 hold
-        // the two halves of the same calls: each draws HM / 2 of the pair's HM calls and the words change lanes through
-        // ds_bpermute (the LDS pipe) — half the Philox instructions, which on this chip are matrix-core time.
-        uint32_t rw[HM][4];
-        if (TRAIN) {
-            constexpr int HC = HM / 2;
-            const int s = g & 1;
-            uint32_t mine[HC][4], theirs[HC][4];
-#pragma unroll
-            for (int tt = 0; tt < HC; ++tt) {
-                const int64_t e = row * LPR + 4 * (HC * s + tt) + (g & ~1);   // (even: the call index is e >> 1)
-                philox4x32_10((uint64_t)(e >> 1), A.offset, A.seed, mine[tt]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) theirs[tt][q] = (uint32_t)__shfl_xor((int)mine[tt][q], 16);
-            }
-#pragma unroll
-            for (int t = 0; t < HM; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t w = (t / HC == s) ? mine[t % HC][q] : theirs[t % HC][q];
-                    rw[t][q] = (w >> (16 * s)) & 0xFFFFu;
-                }
-        }
-#pragma unroll
-        for (int t = 0; t < HM; ++t) {
-            const float4 wv = *reinterpret_cast<const float4 *>(w2l + 4 * ((4 * t) ^ gi));
-            const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-            float o[4];
-            if (TRAIN) {
-                const uint32_t (&r)[4] = rw[t];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool keep = live[rt] && v[t][q] > 0.f && r[q] >= A.threshold;
-                    o[q] = keep ? v[t][q] * A.scale : 0.f;
-                    part[q] |= keep ? (1u << (4 * t + g)) : 0u;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (TRAIN) acc_tr = __builtin_amdgcn_mfma_f32_16x16x4f32(o[q], wq[q], acc_tr, 0, 0, 0);
-                if (EVAL) acc_ev = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t][q] > 0.f ? v[t][q] : 0.f, wq[q], acc_ev, 0, 0, 0);
-            }
-        }
-        if (TRAIN) {
-            unsigned long long words[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t p = part[q];
-                p |= (uint32_t)__shfl_xor((int)p, 16);
-                p |= (uint32_t)__shfl_xor((int)p, 32);
-                unsigned long long word = (unsigned long long)p << ((i % RPW) * LPR);
-                uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
-#pragma unroll
-                for (int d = 1; d < RPW; d <<= 1) {
-                    lo |= (uint32_t)__shfl_xor((int)lo, d);
-                    hi |= (uint32_t)__shfl_xor((int)hi, d);
-                }
-                words[q] = ((unsigned long long)hi << 32) | lo;
-            }
-            if (g == 0 && (i % RPW) == 0 && live[rt]) {
-                unsigned long long *dst = A.bits + (row / RPW) * 4;   // (32-byte aligned: two 16-byte stores)
-                *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(words[0], words[1]);
-                *reinterpret_cast<ulonglong2 *>(dst + 2) = make_ulonglong2(words[2], words[3]);
-            }
-        }
-        // accumulator register r of lane (i, g) is z[row 4g + r of the unit][class i]
-        const int64_t orow = (u + rt) * 16 + 4 * g;
-        if (i < A.C) {
-            if (orow + 3 < A.n_rows) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (TRAIN) A.z_train[(orow + r) * A.ldz + i] = acc_tr[r];
-                    if (EVAL) A.z_eval[(orow + r) * A.ldz + i] = acc_ev[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (orow + r < A.n_rows) {
-                        if (TRAIN) A.z_train[(orow + r) * A.ldz + i] = acc_tr[r];
-                        if (EVAL) A.z_eval[(orow + r) * A.ldz + i] = acc_ev[r];
-                    }
-            }
-        }
-    }
+    for (int rt = 0; rt < CNT; ++rt) first_epilogue<HM, TRAIN, EVAL>(A, u + rt, acc[rt], w2l, b1g, i, g);
 }
 
 template <int HM, int NR, bool TRAIN, bool EVAL>
@@ -282,10 +289,11 @@ template <int HM, int NR>
 static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2, float *pre,
                               float *z_train, float *z_eval, int64_t ldz, unsigned long long *bits, int64_t n_rows, int F, int C, float scale,
                               uint32_t threshold, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
-    static int cus = 0;
+    static int cus_dev[64] = {};   // per device (advisor, round 4: a process may drive several GPUs)
+    int dev = 0;
+    DCR_HIP(hipGetDevice(&dev));
+    int &cus = cus_dev[dev & 63];
     if (!cus) {
-        int dev = 0;
-        DCR_HIP(hipGetDevice(&dev));
         DCR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (cus < 1) cus = 1;
     }
@@ -299,10 +307,10 @@ static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ld
 #define DCR_FIRST_LAUNCH(TR, EV)                                                                                                       \
     do {                                                                                                                              \
         auto kern = k_first_layer_fwd<HM, NR, TR, EV>;                                                                                \
-        static bool raised = false;                                                                                                   \
-        if (!raised) {                                                                                                                \
+        static bool raised[64] = {};                                                                                                  \
+        if (!raised[dev & 63]) {                                                                                                      \
             DCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            raised = true;                                                                                                            \
+            raised[dev & 63] = true;                                                                                                  \
         }                                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * FIRST_WAVES), lds, st, args, w1, b1, w2, offset_dev, upw);                    \
     } while (0)
@@ -310,6 +318,200 @@ static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ld
     else if (train) DCR_FIRST_LAUNCH(true, false);
     else DCR_FIRST_LAUNCH(false, true);
 #undef DCR_FIRST_LAUNCH
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide inputs (round 5): W1 does not fit a CU's LDS — the reference's own datasets (Cora 1,433 x 128, Citeseer 3,703 x 64:
+// utils/hyperparams.py:2-21, models/gcn.py:16-19).  Same MFMA layout, same epilogue; the contraction is split over K:
+//   * workgroup (row group, K chunk): 4 waves, one 16-row unit each; the chunk's KCH = 16384 / H columns of W1 (64 KB) staged
+//     once in LDS (XOR-swizzled as above; columns past in_features are zeros, so in_features need not be a multiple of 16 —
+//     Â·X is padded to one by the caller) and kept while the workgroup walks its row groups (persistent for large N);
+//   * each wave leaves its partial tile [16 rows x H] in the workspace, part[chunk][row][column]; the LAST workgroup of a row
+//     group to arrive (a ticket per row group behind an agent-scope fence) adds the chunks' partials IN CHUNK ORDER —
+//     deterministic whichever workgroup that is — and runs first_epilogue on the sums: bias, pre, Philox keep bits, both
+//     second-layer contractions.  One launch from Â·X to [z_train | z_eval]; the pre-activation is written once.
+// Citeseer shape (2,120 x 3,712 -> 64): 34 row groups x 15 chunks = 510 workgroups of 69 KB LDS (two per CU), 256 MFMAs per wave.
+// Roofline: MFMA f32 for large N; at the citation sizes the kernel is a few microseconds of latency (staging + one chunk + the
+// last arriver's epilogue).
+template <int HM>
+__host__ __device__ constexpr int wide_kch() { return 16384 / (16 * HM); }   // columns of W1 per chunk: 64 KB in LDS
+
+template <int HM, bool TRAIN, bool EVAL>
+__global__ void __launch_bounds__(256) k_first_layer_wide(FirstArgs A, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                          const float *__restrict__ w2, const uint64_t *__restrict__ offset_dev,
+                                                          float *__restrict__ part, unsigned *__restrict__ tickets, int n_chunks,
+                                                          int64_t n_groups, int64_t rows_padded) {
+    constexpr int H = 16 * HM, KCH = wide_kch<HM>(), FS = KCH, HS = H;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int last_sh;
+    float *w1s = lds;               // [H][FS]: this chunk's columns of W1
+    float *w2s = w1s + H * FS;      // [16][HS], rows >= C zero
+    float *b1s = w2s + 16 * HS;     // [H]
+    const int F = A.F;              // the true input width; Â·X has (F + 15) / 16 * 16 columns, the pad zeros
+    const int F16 = (F + 15) / 16 * 16;
+    const int chunk = blockIdx.y, k0 = chunk * KCH;
+    const int kw = F16 - k0 < KCH ? F16 - k0 : KCH;   // columns of this chunk (a multiple of 16)
+    const int n_m = kw / 16;
+    {
+        const bool vec = (F & 3) == 0 && (((uintptr_t)w1) & 15) == 0;
+        for (int e = threadIdx.x; e < H * (KCH / 4); e += 256) {
+            const int r = e / (KCH / 4), c4 = e - r * (KCH / 4), c = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * c4 < kw) {
+                const float *src = w1 + (int64_t)r * F + c;
+                if (vec && c + 3 < F) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    if (c < F) v.x = src[0];
+                    if (c + 1 < F) v.y = src[1];
+                    if (c + 2 < F) v.z = src[2];
+                    if (c + 3 < F) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4 *>(w1s + r * FS + 4 * (c4 ^ (r & 15))) = v;
+        }
+        for (int e = threadIdx.x; e < 16 * (H / 4); e += 256) {
+            const int r = e / (H / 4), c4 = e % (H / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < A.C) {
+                const float *src = w2 + (int64_t)r * H + 4 * c4;
+                v = make_float4(src[0], src[1], src[2], src[3]);
+            }
+            *reinterpret_cast<float4 *>(w2s + r * HS + 4 * (c4 ^ (r & 15))) = v;
+        }
+        for (int e = threadIdx.x; e < H; e += 256) b1s[e] = b1 ? b1[e] : 0.f;
+    }
+    __syncthreads();
+    if (TRAIN && offset_dev) A.offset += *offset_dev;
+
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, gi = g ^ i;
+    const int64_t n_units = (A.n_rows + 15) / 16;
+    const float *w1l = w1s + i * FS;
+    const float *w2l = w2s + i * HS;
+    const float *b1g = b1s + 4 * g;
+    for (int64_t rg = blockIdx.x; rg < n_groups; rg += gridDim.x) {
+        const int64_t unit = rg * 4 + wave;
+        const bool have = unit < n_units;   // (uniform over the wave)
+        if (have) {
+            f32x4 acc[HM];
+#pragma unroll
+            for (int t = 0; t < HM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *ap = first_row_ptr(A, unit, i, g) + k0;
+            auto step = [&](const float4 av, int m) {
+                const float *wm = w1l + 4 * ((4 * m) ^ gi);
+#pragma unroll
+                for (int t = 0; t < HM; ++t) {
+                    const float4 w = *reinterpret_cast<const float4 *>(wm + 16 * t * FS);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, av.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, av.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, av.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, av.w, acc[t], 0, 0, 0);
+                }
+            };
+            // two pieces ahead: the whole chunk of a row is 0.5-1 KB, its latency is the kernel's time at these sizes
+            float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = n_m > 1 ? *reinterpret_cast<const float4 *>(ap + 16) : a0, a2;
+            int m = 0;
+            for (; m + 2 < n_m; ++m) {
+                a2 = *reinterpret_cast<const float4 *>(ap + 16 * (m + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                step(a0, m);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = a1;
+                a1 = a2;
+            }
+            if (m < n_m) step(a0, m);
+            if (m + 1 < n_m) step(a1, m + 1);
+            // the partial tile: register r of acc[t] is column 16t + 4g + r of row i
+            float *dst = part + ((int64_t)chunk * rows_padded + unit * 16 + i) * H + 4 * g;
+#pragma unroll
+            for (int t = 0; t < HM; ++t) *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        }
+        __threadfence();    // (release, agent scope: the tile is visible before the ticket is)
+        __syncthreads();
+        if (threadIdx.x == 0) last_sh = atomicAdd(&tickets[rg], 1u) == (unsigned)(n_chunks - 1);
+        __syncthreads();
+        if (last_sh) {      // uniform over the workgroup: every chunk's tiles of this row group are in memory
+            __threadfence();
+            if (have) {
+                f32x4 acc[HM];
+#pragma unroll
+                for (int t = 0; t < HM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *src = part + (unit * 16 + i) * H + 4 * g;
+                constexpr int CU_ = HM >= 8 ? 2 : 4;   // chunks in flight (HM float4 loads each)
+                int c = 0;
+                for (; c + CU_ <= n_chunks; c += CU_) {
+                    float4 v[CU_][HM];
+#pragma unroll
+                    for (int cc = 0; cc < CU_; ++cc)
+#pragma unroll
+                        for (int t = 0; t < HM; ++t)
+                            v[cc][t] = *reinterpret_cast<const float4 *>(src + (int64_t)(c + cc) * rows_padded * H + 16 * t);
+#pragma unroll
+                    for (int cc = 0; cc < CU_; ++cc)   // (chunk order: the sum does not depend on which workgroup arrived last)
+#pragma unroll
+                        for (int t = 0; t < HM; ++t) {
+                            acc[t][0] += v[cc][t].x; acc[t][1] += v[cc][t].y; acc[t][2] += v[cc][t].z; acc[t][3] += v[cc][t].w;
+                        }
+                }
+                for (; c < n_chunks; ++c)
+#pragma unroll
+                    for (int t = 0; t < HM; ++t) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)c * rows_padded * H + 16 * t);
+                        acc[t][0] += v.x; acc[t][1] += v.y; acc[t][2] += v.z; acc[t][3] += v.w;
+                    }
+                first_epilogue<HM, TRAIN, EVAL>(A, unit, acc, w2l, b1g, i, g);
+            }
+            if (threadIdx.x == 0) tickets[rg] = 0u;   // (for the next call: the tickets are all-zero between launches)
+        }
+        __syncthreads();    // last_sh is rewritten by the next row group
+    }
+}
+
+// shapes the K-chunked kernel takes and its workspace: n_chunks x (rows padded to 16) x H floats of partial tiles + a ticket per
+// group of 64 rows (as floats: the caller sees one buffer; zero before the first use, left zero by every launch)
+static int64_t wide_chunks(int F, int H) { return ((F + 15) / 16 * 16 + 16384 / H - 1) / (16384 / H); }
+static int64_t wide_groups(int64_t n_rows) { return ((n_rows + 15) / 16 + 3) / 4; }
+static int64_t wide_ws_floats(int64_t n_rows, int F, int H) {
+    return wide_chunks(F, H) * ((n_rows + 15) / 16 * 16) * H + wide_groups(n_rows);
+}
+
+template <int HM>
+static int launch_first_layer_wide(bool train, bool eval, const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2,
+                                   float *pre, float *z_train, float *z_eval, int64_t ldz, unsigned long long *bits, int64_t n_rows, int F,
+                                   int C, float scale, uint32_t threshold, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                                   float *ws, hipStream_t st) {
+    constexpr int H = 16 * HM;
+    int dev = 0, cus = 0;
+    DCR_HIP(hipGetDevice(&dev));
+    DCR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < 1) cus = 1;
+    const int64_t n_chunks = wide_chunks(F, H), n_groups = wide_groups(n_rows), rows_padded = (n_rows + 15) / 16 * 16;
+    if (n_chunks > 65535) DCR_FAIL(DCR_ECAPACITY, "first_layer_fwd: input too wide");
+    // two workgroups per CU resident; beyond that a workgroup keeps its chunk of W1 and walks row groups
+    int64_t gx = (2 * (int64_t)cus + n_chunks - 1) / n_chunks;
+    if (gx > n_groups) gx = n_groups;
+    if (gx < 1) gx = 1;
+    const size_t lds = sizeof(float) * ((size_t)H * wide_kch<HM>() + 16 * (size_t)H + H);
+    float *part = ws;
+    unsigned *tickets = reinterpret_cast<unsigned *>(ws + n_chunks * rows_padded * H);
+    FirstArgs args{ax, ldx, pre, z_train, z_eval, ldz, bits, n_rows, F, C, scale, threshold, seed, offset};
+#define DCR_WIDE_LAUNCH(TR, EV)                                                                                                        \
+    do {                                                                                                                              \
+        auto kern = k_first_layer_wide<HM, TR, EV>;                                                                                   \
+        static bool raised[64] = {};   /* per device (a process may drive several) */                                                \
+        if (!raised[dev & 63]) {                                                                                                      \
+            DCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            raised[dev & 63] = true;                                                                                                  \
+        }                                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_chunks), dim3(256), lds, st, args, w1, b1, w2, offset_dev, part, tickets, \
+                           (int)n_chunks, n_groups, rows_padded);                                                                     \
+    } while (0)
+    if (train && eval) DCR_WIDE_LAUNCH(true, true);
+    else if (train) DCR_WIDE_LAUNCH(true, false);
+    else DCR_WIDE_LAUNCH(false, true);
+#undef DCR_WIDE_LAUNCH
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
@@ -636,15 +838,20 @@ __global__ void __launch_bounds__(64 * BWD_WAVES, BWD_WGS) k_first_layer_bwd(con
     }
 }
 
-static int64_t first_layer_bwd_blocks(int64_t n_rows) {
-    static int cus = 0;
+// workgroups along the rows: one per CU in total (the grid's second dimension tiles the input width by 256 columns; every
+// workgroup leaves a partial dW1 tile that the slab reduction reads back, so a wide, short problem — Citeseer: 15 column blocks,
+// 67 stages — takes few, longer row ranges)
+static int64_t first_layer_bwd_blocks(int64_t n_rows, int F16) {
+    static int cus_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int &cus = cus_dev[dev & 63];
     if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     }
     const int64_t n_stages = ((n_rows + 15) / 16 + BWD_UR - 1) / BWD_UR;
-    int64_t blocks = (int64_t)cus * BWD_WGS;
+    const int64_t fblocks = (F16 + 255) / 256;
+    int64_t blocks = ((int64_t)cus * BWD_WGS + fblocks - 1) / fblocks;
     if (blocks > n_stages) blocks = n_stages;
     return blocks < 1 ? 1 : blocks;
 }
@@ -653,57 +860,92 @@ static int64_t first_layer_bwd_blocks(int64_t n_rows) {
 
 using namespace dcr;
 
+static bool first_layer_resident(int in_features, int hidden) {   // W1 whole in one CU's LDS (k_first_layer_fwd)
+    return in_features >= 16 && (in_features % 16) == 0 && first_layer_lds_bytes(in_features, hidden) <= 160 * 1024;
+}
+
 extern "C" int dcr_first_layer_fits(int in_features, int hidden, int classes) {
-    if (in_features < 16 || (in_features % 16) != 0 || (hidden != 64 && hidden != 128) || classes < 1 || classes > 16) return 0;
-    return first_layer_lds_bytes(in_features, hidden) <= 160 * 1024 ? 1 : 0;
+    if (in_features < 1 || (hidden != 64 && hidden != 128) || classes < 1 || classes > 16) return 0;
+    return 1;   // (W1 resident in LDS where it fits, K-chunked otherwise: dcr_first_layer_fwd_workspace says which)
+}
+
+extern "C" int dcr_first_layer_fwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats) {
+    if (!floats || n_rows < 0 || in_features < 1 || (hidden != 64 && hidden != 128)) DCR_FAIL(DCR_EINVAL, "bad first_layer_fwd_workspace arguments");
+    *floats = first_layer_resident(in_features, hidden) ? 0 : dcr::wide_ws_floats(n_rows, in_features, hidden);
+    return DCR_OK;
+}
+
+extern "C" int dcr_first_layer_fwd_ws_f32_dev(const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2, float *pre,
+                                              float *z_train, float *z_eval, int64_t ldz, uint64_t *bits, int64_t n_rows, int in_features,
+                                              int hidden, int classes, double p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                                              float *ws, int64_t ws_floats, void *hip_stream) {
+    const bool train = z_train != nullptr, eval = z_eval != nullptr;
+    const int f16 = (in_features + 15) / 16 * 16;
+    if (!ax || !w1 || !w2 || n_rows < 0 || (!train && !eval) || ldx < f16) DCR_FAIL(DCR_EINVAL, "bad first_layer_fwd arguments (ldx >= in_features rounded up to 16)");
+    if (train && (!bits || !pre || !(p >= 0.0 && p < 1.0)))
+        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: the training output needs bits, pre (the backward pass reads both) and 0 <= p < 1");
+    if (!dcr_first_layer_fits(in_features, hidden, classes) || ldz < classes)
+        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: hidden 64 or 128, at most 16 classes, ldz >= classes (other shapes take the GEMM library and "
+                             "dcr_act_linear_fwd_f32_dev)");
+    if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)w2 & 15) || (pre && ((uintptr_t)pre & 15)))
+        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: 16-byte aligned tensors and row stride expected");
+    if (n_rows == 0) return DCR_OK;
+    const uint32_t threshold = dcr::dropout_threshold16(p);
+    const float scale = (float)(1.0 / (1.0 - p));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (first_layer_resident(in_features, hidden)) {
+        if ((uintptr_t)w1 & 15) DCR_FAIL(DCR_EINVAL, "first_layer_fwd: 16-byte aligned W1 expected");
+        if (hidden == 128)
+            return launch_first_layer<8, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
+                                                       in_features, classes, scale, threshold, seed, offset, offset_dev, st);
+        return launch_first_layer<4, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
+                                                   in_features, classes, scale, threshold, seed, offset, offset_dev, st);
+    }
+    if (!ws || ((uintptr_t)ws & 15) || ws_floats < dcr::wide_ws_floats(n_rows, in_features, hidden))
+        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: this width takes the K-chunked kernel, which needs dcr_first_layer_fwd_workspace floats (16-byte "
+                             "aligned; the trailing tickets zero before the first use — every launch leaves them zero)");
+    if (hidden == 128)
+        return launch_first_layer_wide<8>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, in_features,
+                                          classes, scale, threshold, seed, offset, offset_dev, ws, st);
+    return launch_first_layer_wide<4>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, in_features,
+                                      classes, scale, threshold, seed, offset, offset_dev, ws, st);
 }
 
 extern "C" int dcr_first_layer_fwd_f32_dev(const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2, float *pre,
                                            float *z_train, float *z_eval, int64_t ldz, uint64_t *bits, int64_t n_rows, int in_features,
                                            int hidden, int classes, double p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                                            void *hip_stream) {
-    const bool train = z_train != nullptr, eval = z_eval != nullptr;
-    if (!ax || !w1 || !w2 || n_rows < 0 || (!train && !eval) || ldx < in_features) DCR_FAIL(DCR_EINVAL, "bad first_layer_fwd arguments");
-    if (train && (!bits || !pre || !(p >= 0.0 && p < 1.0)))
-        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: the training output needs bits, pre (the backward pass reads both) and 0 <= p < 1");
-    if (!dcr_first_layer_fits(in_features, hidden, classes) || ldz < classes)
-        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: in_features a multiple of 16 with W1 fitting the LDS (dcr_first_layer_fits), hidden 64 or 128, "
-                             "at most 16 classes, ldz >= classes (other shapes take the GEMM library and dcr_act_linear_fwd_f32_dev)");
-    if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || (pre && ((uintptr_t)pre & 15)))
-        DCR_FAIL(DCR_EINVAL, "first_layer_fwd: 16-byte aligned tensors and row stride expected");
-    if (n_rows == 0) return DCR_OK;
-    const uint32_t threshold = dcr::dropout_threshold16(p);
-    const float scale = (float)(1.0 / (1.0 - p));
-    hipStream_t st = (hipStream_t)hip_stream;
-    if (hidden == 128)
-        return launch_first_layer<8, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
-                                                   in_features, classes, scale, threshold, seed, offset, offset_dev, st);
-    return launch_first_layer<4, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
-                                               in_features, classes, scale, threshold, seed, offset, offset_dev, st);
+    // (the entry point of round 4: shapes whose W1 stays resident in LDS need no workspace)
+    return dcr_first_layer_fwd_ws_f32_dev(ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, bits, n_rows, in_features, hidden, classes, p, seed, offset,
+                                          offset_dev, nullptr, 0, hip_stream);
 }
 
 extern "C" int dcr_first_layer_bwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats) {
-    if (!floats || n_rows < 0 || in_features < 16 || (in_features % 16) != 0 || (hidden != 64 && hidden != 128))
+    if (!floats || n_rows < 0 || in_features < 1 || (hidden != 64 && hidden != 128))
         DCR_FAIL(DCR_EINVAL, "bad first_layer_bwd_workspace arguments");
-    *floats = first_layer_bwd_blocks(n_rows) * ((int64_t)hidden * in_features + 17 * hidden);
+    const int f16 = (in_features + 15) / 16 * 16;
+    *floats = first_layer_bwd_blocks(n_rows, f16) * ((int64_t)hidden * f16 + 17 * hidden);
     return DCR_OK;
 }
 
 extern "C" int dcr_first_layer_bwd_f32_dev(const float *dz, const float *w2, const uint64_t *bits, const float *pre, const float *ax, int64_t ldx,
                                            float *dw1, float *db1, float *dw2, float *ws, int64_t ws_floats, int64_t n_rows, int in_features,
                                            int hidden, int classes, double p, void *hip_stream) {
-    if (!dz || !w2 || !bits || !pre || !ax || !dw1 || !db1 || !dw2 || !ws || n_rows < 0 || ldx < in_features || !(p >= 0.0 && p < 1.0))
-        DCR_FAIL(DCR_EINVAL, "bad first_layer_bwd arguments");
-    if (in_features < 16 || (in_features % 16) != 0 || (hidden != 64 && hidden != 128) || classes < 1 || classes > 16)
-        DCR_FAIL(DCR_EINVAL, "first_layer_bwd: in_features a multiple of 16, hidden 64 or 128, at most 16 classes");
+    // in_features: the true width of W1 / dW1; Â·X holds it rounded up to a multiple of 16 columns (the pad finite: its products
+    // land in columns of the partial tiles that are never read)
+    const int f16 = (in_features + 15) / 16 * 16;
+    if (!dz || !w2 || !bits || !pre || !ax || !dw1 || !db1 || !dw2 || !ws || n_rows < 0 || ldx < f16 || !(p >= 0.0 && p < 1.0))
+        DCR_FAIL(DCR_EINVAL, "bad first_layer_bwd arguments (ldx >= in_features rounded up to 16)");
+    if (in_features < 1 || (hidden != 64 && hidden != 128) || classes < 1 || classes > 16)
+        DCR_FAIL(DCR_EINVAL, "first_layer_bwd: hidden 64 or 128, at most 16 classes");
     if (((uintptr_t)ax & 15) || (ldx & 3) || ((uintptr_t)ws & 15) || ((uintptr_t)dz & 15) || ((uintptr_t)pre & 15) || ((uintptr_t)bits & 15))
         DCR_FAIL(DCR_EINVAL, "first_layer_bwd: 16-byte aligned tensors and row stride expected (the stage copies move 16-byte pieces)");
-    const int64_t blocks = first_layer_bwd_blocks(n_rows);
-    const int64_t per1 = (int64_t)hidden * in_features;
+    const int64_t blocks = first_layer_bwd_blocks(n_rows, f16);
+    const int64_t per1 = (int64_t)hidden * f16;
     if (ws_floats < blocks * (per1 + 17 * hidden)) DCR_FAIL(DCR_EINVAL, "first_layer_bwd: workspace too small (dcr_first_layer_bwd_workspace)");
     hipStream_t st = (hipStream_t)hip_stream;
     if (n_rows == 0) {
-        DCR_HIP(hipMemsetAsync(dw1, 0, sizeof(float) * per1, st));
+        DCR_HIP(hipMemsetAsync(dw1, 0, sizeof(float) * (size_t)hidden * in_features, st));
         DCR_HIP(hipMemsetAsync(db1, 0, sizeof(float) * hidden, st));
         DCR_HIP(hipMemsetAsync(dw2, 0, sizeof(float) * hidden * classes, st));
         return DCR_OK;
@@ -712,13 +954,14 @@ extern "C" int dcr_first_layer_bwd_f32_dev(const float *dz, const float *w2, con
     const int64_t upw = (n_stages + blocks - 1) / blocks;
     float *part1 = ws, *part2 = ws + blocks * per1;
     const float scale = (float)(1.0 / (1.0 - p));
-    const dim3 grid((unsigned)blocks, (unsigned)((in_features + 255) / 256));
+    if ((f16 + 255) / 256 > 65535) DCR_FAIL(DCR_ECAPACITY, "first_layer_bwd: input too wide");
+    const dim3 grid((unsigned)blocks, (unsigned)((f16 + 255) / 256));
     if (hidden == 128)
         hipLaunchKernelGGL((dcr::k_first_layer_bwd<8>), grid, dim3(64 * dcr::BWD_WAVES), 0, st, dz, w2, (const unsigned long long *)bits, pre, ax, ldx, n_rows,
-                           in_features, classes, scale, part1, part2, upw);
+                           f16, classes, scale, part1, part2, upw);
     else
         hipLaunchKernelGGL((dcr::k_first_layer_bwd<4>), grid, dim3(64 * dcr::BWD_WAVES), 0, st, dz, w2, (const unsigned long long *)bits, pre, ax, ldx, n_rows,
-                           in_features, classes, scale, part1, part2, upw);
+                           f16, classes, scale, part1, part2, upw);
 #ifdef DCR_BWD_PROF
     {
         unsigned long long h[8];
@@ -730,7 +973,8 @@ extern "C" int dcr_first_layer_bwd_f32_dev(const float *dz, const float *w2, con
         DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dcr::bwd_prof), z, sizeof(z)));
     }
 #endif
-    dcr::launch_slab_reduce(part1, dw1, per1, in_features, in_features, (int)blocks, st);
+    // (the partial tiles are f16 columns wide; dW1 takes the true width)
+    dcr::launch_slab_reduce_cols(part1, dw1, per1, f16, in_features, in_features, (int)blocks, st);
     dcr::launch_parts_finish(part2, blocks, 17 * hidden, hidden, hidden * (1 + classes), db1, dw2, st);
     DCR_HIP(hipGetLastError());
     return DCR_OK;

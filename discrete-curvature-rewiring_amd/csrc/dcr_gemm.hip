@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) k_atb_partial(const float *__r
 // zg, zg + 4, ... (four loads in flight), the four group sums are then added in group order: deterministic, and four
 // times the memory-level parallelism of one thread per output.
 __global__ void __launch_bounds__(256) k_atb_reduce(const float *__restrict__ part, float *__restrict__ C, int64_t mn,
-                                                     int N, int64_t ldc, int splits) {
+                                                     int N, int64_t ldc, int splits, int ncols) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_atb_reduce(const float *__restrict__ pa
     }
     red[zg][e] = s;
     __syncthreads();
-    if (zg == 0 && i < mn) C[(i / N) * ldc + (i % N)] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (zg == 0 && i < mn && (int)(i % N) < ncols) C[(i / N) * ldc + (i % N)] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
 struct AtbPlan {
@@ -143,7 +143,11 @@ static AtbPlan atb_plan(int64_t K, int64_t M, int64_t N) {
 // C[i / N][i % N] = sum over the splits of part[z][i], in slab order (k_atb_reduce) — for the kernels of other files that leave
 // K-slab partial tiles (csrc/dcr_gcn_first.hip)
 void launch_slab_reduce(const float *part, float *C, int64_t mn, int N, int64_t ldc, int splits, hipStream_t st) {
-    hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, st, part, C, mn, N, ldc, splits);
+    hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, st, part, C, mn, N, ldc, splits, N);
+}
+// the same, writing only the first ncols columns of every row of the N-column tiles (padded widths: csrc/dcr_gcn_first.hip)
+void launch_slab_reduce_cols(const float *part, float *C, int64_t mn, int N, int ncols, int64_t ldc, int splits, hipStream_t st) {
+    hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, st, part, C, mn, N, ldc, splits, ncols);
 }
 
 }  // namespace dcr
@@ -178,7 +182,7 @@ extern "C" int dcr_atb_f32_dev(const float *A, const float *B, float *C, int64_t
                            p.k_chunk);
     const int64_t mn = M * N;
     hipLaunchKernelGGL(k_atb_reduce, dim3((unsigned)((mn + 63) / 64)), dim3(256), 0, st, workspace, C, mn, (int)N, ldc,
-                       p.splits);
+                       p.splits, (int)N);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }

@@ -340,6 +340,7 @@ int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st = nullpt
 int launch_argext_both(dcr_graph *g, hipStream_t st = nullptr);
 // reductions of per-workgroup partial results shared by the GCN kernels (csrc/dcr_gemm.hip, csrc/dcr_gcn.hip)
 void launch_slab_reduce(const float *part, float *C, int64_t mn, int N, int64_t ldc, int splits, hipStream_t st);
+void launch_slab_reduce_cols(const float *part, float *C, int64_t mn, int N, int ncols, int64_t ldc, int splits, hipStream_t st);
 void launch_parts_finish(const float *part, int64_t n_parts, int stride, int split, int columns, float *out0, float *out1, hipStream_t st);
 int process_giant_edges(dcr_graph *g, int curv_type);  // dcr_bfc_giant.hip; syncs once
 int process_hub_edges(dcr_graph *g, int curv_type, bool incremental);  // dcr_bfc_giant.hip; syncs once

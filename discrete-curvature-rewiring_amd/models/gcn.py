@@ -552,9 +552,17 @@ class _FirstLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ax, w1, b1, w2, p, want_train, want_eval):
         from dcr import _lib
-        ax, w1, w2 = ax.contiguous(), w1.contiguous(), w2.contiguous()
-        n, feats = ax.shape
-        hidden, classes = w1.shape[0], w2.shape[0]
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        # ax: Â·X, [n, feats] or (round 5) [n, feats rounded up to 16] with zero pad columns — what the K-chunked kernel for
+        # input widths like Cora's 1,433 and Citeseer's 3,703 reads (GCNConv.propagated_input(..., pad16=True))
+        if ax.stride(1) != 1 or ax.stride(0) % 4:
+            ax = ax.contiguous()
+        n = ax.shape[0]
+        hidden, feats, classes = w1.shape[0], w1.shape[1], w2.shape[0]
+        f16 = (feats + 15) // 16 * 16
+        if ax.shape[1] < f16:                      # (a caller that did not pad: pad here, once per call)
+            ax = torch.nn.functional.pad(ax, (0, f16 - ax.shape[1]))
+        ldx = ax.stride(0)
         stream = torch.cuda.current_stream(ax.device).cuda_stream
         if want_train and want_eval:
             both = torch.empty((n, 2 * classes), dtype=ax.dtype, device=ax.device)
@@ -570,15 +578,17 @@ class _FirstLayerFn(torch.autograd.Function):
             bits = torch.empty(max(words.value, 1), dtype=torch.int64, device=ax.device)
             ctr = _dropout_counter(ax.device)
             pre = torch.empty((n, hidden), dtype=ax.dtype, device=ax.device)
-        _lib.check(_lib.lib().dcr_first_layer_fwd_f32_dev(
-            ax.data_ptr(), feats, w1.data_ptr(), None if b1 is None else b1.data_ptr(), w2.data_ptr(),
+        ws = _first_layer_workspace(ax.device, stream, n, feats, hidden)
+        _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(
+            ax.data_ptr(), ldx, w1.data_ptr(), None if b1 is None else b1.data_ptr(), w2.data_ptr(),
             None if pre is None else pre.data_ptr(), z_tr.data_ptr() if want_train else None,
             z_ev.data_ptr() if want_eval else None, ldz, bits.data_ptr() if want_train else None, n, feats, hidden, classes,
-            float(p), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None, ctypes.c_void_p(stream)))
+            float(p), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None,
+            None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), ctypes.c_void_p(stream)))
         if want_train:
             ctr.add_(1)
             ctx.save_for_backward(ax, w2)
-            ctx.pre, ctx.bits, ctx.p, ctx.has_bias = pre, bits, float(p), b1 is not None
+            ctx.pre, ctx.bits, ctx.p, ctx.has_bias, ctx.feats = pre, bits, float(p), b1 is not None, feats
         if want_eval:
             ctx.mark_non_differentiable(z_ev)
         return z_tr, z_ev
@@ -592,10 +602,10 @@ class _FirstLayerFn(torch.autograd.Function):
         stream = torch.cuda.current_stream(g_tr.device).cuda_stream
         n, hidden = pre.shape
         aligned = all(t.data_ptr() % 16 == 0 for t in (ax, g_tr, pre, ctx.bits))   # (the kernel's stage copies move 16-byte pieces)
-        if os.environ.get('DCR_FIRST_BWD_FUSED', '1') != '0' and ax.is_contiguous() and aligned:
+        feats = ctx.feats
+        if os.environ.get('DCR_FIRST_BWD_FUSED', '1') != '0' and aligned:
             # one kernel (dcr_first_layer_bwd_f32_dev): the gradient of the pre-activation stays in registers between the
             # contraction with W2 that forms it and the contraction with Â·X that consumes it
-            feats = ax.shape[1]
             gw1 = torch.empty((hidden, feats), dtype=torch.float32, device=pre.device)
             gw2 = torch.empty_like(w2)
             gb1 = torch.empty(hidden, dtype=torch.float32, device=pre.device)
@@ -603,11 +613,13 @@ class _FirstLayerFn(torch.autograd.Function):
             _lib.check(_lib.lib().dcr_first_layer_bwd_workspace(n, feats, hidden, ctypes.byref(need)))
             ws = torch.empty(max(need.value, 1), dtype=torch.float32, device=pre.device)
             _lib.check(_lib.lib().dcr_first_layer_bwd_f32_dev(g_tr.data_ptr(), w2.data_ptr(), ctx.bits.data_ptr(), pre.data_ptr(),
-                                                              ax.data_ptr(), feats, gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(),
+                                                              ax.data_ptr(), ax.stride(0), gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(),
                                                               ws.data_ptr(), need.value, n, feats, hidden, w2.shape[0], ctx.p,
                                                               ctypes.c_void_p(stream)))
             return (None, gw1 if ctx.needs_input_grad[1] else None, gb1 if (ctx.has_bias and ctx.needs_input_grad[2]) else None,
                     gw2 if ctx.needs_input_grad[3] else None, None, None, None)
+        if ax.shape[1] != feats:
+            ax = ax[:, :feats].contiguous()      # (the separate kernels take the unpadded matrix)
         gx = torch.empty_like(pre)
         gw2 = torch.empty_like(w2)
         colsum = torch.empty(hidden, dtype=torch.float32, device=pre.device)
@@ -625,15 +637,38 @@ class _FirstLayerFn(torch.autograd.Function):
         return None, gw1, gb1, (gw2 if ctx.needs_input_grad[3] else None), None, None, None
 
 
-def first_layer_fused_ok(ax, act_fn, first, lin2):
-    """Whether dcr_first_layer_fwd_f32_dev takes this shape: ReLU, fp32 on the MI355X, the input width a multiple of 16
-    with W1 fitting the LDS of a CU, hidden width 64 / 128, at most 16 classes.  ``DCR_FIRST_FUSED=0`` switches it off."""
-    if not (_AGG_BACKEND == 'hip' and ax.is_cuda and ax.dtype == torch.float32 and ax.dim() == 2 and isinstance(act_fn, ReLU)):
+_FIRST_WS = {}
+
+
+def _first_layer_workspace(device, stream, n, feats, hidden):
+    """Workspace of the K-chunked first-layer kernel (None for shapes whose W1 stays resident in LDS): partial tiles + one
+    ticket per 64 rows.  The tickets must be zero before the first launch and every launch leaves them zero, so the buffer is
+    allocated (zeroed) once per (device, stream, shape) and kept: no fill launch per call, and the captured epoch replays on a
+    buffer that outlives the capture."""
+    from dcr import _lib
+    need = ctypes.c_int64()
+    _lib.check(_lib.lib().dcr_first_layer_fwd_workspace(n, feats, hidden, ctypes.byref(need)))
+    if need.value == 0:
+        return None
+    key = (str(device), int(stream), int(n), int(feats), int(hidden))
+    ws = _FIRST_WS.get(key)
+    if ws is None:
+        if len(_FIRST_WS) >= 8:
+            _FIRST_WS.pop(next(iter(_FIRST_WS)))
+        ws = _FIRST_WS[key] = torch.zeros(need.value, dtype=torch.float32, device=device)
+    return ws
+
+
+def first_layer_fused_ok(x, act_fn, first, lin2):
+    """Whether the one-kernel first layer (dcr_first_layer_fwd_ws_f32_dev) takes this model: ReLU, fp32 on the MI355X, hidden
+    width 64 / 128, at most 16 classes; any input width since round 5 (W1 resident in LDS where it fits, streamed through it
+    in K chunks otherwise: Cora 1,433, Citeseer 3,703).  ``DCR_FIRST_FUSED=0`` switches it off."""
+    if not (_AGG_BACKEND == 'hip' and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and isinstance(act_fn, ReLU)):
         return False
-    if os.environ.get('DCR_FIRST_FUSED', '1') == '0' or ax.data_ptr() % 16:
+    if os.environ.get('DCR_FIRST_FUSED', '1') == '0':
         return False
     from dcr import _lib
-    return bool(_lib.lib().dcr_first_layer_fits(int(ax.shape[1]), int(first.lin.weight.shape[0]), int(lin2.weight.shape[0])))
+    return bool(_lib.lib().dcr_first_layer_fits(int(first.lin.weight.shape[1]), int(first.lin.weight.shape[0]), int(lin2.weight.shape[0])))
 
 
 class _Linear(torch.nn.Module):
@@ -686,14 +721,19 @@ class GCNConv(torch.nn.Module):
                 self.bias.zero_()
         self.invalidate()
 
-    def propagated_input(self, x, csr):
+    def propagated_input(self, x, csr, pad16=False):
         """Â·x, cached while x (same storage, same version) and the graph stay the same.  The cache holds a reference
         to the tensor it is keyed on: its storage cannot be freed and handed to another tensor while the entry lives,
-        so an equal (address, version, shape) key always means the same values."""
-        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), str(x.device), self._cache_key)
+        so an equal (address, version, shape) key always means the same values.  ``pad16``: the width rounded up to a
+        multiple of 16 with zero columns (what the one-kernel first layer reads: 16-column MFMA steps, 16-byte pieces)."""
+        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), str(x.device), self._cache_key, bool(pad16))
         if key != self._ax_key:
             with torch.no_grad():
-                self._ax = spmm(csr.rowptr, csr.col, csr.val, x.contiguous(), csr.n_rows)
+                xc = x.contiguous()
+                pad = (-xc.shape[1]) % 16 if pad16 else 0
+                if pad:
+                    xc = torch.nn.functional.pad(xc, (0, pad))
+                self._ax = spmm(csr.rowptr, csr.col, csr.val, xc, csr.n_rows)
             self._ax_key = key
             self._ax_ref = x
         return self._ax
@@ -771,10 +811,10 @@ class GCN(torch.nn.Module):
         grads = torch.is_grad_enabled() and any(q.requires_grad for q in list(first.parameters()) + [second.lin.weight])
         if want_eval and not want_train and grads:
             return None                                   # evaluation mode WITH a gradient: the stock modules
-        csr = first.norm_csr(data.edge_index, data.edge_attr, x.shape[0])
-        ax = first.propagated_input(x, csr)
-        if not first_layer_fused_ok(ax, self.act_fn, first, second.lin):
+        if not first_layer_fused_ok(x, self.act_fn, first, second.lin):
             return None
+        csr = first.norm_csr(data.edge_index, data.edge_attr, x.shape[0])
+        ax = first.propagated_input(x, csr, pad16=True)
         if want_train:
             return _FirstLayerFn.apply(ax, first.lin.weight, first.bias, second.lin.weight, p, True, want_eval)
         with torch.no_grad():

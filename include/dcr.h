@@ -274,9 +274,24 @@ int dcr_act_linear_bwd_colsum_f32_dev(const float *dz_dev, const float *w_dev, c
  *     z_train = dropout_p(relu(pre)) · W2ᵀ,  z_eval = relu(pre) · W2ᵀ   [n_rows x classes, row stride ldz]; either may be NULL
  * Keep bits, Philox stream and the order of operations of the second contraction are those of dcr_act_linear_fwd_f32_dev on
  * the same pre, so dcr_act_linear_bwd_fused_f32_dev(dz, W2, bits, pre, ...) is its backward.  b1_dev may be NULL.  Shapes:
- * dcr_first_layer_fits(in_features, hidden, classes) != 0 (in_features a multiple of 16 with W1 fitting one CU's LDS, hidden 64 or
- * 128, classes <= 16); others return DCR_EINVAL — the caller keeps the GEMM library + dcr_act_linear_fwd_f32_dev for them. */
+ * dcr_first_layer_fits(in_features, hidden, classes) != 0: hidden 64 or 128, classes <= 16, any input width (round 5).  Two
+ * kernels behind one entry point:
+ *   - W1 resident in one CU's LDS (in_features a multiple of 16, hidden x in_features floats + W2 + b1 within 160 KB: the
+ *     synthetic bench shape 256 -> 128): dcr_first_layer_fwd_workspace gives 0, ws_dev may be NULL;
+ *   - K-chunked (everything else, the reference's own datasets among them — Cora 1,433 -> 128, Citeseer 3,703 -> 64,
+ *     utils/hyperparams.py:2-21): W1 streamed through LDS in chunks of 16384 / hidden columns, a workgroup per (64 rows, chunk),
+ *     partial tiles in ws_dev, the last workgroup of a row group to arrive adds them in chunk order and runs the epilogue.
+ *     ws_dev: dcr_first_layer_fwd_workspace floats, 16-byte aligned; its trailing (n_rows / 64 rounded up) words are tickets:
+ *     ZERO before the first use, left zero by every launch (one launch at a time per workspace).
+ * ax_dev: n_rows x ldx, ldx >= in_features rounded up to a multiple of 16, the pad columns zero (W1's pad is zero inside the
+ * kernel; 0 x NaN would still be NaN).  w1_dev: hidden x in_features, row stride in_features (any alignment for the K-chunked
+ * kernel).  dcr_first_layer_fwd_f32_dev is the round-4 entry point: the same call without a workspace (resident shapes only). */
 int dcr_first_layer_fits(int in_features, int hidden, int classes);
+int dcr_first_layer_fwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats);
+int dcr_first_layer_fwd_ws_f32_dev(const float *ax_dev, int64_t ldx, const float *w1_dev, const float *b1_dev, const float *w2_dev,
+                                   float *pre_dev, float *z_train_dev, float *z_eval_dev, int64_t ldz, uint64_t *bits_dev, int64_t n_rows,
+                                   int in_features, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
+                                   const uint64_t *offset_dev, float *ws_dev, int64_t ws_floats, void *hip_stream);
 int dcr_first_layer_fwd_f32_dev(const float *ax_dev, int64_t ldx, const float *w1_dev, const float *b1_dev, const float *w2_dev,
                                 float *pre_dev, float *z_train_dev, float *z_eval_dev, int64_t ldz, uint64_t *bits_dev, int64_t n_rows,
                                 int in_features, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
@@ -286,8 +301,10 @@ int dcr_first_layer_fwd_f32_dev(const float *ax_dev, int64_t ldx, const float *w
  * two layers' dense parts): from dz = d loss / d z_train [n_rows x classes, contiguous] to
  *     dw1 [hidden x in_features] = dpreᵀ · ax,  db1 [hidden] = column sums of dpre,  dw2 [classes x hidden] = dzᵀ · dropout(relu(pre)),
  * with dpre = keep ? (dz · W2) / (1 - p) : 0 never written to memory (the first layer's input needs no gradient).  bits, pre:
- * as dcr_first_layer_fwd_f32_dev left them.  ws_dev: dcr_first_layer_bwd_workspace floats.  in_features a multiple of 16, hidden
- * 64 or 128, classes <= 16.  Partial results are added in a fixed order: deterministic. */
+ * as dcr_first_layer_fwd_f32_dev left them.  ws_dev: dcr_first_layer_bwd_workspace floats.  Any in_features (round 5: the true
+ * width of W1 / dW1, row stride in_features; ax_dev as in the forward call, ldx >= in_features rounded up to 16), hidden 64 or
+ * 128, classes <= 16.  The input width is tiled by 256 columns (grid y), the rows by about one workgroup per CU in total.
+ * Partial results are added in a fixed order: deterministic. */
 int dcr_first_layer_bwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats);
 int dcr_first_layer_bwd_f32_dev(const float *dz_dev, const float *w2_dev, const uint64_t *bits_dev, const float *pre_dev,
                                 const float *ax_dev, int64_t ldx, float *dw1_dev, float *db1_dev, float *dw2_dev, float *ws_dev,

@@ -102,6 +102,122 @@ def _s1m_inputs(dev):
     return torch.from_numpy(ei).to(dev), n, x
 
 
+def _training_step_against_fp64(ei, n, x, n_cls, hidden, p, frac_train, tol=1e-5):
+    """One training step (experiment/training_loop.py:48-54: model.train(), NLL on the training rows, backward) through the
+    one-kernel first layer + the row-selected aggregation: logits of the training rows and dW1, db1, dW2, db2 against a float64
+    evaluation from the raw edge list, <= tol of the largest reference entry.  The float64 side uses the product's OWN
+    activation pattern (sign of the float32 pre-activation AND the keep mask of the same dropout call): a pre-activation within
+    float32 rounding of zero would otherwise sit on the other side of the ReLU in float64, and one such row moves an entry of
+    dW1 by ~1e-3 of its size (a few dozen of the 128 M elements at S1M do)."""
+    import ctypes
+    from dcr import _lib
+    from dcr.data import Data, Dataset
+    from models import gcn
+    from models.gcn import GCN, _ReluDropoutFn
+    dev = x.device
+    g = torch.Generator(device=dev).manual_seed(4)
+    y = torch.randint(0, n_cls, (n,), device=dev, generator=g)
+    train_rows = torch.nonzero(torch.rand(n, device=dev, generator=g) < frac_train).flatten()
+    data = Data(x=x, edge_index=ei, y=y, num_nodes=n)
+    torch.manual_seed(2)
+    model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=p).to(dev)
+    with torch.no_grad():
+        model.layers[0].bias.uniform_(-0.1, 0.1)
+    model.train()
+    assert gcn.first_layer_fused_ok(x, model.act_fn, model.layers[0], model.layers[1].lin)
+    calls = {'n': 0}
+    real = gcn._FirstLayerFn.apply
+
+    def counting(*a):
+        calls['n'] += 1
+        return real(*a)
+    gcn._FirstLayerFn.apply = staticmethod(counting)
+    try:
+        ctr = gcn._dropout_counter(dev)
+        c0 = ctr.clone()
+        logp = model(data, rows=train_rows)                     # (the last aggregation at the rows the loss reads: the epoch's route)
+    finally:
+        gcn._FirstLayerFn.apply = real
+    assert calls['n'] == 1                                      # the first layer went through the one kernel
+    torch.nn.functional.nll_loss(logp, y[train_rows]).backward()
+    got = {name: q.grad.double() for name, q in model.named_parameters()}
+    # the product's activation pattern: the float32 pre-activation from the same kernel on the same inputs, the keep mask of
+    # dropout call c0 from the stand-alone kernel (same Philox counters and bit layout: tests/test_gcn.py pins that)
+    ax = model.layers[0]._ax
+    feats = x.shape[1]
+    w1, b1, w2 = model.layers[0].lin.weight.detach(), model.layers[0].bias.detach(), model.layers[1].lin.weight.detach()
+    words = ctypes.c_int64()
+    _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n * hidden, ctypes.byref(words)))
+    bits = torch.zeros(words.value, dtype=torch.int64, device=dev)
+    pre = torch.empty(n, hidden, device=dev)
+    z = torch.empty(n, n_cls, device=dev)
+    ctr.copy_(c0)
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    ws = gcn._first_layer_workspace(dev, cur, n, feats, hidden)
+    _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(ax.data_ptr(), ax.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), pre.data_ptr(),
+                                                         z.data_ptr(), None, n_cls, bits.data_ptr(), n, feats, hidden, n_cls, p,
+                                                         torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr(),
+                                                         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                                         ctypes.c_void_p(cur)))
+    ctr.copy_(c0)
+    keep = _ReluDropoutFn.apply(torch.ones(n, hidden, device=dev), p) != 0
+    pattern = ((pre > 0) & keep).double() / (1.0 - p)
+    del pre, bits, z, keep
+    ref = [(l.lin.weight.detach().clone().double().requires_grad_(), l.bias.detach().clone().double().requires_grad_())
+           for l in model.layers]
+    (rw1, rb1), (rw2, rb2) = ref
+    src, dst = ei[0], ei[1]
+    loops = torch.arange(n, device=dev)
+    src, dst = torch.cat([src, loops]), torch.cat([dst, loops])
+    deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float64))
+    val = deg.pow(-0.5)[src] * deg.pow(-0.5)[dst]
+
+    def propagate(t, chunk=4_000_000):
+        out = torch.zeros((n, t.shape[1]), dtype=torch.float64, device=dev)
+        for s0 in range(0, src.shape[0], chunk):
+            e = slice(s0, s0 + chunk)
+            out = out.index_add(0, dst[e], t[src[e]] * val[e, None])
+        return out
+    with torch.no_grad():
+        ax64 = propagate(x.double())                        # Â·X (a constant of the run: no gradient flows into it)
+    h = (ax64 @ rw1.t() + rb1) * pattern
+    out = torch.log_softmax(propagate(h @ rw2.t()) + rb2, dim=1)[train_rows]
+    torch.nn.functional.nll_loss(out, y[train_rows]).backward()
+    assert (logp.detach().double() - out.detach()).abs().max().item() < tol
+    want = {'layers.0.lin.weight': rw1.grad, 'layers.0.bias': rb1.grad, 'layers.1.lin.weight': rw2.grad, 'layers.1.bias': rb2.grad}
+    for name, w in want.items():
+        err, scale = (got[name] - w).abs().max().item(), w.abs().max().item()
+        assert got[name].shape == w.shape and err <= tol * scale, (name, err, scale)
+
+
+def test_s1m_training_step_gradients_against_fp64():
+    """configs[4], one training step at N = 1M on the rewired graph (round 5: the one-kernel backward had never been compared
+    with anything at this size)."""
+    dev = torch.device('cuda', 0)
+    ei, n, x = _s1m_inputs(dev)
+    _training_step_against_fp64(ei, n, x, 16, 128, 0.5, 0.1)
+
+
+@pytest.mark.parametrize('name,n,n_feat,n_cls', [('Citeseer', 2120, 3703, 6), ('Cora', 2485, 1433, 7)])
+def test_reference_dataset_shapes_training_step_through_the_one_kernel_first_layer(name, n, n_feat, n_cls):
+    """configs[3] (round 5): the reference's own dataset shapes — Citeseer 3,703 -> 64 -> 6, Cora 1,433 -> 128 -> 7, hidden widths,
+    dropout and rewiring parameters from utils/hyperparams.py — take the one-kernel first layer (W1 streamed through LDS in K
+    chunks; before, the GEMM library): a training step on the REWIRED graph, logits and all four gradients <= 1e-5 of a float64
+    evaluation.  Features: a row-normalised bag of words of Planetoid's density (the datasets themselves are not in the image)."""
+    from dcr import synthetic
+    from dcr.data import Data
+    from rewiring.rewire import rewire
+    from utils.hyperparams import hyperparams
+    hp = hyperparams[name]
+    ei, n = synthetic.powerlaw_graph(n, 2, seed=12345)
+    np.random.seed(0)
+    rewired = rewire(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', hp['max_iterations'], hp['removal_bound'], hp['tau'])
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(n, n_feat, generator=g) < 0.0086).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1.0)
+    _training_step_against_fp64(rewired.cuda(), n, x.cuda(), n_cls, hp['hidden_dim'], hp['dropout'], 0.3)
+
+
 def _s1m_worker(rank, world, port, rows_path, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))

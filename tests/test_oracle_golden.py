@@ -230,16 +230,18 @@ def test_bfc_cuda_fixtures_do_not_depend_on_the_float32_typing_model():
             assert np.float32(v) == np.float32(stored) or abs(v) <= abs(stored) + 4.0
 
 
-def test_scale_fixture_is_what_the_c_oracle_produces():
-    """tests/golden/sdrf_s100k_oracle.json (tools/make_golden_scale.py) against the C oracle itself, first iteration only
-    (a pass over the 1M edges + 170k literal add / recompute / remove evaluations: ~15 s on a few threads)."""
+@pytest.mark.parametrize('name', ['sdrf_s100k_oracle.json', 'sdrf_s100k_removal_oracle.json'])
+def test_scale_fixture_is_what_the_c_oracle_produces(name):
+    """tests/golden/sdrf_s100k_oracle.json and sdrf_s100k_removal_oracle.json (tools/make_golden_scale.py) against the C oracle
+    itself, first iteration only (a pass over the 1M edges + 170k literal add / recompute / remove evaluations: ~15 s on a few
+    threads); the removal case's first iteration removes an edge (sdrf_no_cuda.py:62-63)."""
     import hashlib
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'discrete-curvature-rewiring_amd'))
     from dcr import synthetic
     from oracle import c_oracle
-    fix = load_golden('sdrf_s100k_oracle.json')
+    fix = load_golden(name)
     g = fix['graph']
     ei, n = synthetic.powerlaw_graph(g['n'], g['m'], seed=g['seed'])
     assert hashlib.sha256(np.ascontiguousarray(ei).tobytes()).hexdigest() == g['edge_index_sha256']
@@ -248,3 +250,4 @@ def test_scale_fixture_is_what_the_c_oracle_produces():
     c_oracle.sdrf(ei, n, 'bfc', 1, fix['remove_edges'], fix['removal_bound'], fix['tau'], trace=trace,
                   nthreads=max(1, min(8, (os.cpu_count() or 2) - 1)), compact=True)
     assert trace[0] == fix['iterations'][0]
+    assert ('removal' in name) == (trace[0]['removed'] is not None)

@@ -70,6 +70,9 @@ def _untraced_run(ei, n, fix, loops, incremental):
                   incremental=incremental)
     for i in range(loops):
         assert run.step(more=i + 1 < loops)
+        x, y, n_cand = run.last          # every iteration of the untraced legs: the arg-min edge and its candidate count
+        want = fix['iterations'][i]
+        assert [x, y] == want['argmin'] and n_cand == want['n_candidates'], (i, (x, y, n_cand), want['argmin'], want['n_candidates'])
     return run
 
 
@@ -82,17 +85,37 @@ def _final_checks(run, fix, what, curvatures=True):
         _check_curvatures(run.G, fix['rewired_curvature'], what + ': rewired graph')
 
 
+TRACED = 25   # iterations replayed with the improvements on the host (candidate list and improvement vector hashed): ~1 s each
+
+
 def test_s100k_sdrf_follows_the_oracle_trace():
-    """configs[2]: the 100k-node / 1M-edge graph, tau = 163, bound 0.95, seed 0, 25 iterations — traced (improvements on the
-    host, numpy's draw), untraced (draw on the device, fused tail + next pass) and with the incremental pass."""
+    """configs[2] AS WRITTEN: the 100k-node / 1M-edge graph, tau = 163, bound 0.95, seed 0, all 500 iterations (round 5; 25 in
+    round 4) — the first 25 traced (improvements on the host, numpy's draw: candidate list and improvement vector against their
+    SHA-256), then the whole run untraced (draw on the device, fused tail + next pass) and with the incremental pass: arg-min
+    edge and candidate count of EVERY iteration, final edge list, numpy's stream position, sampled + heaviest curvatures."""
     fix = load_golden('sdrf_s100k_oracle.json')
     ei, n = _graph(fix)
     loops = len(fix['iterations'])
     assert loops >= 25
-    _final_checks(_traced_run(ei, n, fix, loops), fix, 'traced')
+    _traced_run(ei, n, fix, min(TRACED, loops))
     run = _untraced_run(ei, n, fix, loops, incremental=False)
     assert run.device_draws + run.host_draws == loops - 1    # (the last iteration goes the plain way: no pass follows it)
     _final_checks(run, fix, 'device draw')
+    _final_checks(_untraced_run(ei, n, fix, loops, incremental=True), fix, 'incremental', curvatures=False)
+
+
+def test_s100k_removal_branch_follows_the_oracle_trace():
+    """rewiring/sdrf_no_cuda.py:57-63 at full size (round 5): the stale arg-max, the exclusion of the edge just added and the
+    conditional removal had only ever run against the oracle below 2,485 nodes — no curvature of these graphs exceeds the
+    reference's bounds.  tests/golden/sdrf_s100k_removal_oracle.json: S100k, Citeseer's tau = 180, bound -1.19 (20 edges of the
+    initial graph lie above it): 40 iterations, the first 20 remove, the last 20 do not.  Traced, untraced, incremental."""
+    fix = load_golden('sdrf_s100k_removal_oracle.json')
+    removed = [it['removed'] for it in fix['iterations']]
+    assert sum(r is not None for r in removed) >= 5 and sum(r is None for r in removed) >= 5   # both outcomes of :62
+    ei, n = _graph(fix)
+    loops = len(fix['iterations'])
+    _final_checks(_traced_run(ei, n, fix, loops), fix, 'traced')
+    _final_checks(_untraced_run(ei, n, fix, loops, incremental=False), fix, 'device draw')
     _final_checks(_untraced_run(ei, n, fix, loops, incremental=True), fix, 'incremental', curvatures=False)
 
 
@@ -106,3 +129,14 @@ def test_s1m_rewiring_step_follows_the_oracle_trace():
     loops = len(fix['iterations'])
     _final_checks(_traced_run(ei, n, fix, loops), fix, 'traced')
     _final_checks(_untraced_run(ei, n, fix, loops, incremental=False), fix, 'device draw', curvatures=False)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', 'sdrf_s1m_removal_oracle.json')),
+                    reason='tests/golden/sdrf_s1m_removal_oracle.json not recorded')
+def test_s1m_removal_step_follows_the_oracle_trace():
+    """One iteration of the removal case at 1M nodes / 10M edges (tau = 180, bound -1.19): the added AND the removed edge, the
+    final edge list, sampled + heaviest curvatures of the rewired graph."""
+    fix = load_golden('sdrf_s1m_removal_oracle.json')
+    assert all(it['removed'] is not None for it in fix['iterations'])
+    ei, n = _graph(fix)
+    _final_checks(_traced_run(ei, n, fix, len(fix['iterations'])), fix, 'traced')
