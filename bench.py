@@ -144,7 +144,11 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=train_mask, val_mask=val_mask)
     model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
     from experiment.save_models import make_adam
-    fused_adam = os.environ.get('DCR_FUSED_ADAM', '1') == '1'   # (the experiment drivers default to the stock implementation)
+    # DCR_FUSED_ADAM: 2 (default here) = the one-launch Adam of this package (experiment/adam.py), 1 = torch's fused
+    # implementation (one kernel per group + counters), 0 = torch's stock one (the experiment drivers' default)
+    adam_mode = os.environ.get('DCR_FUSED_ADAM', '2')
+    os.environ['DCR_FUSED_ADAM'] = adam_mode
+    fused_adam = None if adam_mode == '2' else adam_mode == '1'
     opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
                      {'params': model.reg_params, 'weight_decay': 5e-4}], 0.01, dev, fused=fused_adam)
 
@@ -213,7 +217,9 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
     res['first_layer_backward'] = ('one kernel: dW1, db1, dW2 with the pre-activation gradient in registers (dcr_first_layer_bwd_f32_dev; '
                                    'DCR_FIRST_BWD_FUSED=0: dcr_act_linear_bwd_fused_f32_dev + dcr_atb_f32_dev)'
                                    if one_kernel_bwd else 'dcr_act_linear_bwd_fused_f32_dev + dcr_atb_f32_dev')
-    res['adam'] = ('torch fused (one kernel per group; DCR_FUSED_ADAM=0: stock foreach implementation, the experiment drivers\' default)'
+    res['adam'] = ('one launch per step (experiment/adam.py, dcr_adam_step_f32_dev; DCR_FUSED_ADAM=1: torch fused, 0: torch stock — the '
+                   'experiment drivers\' default)' if type(opt).__name__ == 'OneLaunchAdam' else
+                   'torch fused (one kernel per group; DCR_FUSED_ADAM=0: stock foreach implementation, the experiment drivers\' default)'
                    if getattr(opt, 'defaults', {}).get('fused') else 'torch stock (foreach), capturable')
     res['last_aggregation'] = ('evaluated at the rows the epoch reads (training rows for the loss, validation rows for the accuracy: '
                                f'{n_tr} + {n_va} of {n}); DCR_GCN_ALL_ROWS=1 computes every row')
@@ -347,7 +353,8 @@ def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, ep
     model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=dropout).to(dev)
     from experiment.save_models import make_adam
     opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                     {'params': model.reg_params, 'weight_decay': wd}], lr, dev, fused=os.environ.get('DCR_FUSED_ADAM', '1') == '1')
+                     {'params': model.reg_params, 'weight_decay': wd}], lr, dev,
+                    fused=None if os.environ.get('DCR_FUSED_ADAM', '2') == '2' else os.environ.get('DCR_FUSED_ADAM') == '1')
     # the epoch as experiment/training_loop.py runs it: eager for the first calls, then two captured HIP graphs
     epoch = make_epoch(model, opt, data, lagged=True)
     for _ in range(10):

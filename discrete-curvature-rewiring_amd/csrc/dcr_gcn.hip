@@ -883,6 +883,230 @@ __global__ void __launch_bounds__(256) k_count_argmax_equal(const float *__restr
     if (threadIdx.x == 0 && red[0]) atomicAdd(out, (unsigned long long)red[0]);
 }
 
+
+// ---- Round 5: the head of an epoch in ONE kernel per direction ------------------------------------------------------------------
+// experiment/training_loop.py:50-51 F.nll_loss(model(data)[train_mask], y[train_mask]) with models/gcn.py:44 log_softmax in front
+// of it, and :64-71 the arg-max accuracy on the evaluated split, from the RAW outputs of the last aggregation (the arg-max of a row
+// of log-probabilities is the arg-max of its logits).  Before: two softmax launches, the picked-mean kernel, the arg-max count and
+// two fills forward; a fill, the picked-mean backward, the softmax backward, a fill and a column-sum reduction (the last layer's
+// bias gradient) backward — eleven launches of 4-12 us each for a few hundred KB.  A thread per row (at most 32 classes):
+//   forward:  nll_i = lse_i - o[i, y_i],  lse_i = max_c o[i, c] + log(sum_c exp(o[i, c] - max)); loss = mean_i nll_i (float64 sum
+//             of per-block sums in block order); correct = number of evaluated rows whose first maximum is their label;
+//   backward: grad[i, c] = (exp(o[i, c] - lse_i) - [c == y_i]) * g / m, and its column sums (per-block partials added in block
+//             order: deterministic) = the gradient of the last layer's bias.
+// The last block to finish (a ticket behind an agent-scope fence) closes each reduction; partials and tickets live in a
+// workspace of the CALLER (advisor, round 4: the round-4 loss kernel kept them in process-global device variables, shared by
+// every stream) whose tickets are zero before the first use and left zero by every launch.
+constexpr int HEAD_MAXC = 32, HEAD_MAXB = 1024;
+struct HeadWs {
+    double loss_part[HEAD_MAXB];
+    unsigned long long hit_part[HEAD_MAXB];
+    float col_part[HEAD_MAXB][HEAD_MAXC];
+    unsigned ticket_fwd, ticket_bwd;
+    unsigned pad[2];
+};
+
+template <int C>
+__device__ __forceinline__ float head_lse(const float (&o)[C], int classes) {
+    float mx = o[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c)
+        if (c < classes) mx = fmaxf(mx, o[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        if (c < classes) s += expf(o[c] - mx);
+    return mx + logf(s);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_head_fwd(const float *__restrict__ o_tr, int64_t ld_tr, const int64_t *__restrict__ y_tr, int64_t m_tr,
+                                                  int nb_tr, const float *__restrict__ o_ev, int64_t ld_ev, const int64_t *__restrict__ y_ev,
+                                                  int64_t m_ev, int nb_ev, int classes, float *__restrict__ out_loss,
+                                                  long long *__restrict__ out_correct, HeadWs *__restrict__ ws) {
+    __shared__ double red[256];
+    __shared__ unsigned long long redh[256];
+    __shared__ int last_sh;
+    const int b = blockIdx.x;
+    double a = 0.0;
+    unsigned long long hits = 0ull;
+    if (b < nb_tr) {
+        const int64_t per = (m_tr + nb_tr - 1) / nb_tr, lo = (int64_t)b * per, hi = lo + per < m_tr ? lo + per : m_tr;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            float o[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = c < classes ? o_tr[i * ld_tr + c] : 0.f;
+            const int64_t t = y_tr[i];
+            float pick = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if ((int64_t)c == t) pick = o[c];
+            if (t >= 0 && t < classes) a += (double)(head_lse<C>(o, classes) - pick);
+        }
+    } else {
+        const int be = b - nb_tr;
+        const int64_t per = (m_ev + nb_ev - 1) / nb_ev, lo = (int64_t)be * per, hi = lo + per < m_ev ? lo + per : m_ev;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const float *r = o_ev + i * ld_ev;
+            float best = r[0];
+            int arg = 0;
+            for (int c = 1; c < classes; ++c) {  // first maximum; a NaN counts as the maximum (torch.max)
+                const float v = r[c];
+                if (!(best != best) && (v > best || v != v)) {
+                    best = v;
+                    arg = c;
+                }
+            }
+            hits += (int64_t)arg == y_ev[i] ? 1ull : 0ull;
+        }
+    }
+    red[threadIdx.x] = a;
+    redh[threadIdx.x] = hits;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[threadIdx.x] += red[threadIdx.x + s];
+            redh[threadIdx.x] += redh[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ws->loss_part[b] = red[0];
+        ws->hit_part[b] = redh[0];
+        __threadfence();
+        last_sh = atomicAdd(&ws->ticket_fwd, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    double l = 0.0;
+    unsigned long long h = 0ull;
+    if (threadIdx.x == 0) {   // (at most 2,048 partials: one thread, block order)
+        for (int k = 0; k < nb_tr; ++k) l += __hip_atomic_load(&ws->loss_part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = nb_tr; k < (int)gridDim.x; ++k) h += __hip_atomic_load(&ws->hit_part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (out_loss) out_loss[0] = m_tr > 0 ? (float)(l / (double)m_tr) : 0.f;
+        if (out_correct) out_correct[0] = (long long)h;
+        ws->ticket_fwd = 0u;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_head_bwd(const float *__restrict__ o_tr, int64_t ld_tr, const int64_t *__restrict__ y_tr, int64_t m_tr,
+                                                  int classes, const float *__restrict__ g, float *__restrict__ grad,
+                                                  float *__restrict__ grad_bias, HeadWs *__restrict__ ws) {
+    __shared__ float red[4][HEAD_MAXC];
+    __shared__ int last_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = g[0] / (float)m_tr;
+    const int64_t per = (m_tr + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = lo + per < m_tr ? lo + per : m_tr;
+    float cs[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cs[c] = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        float o[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = c < classes ? o_tr[i * ld_tr + c] : 0.f;
+        const float lse = head_lse<C>(o, classes);
+        const int64_t t = y_tr[i];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (c < classes) {
+                const float v = (expf(o[c] - lse) - ((int64_t)c == t ? 1.f : 0.f)) * scale;
+                grad[i * classes + c] = v;
+                cs[c] += v;
+            }
+    }
+    // column sums: inside a wave by a fixed butterfly, the four waves in wave order, the blocks in block order
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float v = cs[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)classes) ws->col_part[blockIdx.x][threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last_sh = atomicAdd(&ws->ticket_bwd, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    if (threadIdx.x < (unsigned)classes) {
+        float s = 0.f;
+        for (int k = 0; k < (int)gridDim.x; ++k) s += __hip_atomic_load(&ws->col_part[k][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (grad_bias) grad_bias[threadIdx.x] = s;
+    }
+    if (threadIdx.x == 0) ws->ticket_bwd = 0u;
+}
+
+static int head_blocks(int64_t m) {
+    int64_t b = (m + 255) / 256;
+    if (b > HEAD_MAXB / 2) b = HEAD_MAXB / 2;
+    return (int)b;
+}
+
+
+// ---- Round 5: the optimiser step of an epoch as ONE launch --------------------------------------------------------------------
+// experiment/save_models.py:78-82: Adam over two parameter groups that differ in their weight decay only (L2 added to the
+// gradient).  torch's implementations take 2-3 launches per group (step counters, the update; ~45 without `fused`); the four
+// tensors of the 2-layer model are 33k + 2k elements: one grid over all of them.  The update is torch.optim.Adam's
+// (amsgrad off, maximize off), in float32, with the step count in device memory so that a captured epoch advances it:
+//     g += wd * p;  m += (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+constexpr int ADAM_MAXT = 8;
+struct AdamArgs {
+    float *p[ADAM_MAXT];
+    const float *g[ADAM_MAXT];
+    float *m[ADAM_MAXT];
+    float *v[ADAM_MAXT];
+    int64_t start[ADAM_MAXT + 1];   // tensor t holds the flat elements start[t] .. start[t + 1]
+    float wd[ADAM_MAXT];
+    int nt;
+    float lr, b1, b2, eps;
+};
+__global__ void __launch_bounds__(256) k_adam_multi(AdamArgs A, float *__restrict__ step, unsigned *__restrict__ ticket) {
+    const float t = step[0] + 1.f;   // (every block reads it before the last one to finish advances it)
+    const float bc1 = 1.f - powf(A.b1, t), bc2 = 1.f - powf(A.b2, t);
+    const float step_size = A.lr / bc1, bc2_sqrt = sqrtf(bc2);
+    const int64_t total = A.start[A.nt];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < ADAM_MAXT; ++j)
+            if (j < A.nt && e >= A.start[j]) k = j;
+        // (selects, not A.p[k]: indexing a kernel argument with a run-time value puts the struct into scratch)
+        float *pp = A.p[0], *mm = A.m[0], *vv = A.v[0];
+        const float *gg = A.g[0];
+        float wd = A.wd[0];
+        int64_t s0 = A.start[0];
+#pragma unroll
+        for (int j = 1; j < ADAM_MAXT; ++j)
+            if (k == j) {
+                pp = A.p[j]; mm = A.m[j]; vv = A.v[j]; gg = A.g[j]; wd = A.wd[j]; s0 = A.start[j];
+            }
+        const int64_t i = e - s0;
+        const float p0 = pp[i];
+        float g = gg[i];
+        if (wd != 0.f) g = g + wd * p0;
+        float m = mm[i], v = vv[i];
+        m = m + (1.f - A.b1) * (g - m);
+        v = A.b2 * v + (1.f - A.b2) * g * g;
+        mm[i] = m;
+        vv[i] = v;
+        pp[i] = p0 - step_size * (m / (sqrtf(v) / bc2_sqrt + A.eps));
+    }
+    __shared__ int last_sh;
+    __syncthreads();
+    if (threadIdx.x == 0) last_sh = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last_sh && threadIdx.x == 0) {
+        step[0] = t;
+        *ticket = 0u;
+    }
+}
+
 }  // namespace dcr
 
 extern "C" int dcr_nll_picked_mean_fwd_f32_dev(const float *lp, int64_t ld, const int64_t *y, int64_t m, int classes, float *out_loss,
@@ -913,6 +1137,82 @@ extern "C" int dcr_count_argmax_equal_f32_dev(const float *lp, int64_t ld, const
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(dcr::k_count_argmax_equal, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, lp, ld, y, m, classes,
                        (unsigned long long *)out_count);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_adam_step_f32_dev(int n_tensors, void *const *params, const void *const *grads, void *const *exp_avg, void *const *exp_avg_sq,
+                                     const int64_t *numel, const float *weight_decay, double lr, double beta1, double beta2, double eps,
+                                     float *step_dev, uint32_t *ticket_dev, void *hip_stream) {
+    if (n_tensors < 1 || n_tensors > dcr::ADAM_MAXT || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !weight_decay || !step_dev || !ticket_dev)
+        DCR_FAIL(DCR_EINVAL, "bad adam_step arguments (1..8 tensors per call)");
+    dcr::AdamArgs A;
+    A.nt = n_tensors;
+    A.start[0] = 0;
+    for (int t = 0; t < dcr::ADAM_MAXT; ++t) {
+        const bool live = t < n_tensors;
+        if (live && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t] || numel[t] < 0)) DCR_FAIL(DCR_EINVAL, "bad adam_step tensor");
+        A.p[t] = live ? (float *)params[t] : nullptr;
+        A.g[t] = live ? (const float *)grads[t] : nullptr;
+        A.m[t] = live ? (float *)exp_avg[t] : nullptr;
+        A.v[t] = live ? (float *)exp_avg_sq[t] : nullptr;
+        A.wd[t] = live ? weight_decay[t] : 0.f;
+        A.start[t + 1] = A.start[t] + (live ? numel[t] : 0);
+    }
+    A.lr = (float)lr; A.b1 = (float)beta1; A.b2 = (float)beta2; A.eps = (float)eps;
+    int64_t blocks = (A.start[n_tensors] + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dcr::k_adam_multi, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, A, step_dev, ticket_dev);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_head_workspace(int64_t *bytes) {
+    if (!bytes) DCR_FAIL(DCR_EINVAL, "bad head_workspace arguments");
+    *bytes = (int64_t)sizeof(dcr::HeadWs);
+    return DCR_OK;
+}
+
+extern "C" int dcr_head_fwd_f32_dev(const float *o_train, int64_t ld_train, const int64_t *y_train, int64_t m_train, const float *o_eval,
+                                    int64_t ld_eval, const int64_t *y_eval, int64_t m_eval, int classes, float *out_loss,
+                                    int64_t *out_correct, void *ws, int64_t ws_bytes, void *hip_stream) {
+    if (m_train < 0 || m_eval < 0 || (m_train == 0 && m_eval == 0) || classes < 1 || classes > dcr::HEAD_MAXC || !ws ||
+        ws_bytes < (int64_t)sizeof(dcr::HeadWs) || ((uintptr_t)ws & 7))
+        DCR_FAIL(DCR_EINVAL, "bad head_fwd arguments (1..32 classes, a workspace of dcr_head_workspace bytes)");
+    if ((m_train > 0 && (!o_train || !y_train || !out_loss || ld_train < classes)) || (m_eval > 0 && (!o_eval || !y_eval || !out_correct || ld_eval < classes)))
+        DCR_FAIL(DCR_EINVAL, "bad head_fwd arguments");
+    const int nb_tr = m_train > 0 ? dcr::head_blocks(m_train) : 0, nb_ev = m_eval > 0 ? dcr::head_blocks(m_eval) : 0;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (classes <= 8)
+        hipLaunchKernelGGL((dcr::k_head_fwd<8>), dim3((unsigned)(nb_tr + nb_ev)), dim3(256), 0, st, o_train, ld_train, y_train, m_train, nb_tr, o_eval,
+                           ld_eval, y_eval, m_eval, nb_ev, classes, out_loss, (long long *)out_correct, (dcr::HeadWs *)ws);
+    else if (classes <= 16)
+        hipLaunchKernelGGL((dcr::k_head_fwd<16>), dim3((unsigned)(nb_tr + nb_ev)), dim3(256), 0, st, o_train, ld_train, y_train, m_train, nb_tr, o_eval,
+                           ld_eval, y_eval, m_eval, nb_ev, classes, out_loss, (long long *)out_correct, (dcr::HeadWs *)ws);
+    else
+        hipLaunchKernelGGL((dcr::k_head_fwd<32>), dim3((unsigned)(nb_tr + nb_ev)), dim3(256), 0, st, o_train, ld_train, y_train, m_train, nb_tr, o_eval,
+                           ld_eval, y_eval, m_eval, nb_ev, classes, out_loss, (long long *)out_correct, (dcr::HeadWs *)ws);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
+extern "C" int dcr_head_bwd_f32_dev(const float *o_train, int64_t ld_train, const int64_t *y_train, int64_t m_train, int classes, const float *g,
+                                    float *grad, float *grad_bias, void *ws, int64_t ws_bytes, void *hip_stream) {
+    if (!o_train || !y_train || !g || !grad || m_train <= 0 || classes < 1 || classes > dcr::HEAD_MAXC || ld_train < classes || !ws ||
+        ws_bytes < (int64_t)sizeof(dcr::HeadWs) || ((uintptr_t)ws & 7))
+        DCR_FAIL(DCR_EINVAL, "bad head_bwd arguments");
+    const int nb = dcr::head_blocks(m_train);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (classes <= 8)
+        hipLaunchKernelGGL((dcr::k_head_bwd<8>), dim3((unsigned)nb), dim3(256), 0, st, o_train, ld_train, y_train, m_train, classes, g, grad, grad_bias,
+                           (dcr::HeadWs *)ws);
+    else if (classes <= 16)
+        hipLaunchKernelGGL((dcr::k_head_bwd<16>), dim3((unsigned)nb), dim3(256), 0, st, o_train, ld_train, y_train, m_train, classes, g, grad, grad_bias,
+                           (dcr::HeadWs *)ws);
+    else
+        hipLaunchKernelGGL((dcr::k_head_bwd<32>), dim3((unsigned)nb), dim3(256), 0, st, o_train, ld_train, y_train, m_train, classes, g, grad, grad_bias,
+                           (dcr::HeadWs *)ws);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }

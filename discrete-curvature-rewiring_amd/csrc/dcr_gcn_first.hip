@@ -501,8 +501,8 @@ static int launch_first_layer_wide(bool train, bool eval, const float *ax, int64
     do {                                                                                                                              \
         auto kern = k_first_layer_wide<HM, TR, EV>;                                                                                   \
         static bool raised[64] = {};   /* per device (a process may drive several) */                                                \
-        if (!raised[dev & 63]) {                                                                                                      \
-            DCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        if (!raised[dev & 63]) {   /* (the kernel also has a few static bytes: the limit is what it asks for, not the whole LDS) */    \
+            DCR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             raised[dev & 63] = true;                                                                                                  \
         }                                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)n_chunks), dim3(256), lds, st, args, w1, b1, w2, offset_dev, part, tickets, \

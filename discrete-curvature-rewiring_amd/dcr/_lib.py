@@ -72,6 +72,11 @@ SIGNATURES = {
     'dcr_nll_picked_mean_fwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp]),
     'dcr_nll_picked_mean_bwd_f32_dev': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'dcr_count_argmax_equal_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp]),
+    'dcr_adam_step_f32_dev': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                             _i64p, ctypes.POINTER(ctypes.c_float), _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
+    'dcr_head_workspace': (ctypes.c_int, [_i64p]),
+    'dcr_head_fwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp, _vp, _i64, _vp]),
+    'dcr_head_bwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp, _vp, _vp, _i64, _vp]),
     'dcr_first_layer_fits': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'dcr_first_layer_fwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _f64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),

@@ -52,6 +52,10 @@ def make_adam(param_groups, lr, device, fused=None):
     rounding, not bit for bit — which is why the experiment drivers default to the stock implementation and ``bench.py``
     says which one it timed.  A torch build without fused + capturable falls back to the stock one."""
     on_gpu = torch.device(device).type == 'cuda'
+    if fused is None and on_gpu and os.environ.get('DCR_FUSED_ADAM', '0') == '2':
+        # (round 5) the whole step as one launch of this package (experiment/adam.py): same update rule, float32
+        from experiment.adam import OneLaunchAdam
+        return OneLaunchAdam(param_groups, lr=lr)
     if fused is None:
         fused = os.environ.get('DCR_FUSED_ADAM', '0') == '1'
     if on_gpu and fused:

@@ -76,12 +76,48 @@ def _takes_rows(model):
     return getattr(model, 'supports_rows', False) and os.environ.get('DCR_GCN_ALL_ROWS', '0') != '1'
 
 
+_LABELS_OK = {}
+
+
+def _head_classes(model):
+    """Output width of a model that offers ``forward_head`` (models/gcn.py: loss and accuracy straight from the last
+    aggregation's raw outputs, one kernel each way), else None."""
+    if not hasattr(model, 'forward_head') or os.environ.get('DCR_FUSED_HEAD', '1') == '0':
+        return None
+    layers = getattr(model, 'layers', None)
+    return int(getattr(layers[-1], 'out_channels', 0)) or None if layers is not None and len(layers) > 1 else None
+
+
+def _labels_in_range(y, n_classes):
+    """The head kernels read labels as int64 class ids in [0, n_classes): F.nll_loss raises on anything else except
+    ignore_index = -100, which it leaves out of the mean — such labels keep the stock ops.  One host sync per label tensor
+    (cached on its storage and version)."""
+    if y.dtype != torch.int64 or not y.is_cuda or y.numel() == 0:
+        return False
+    key = (y.data_ptr(), y._version, tuple(y.shape), n_classes)
+    hit = _LABELS_OK.get(key)
+    if hit is None:
+        if len(_LABELS_OK) >= 64:
+            _LABELS_OK.clear()
+        hit = _LABELS_OK[key] = bool(int(y.min()) >= 0 and int(y.max()) < n_classes)
+    return hit
+
+
 def train(model, optimizer, data):
     """One optimisation step on the training nodes; returns the loss value (training_loop.py:40-54)."""
     model.train()
     optimizer.zero_grad()
     mask = data.train_mask
-    if _takes_rows(model):
+    loss = None
+    n_classes = _head_classes(model) if _takes_rows(model) else None
+    if n_classes and _labels_in_range(data.y, n_classes):
+        # (round 5) log_softmax + nll_loss on the training rows as one kernel behind the last aggregation: same loss, same gradient
+        # up to float32 rounding; the captured epochs take the same route, so they stay bit-identical to this loop
+        head = model.forward_head(data, rows_train=mask, y_train=data.y[mask].contiguous())
+        loss = head[0] if head is not None else None
+    if loss is not None:
+        pass
+    elif _takes_rows(model):
         loss = F.nll_loss(model(data, rows=mask), data.y[mask])
     else:
         log_probs = model(data)
@@ -101,7 +137,13 @@ def evaluate(model, data, test):
     model.eval()
     if not test and _takes_rows(model):
         mask = data['val_mask']
+        n_classes = _head_classes(model)
         with torch.no_grad():
+            head = None
+            if n_classes and _labels_in_range(data.y, n_classes):
+                head = model.forward_head(data, rows_eval=mask, y_eval=data.y[mask].contiguous())
+            if head is not None:
+                return {'val_acc': head[1].item() / mask.sum().item()}
             predicted = model(data, rows=mask).max(1)[1]
         return {'val_acc': predicted.eq(data.y[mask]).sum().item() / mask.sum().item()}
     with torch.no_grad():
@@ -173,15 +215,31 @@ class GraphedEpoch:
             self._n_classes_checked = n_classes
         return True
 
+    def _head(self, train, evaluate):
+        """(loss, correct) from ``model.forward_head`` (one aggregation + one head kernel; models/gcn.py), or None when the model,
+        the labels or the shapes ask for the log-probabilities and the separate kernels."""
+        n_classes = _head_classes(self.model) if self.rows else None
+        if not n_classes or not self._labels_fit(n_classes):
+            return None
+        return self.model.forward_head(self.data, rows_train=self.train_idx if train else None, y_train=self.y_train if train else None,
+                                       rows_eval=self.val_idx if evaluate else None, y_eval=self.y_val if evaluate else None)
+
     def _train_step(self):
-        log_probs = self.model(self.data, rows=self.train_idx) if self.rows else self.model(self.data)
-        loss = self._nll(log_probs)
+        head = self._head(True, False)
+        if head is not None:
+            loss = head[0]
+        else:
+            log_probs = self.model(self.data, rows=self.train_idx) if self.rows else self.model(self.data)
+            loss = self._nll(log_probs)
         loss.backward()
         self.optimizer.step()
         return loss
 
     def _val_correct(self):
         with torch.no_grad():
+            head = self._head(False, True)
+            if head is not None:
+                return head[1]
             if self.rows:
                 lp = self.model(self.data, rows=self.val_idx)
                 return _count_correct(lp, self.y_val) if _fused_ok(lp) and self._labels_fit(lp.shape[1]) else lp.max(1)[1].eq(self.y_val).sum()
@@ -244,6 +302,12 @@ class LaggedGraphedEpoch(GraphedEpoch):
 
     def _fused_step(self):
         torch._foreach_copy_(self.prev, list(self.model.state_dict().values()))   # (one launch for the snapshot)
+        head = self._head(True, True)
+        if head is not None:
+            loss, correct_prev = head
+            loss.backward()
+            self.optimizer.step()
+            return correct_prev
         if self.rows:
             lp_train, lp_eval = self.model.forward_pair(self.data, rows_train=self.train_idx, rows_eval=self.val_idx)
             correct_prev = (_count_correct(lp_eval, self.y_val) if _fused_ok(lp_eval) and self._labels_fit(lp_eval.shape[1])

@@ -350,6 +350,106 @@ class _AggregateRowsPair(torch.autograd.Function):
         return gz, None, gb, None, None, None
 
 
+_HEAD_WS = {}
+
+
+def _head_workspace(device, stream):
+    """Partials + tickets of the head kernels (dcr_head_*): zero before the first use, left zero by every launch — allocated
+    once per (device, stream) and kept, so that the captured epoch replays on a buffer that outlives the capture."""
+    from dcr import _lib
+    key = (str(device), int(stream))
+    ws = _HEAD_WS.get(key)
+    if ws is None:
+        need = ctypes.c_int64()
+        _lib.check(_lib.lib().dcr_head_workspace(ctypes.byref(need)))
+        ws = _HEAD_WS[key] = torch.zeros((need.value + 7) // 8, dtype=torch.int64, device=device)
+    return ws
+
+
+def head_ok(z, sel_train, sel_eval, n_classes):
+    """Whether the one-kernel head takes these outputs: fp32 on the GPU, at most 32 classes, row selections without repeats."""
+    return (_AGG_BACKEND == 'hip' and z.is_cuda and z.dtype == torch.float32 and 1 <= n_classes <= 32
+            and (sel_train is None or sel_train.expand is None) and (sel_eval is None or sel_eval.expand is None)
+            and os.environ.get('DCR_FUSED_HEAD', '1') != '0')
+
+
+class _AggregateRowsHead(torch.autograd.Function):
+    """The last aggregation at the rows an epoch reads AND what the epoch does with them, without the log-probabilities in
+    between (models/gcn.py:44 + experiment/training_loop.py:51 and :64-71):
+        loss    = F.nll_loss(log_softmax((Â·Z_train + b)[rows_train]), y_train)      (float32 0-dim; None without training rows)
+        correct = ((Â·Z_eval + b)[rows_eval].argmax(1) == y_eval).sum()             (int64 0-dim; None without evaluated rows)
+    One aggregation launch (``dcr_spmm_csr_rows2_f32_dev`` when both operands are the halves of one buffer) and one head kernel
+    (``dcr_head_fwd_f32_dev``); backward: ``dcr_head_bwd_f32_dev`` (gradient of the selected outputs and its column sums = the
+    bias gradient), then dZ = Âᵀ[:, rows]·dOut.  Every selected output row is what ``spmm_rows`` computes."""
+
+    @staticmethod
+    def forward(ctx, z_train, z_eval, bias, csr, sel_train, sel_eval, y_train, y_eval):
+        from dcr import _lib
+        have_tr, have_ev = z_train is not None, z_eval is not None
+        ref = z_train if have_tr else z_eval
+        f = ref.shape[1]
+        out_tr = out_ev = None
+        if have_tr and have_ev:
+            out_tr, out_ev = _AggregateRowsPair.forward(_NoCtx(), z_train, z_eval, bias, csr, sel_train, sel_eval)
+        elif have_tr:
+            out_tr = spmm_rows(csr, sel_train, z_train, bias)
+        else:
+            out_ev = spmm_rows(csr, sel_eval, z_eval, bias)
+        stream = torch.cuda.current_stream(ref.device).cuda_stream
+        ws = _head_workspace(ref.device, stream)
+        loss = torch.empty((), dtype=torch.float32, device=ref.device) if have_tr else None
+        correct = torch.empty((), dtype=torch.int64, device=ref.device) if have_ev else None
+        m_tr = out_tr.shape[0] if have_tr else 0
+        m_ev = out_ev.shape[0] if have_ev else 0
+        if m_tr + m_ev > 0:
+            _lib.check(_lib.lib().dcr_head_fwd_f32_dev(
+                out_tr.data_ptr() if m_tr else None, out_tr.stride(0) if m_tr else f, y_train.data_ptr() if m_tr else None, m_tr,
+                out_ev.data_ptr() if m_ev else None, out_ev.stride(0) if m_ev else f, y_eval.data_ptr() if m_ev else None, m_ev, f,
+                loss.data_ptr() if have_tr else None, correct.data_ptr() if have_ev else None, ws.data_ptr(), ws.numel() * 8,
+                ctypes.c_void_p(stream)))
+        if have_tr and not m_tr:
+            loss.fill_(float('nan'))          # (the mean over no rows, as F.nll_loss gives it)
+        if have_ev and not m_ev:
+            correct.zero_()
+        ctx.csr, ctx.sel, ctx.has_bias, ctx.out_tr, ctx.y_train = csr, sel_train, bias is not None, out_tr, y_train
+        ctx.z_shape = z_train.shape if have_tr else None
+        if correct is not None:
+            ctx.mark_non_differentiable(correct)
+        return loss, correct
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_correct):
+        from dcr import _lib
+        csr, sel, out_tr = ctx.csr, ctx.sel, ctx.out_tr
+        m, f = out_tr.shape
+        gz = gb = None
+        if m == 0:
+            return (out_tr.new_zeros(ctx.z_shape) if ctx.needs_input_grad[0] else None, None,
+                    out_tr.new_zeros(f) if ctx.has_bias and ctx.needs_input_grad[2] else None, None, None, None, None, None)
+        g = g_loss.contiguous().float()
+        grad = torch.empty((m, f), dtype=torch.float32, device=out_tr.device)
+        gb_buf = torch.empty(f, dtype=torch.float32, device=out_tr.device)
+        stream = torch.cuda.current_stream(out_tr.device).cuda_stream
+        ws = _head_workspace(out_tr.device, stream)
+        _lib.check(_lib.lib().dcr_head_bwd_f32_dev(out_tr.data_ptr(), out_tr.stride(0), ctx.y_train.data_ptr(), m, f, g.data_ptr(),
+                                                   grad.data_ptr(), gb_buf.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                                   ctypes.c_void_p(stream)))
+        if ctx.needs_input_grad[0]:
+            rp, ci, va = sel.transposed()
+            gz = spmm(rp, ci, va, grad, csr.n_cols)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gb_buf
+        return gz, None, gb, None, None, None, None, None
+
+
+class _NoCtx:
+    """Stands in for an autograd context where a Function's forward is reused as a plain function."""
+    needs_input_grad = (False,) * 8
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
 def atb_hip(a, b):
     """``a.t() @ b`` for tall-skinny fp32 operands [K, M], [K, N] on the hand-written MFMA kernel
     (csrc/dcr_gemm.hip, ``dcr_atb_f32_dev``)."""
@@ -891,6 +991,60 @@ class GCN(torch.nn.Module):
             o_tr, o_ev = pick(o_tr, rows_train), pick(o_ev, rows_eval)
         log_softmax = torch.nn.functional.log_softmax
         return log_softmax(o_tr, dim=1), log_softmax(o_ev, dim=1)
+
+
+def _forward_head(self, data, rows_train=None, y_train=None, rows_eval=None, y_eval=None):
+    """(loss, correct) of one epoch's two readings of the model in ONE pass, without the log-probabilities in between:
+    ``loss = F.nll_loss(model(data)[rows_train], y_train)`` in training mode (dropout on, autograd graph attached) and
+    ``correct = (model(data)[rows_eval].argmax(1) == y_eval).sum()`` in evaluation mode, of the SAME weights (see
+    ``forward_pair``).  Either half may be left out (rows_* = None): the training step alone, or the evaluation alone.
+    Returns None when a shape, a mode or the backend asks for the separate kernels (the caller then takes the log-probabilities
+    from ``forward`` / ``forward_pair``): two or more layers, row index tensors without repeats, at most 32 classes."""
+    want_tr, want_ev = rows_train is not None, rows_eval is not None
+    last = len(self.layers) - 1
+    if last < 1 or not (want_tr or want_ev) or (want_tr and not self.training):
+        return None
+    conv = self.layers[last]
+    first = self.layers[0]
+    z_first = self._fused_first(data, want_tr, want_ev)
+    if z_first is None:
+        if want_tr:
+            o_tr = first(data.x, data.edge_index, edge_weight=data.edge_attr)
+            o_ev = o_tr.detach()
+        else:
+            with torch.no_grad():
+                o_ev = first(data.x, data.edge_index, edge_weight=data.edge_attr)
+            o_tr = None
+    z_tr = z_ev = None
+    for depth, layer in enumerate(list(self.layers)[1:], start=1):
+        if z_first is not None:
+            (z_tr, z_ev), z_first = z_first, None
+        elif want_tr and want_ev and o_ev.data_ptr() == o_tr.data_ptr():
+            z_tr, z_ev = act_then_linear(o_tr, self.act_fn, self.dropout, layer.lin, want_train=True, want_eval=True)
+        else:
+            z_tr = act_then_linear(o_tr, self.act_fn, self.dropout, layer.lin, want_train=True, want_eval=False)[0] if want_tr else None
+            if want_ev:
+                with torch.no_grad():
+                    z_ev = act_then_linear(o_ev, self.act_fn, self.dropout, layer.lin, want_train=False, want_eval=True)[1]
+        ref = z_tr if want_tr else z_ev
+        csr = layer.norm_csr(data.edge_index, data.edge_attr, ref.shape[0])
+        if depth == last:
+            sel_tr = layer.row_selection(rows_train, csr) if want_tr else None
+            sel_ev = layer.row_selection(rows_eval, csr) if want_ev else None
+            if not head_ok(ref, sel_tr, sel_ev, ref.shape[1]):
+                return None
+            return _AggregateRowsHead.apply(z_tr, z_ev, layer.bias, csr, sel_tr, sel_ev, y_train, y_eval)
+        if want_tr and want_ev:
+            o_tr, o_ev = _AggregatePair.apply(z_tr, z_ev, layer.bias, csr)
+        elif want_tr:
+            o_tr = aggregate(z_tr, layer.bias, csr)
+        else:
+            with torch.no_grad():
+                o_ev = aggregate(z_ev, layer.bias, csr)
+    return None
+
+
+GCN.forward_head = _forward_head
 
 
 def dense_reference_logits(model, x, edge_index, num_nodes):

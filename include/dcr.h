@@ -326,6 +326,29 @@ int dcr_act_linear_bwd_fused_f32_dev(const float *dz_dev, const float *w_dev, co
  * per row). */
 int dcr_nll_picked_mean_fwd_f32_dev(const float *lp_dev, int64_t ld, const int64_t *y_dev, int64_t m, int classes, float *out_loss_dev,
                                     void *hip_stream);
+/* Round 5: the head of an epoch in ONE kernel per direction, from the RAW outputs o = (Â·Z + b)[rows] of the last aggregation
+ * (models/gcn.py:44 log_softmax + experiment/training_loop.py:51 F.nll_loss on the training rows; :64-71 arg-max accuracy on the
+ * evaluated rows — the arg-max of log-probabilities is the arg-max of the logits):
+ *     out_loss[0]    = mean_i (lse_i - o_train[i, y_i]),  lse_i = log sum_c exp o_train[i, c]
+ *     out_correct[0] = #{i : first arg-max of o_eval[i, :] == y_eval[i]}
+ * and backward  grad[i, c] = (exp(o_train[i, c] - lse_i) - [c == y_i]) * g[0] / m_train  (contiguous [m_train, classes]) with
+ * grad_bias[c] = its column sums (the gradient of the last GCNConv's bias; may be NULL).  Either half of the forward call may be
+ * absent (m = 0).  classes <= 32.  Labels must be class ids in [0, classes) (what F.nll_loss accepts without ignore_index).
+ * ws_dev: dcr_head_workspace bytes, 8-byte aligned, ZERO before the first use; every launch leaves its tickets zero (one launch
+ * at a time per workspace).  Sums in a fixed order: deterministic. */
+/* Round 5: torch.optim.Adam's update (experiment/save_models.py:78-82; amsgrad off, L2 weight decay added to the gradient) for up
+ * to 8 float32 tensors in ONE launch: params / grads / exp_avg / exp_avg_sq are host arrays of device pointers, numel and
+ * weight_decay host arrays.  step_dev: the step count as one float in device memory (read, then advanced by one: a captured
+ * epoch replays the increment); ticket_dev: one zero word, left zero. */
+int dcr_adam_step_f32_dev(int n_tensors, void *const *params_dev, const void *const *grads_dev, void *const *exp_avg_dev,
+                          void *const *exp_avg_sq_dev, const int64_t *numel, const float *weight_decay, double lr, double beta1,
+                          double beta2, double eps, float *step_dev, uint32_t *ticket_dev, void *hip_stream);
+int dcr_head_workspace(int64_t *bytes);
+int dcr_head_fwd_f32_dev(const float *o_train_dev, int64_t ld_train, const int64_t *y_train_dev, int64_t m_train, const float *o_eval_dev,
+                         int64_t ld_eval, const int64_t *y_eval_dev, int64_t m_eval, int classes, float *out_loss_dev,
+                         int64_t *out_correct_dev, void *ws_dev, int64_t ws_bytes, void *hip_stream);
+int dcr_head_bwd_f32_dev(const float *o_train_dev, int64_t ld_train, const int64_t *y_train_dev, int64_t m_train, int classes,
+                         const float *g_dev, float *grad_dev, float *grad_bias_dev, void *ws_dev, int64_t ws_bytes, void *hip_stream);
 int dcr_nll_picked_mean_bwd_f32_dev(const int64_t *y_dev, int64_t m, int classes, const float *g_dev, float *grad_dev, void *hip_stream);
 int dcr_count_argmax_equal_f32_dev(const float *lp_dev, int64_t ld, const int64_t *y_dev, int64_t m, int classes, int64_t *out_count_dev,
                                    void *hip_stream);

@@ -362,6 +362,139 @@ def test_loss_and_accuracy_kernels_against_the_stock_ops():
         assert int(_count_correct(lp, yt)) == int(lp.max(1)[1].eq(yt).sum()), y
 
 
+def test_head_kernels_against_the_stock_ops():
+    """dcr_head_fwd_f32_dev / dcr_head_bwd_f32_dev (round 5: models/gcn.py:44 log_softmax + experiment/training_loop.py:51 nll_loss
+    on the training rows and :64-71 the arg-max accuracy on the evaluated rows, one kernel per direction from the RAW outputs of
+    the last aggregation): loss and gradient within float32 rounding of the stock ops, the bias gradient = the column sums of
+    that gradient, the count exactly (ties to the first maximum, a NaN counts as the maximum), every call reproducible bit for
+    bit; and GCN.forward_head against forward_pair + the stock ops on a model."""
+    import torch.nn.functional as F
+    from models import gcn
+    from models.gcn import RowSelection, _AggregateRowsHead, gcn_norm_csr
+    model, _, data = _gcn_case(0.0)
+    n = data.num_nodes
+    csr = gcn_norm_csr(data.edge_index, None, n)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    s_tr, s_ev = RowSelection(csr, data.train_mask), RowSelection(csr, data.val_mask)
+    y_tr, y_ev = data.y[data.train_mask].contiguous(), data.y[data.val_mask].contiguous()
+    for c in (5, 7, 16, 32):
+        both = torch.randn(n, 2 * c, device='cuda', generator=g)
+        bias = torch.randn(c, device='cuda', generator=g)
+        ytr, yev = y_tr % c, y_ev % c
+        z_tr = both[:, :c].clone().requires_grad_(True) if c % 4 else None
+        a = both.clone().requires_grad_(True)
+        ba = bias.clone().requires_grad_(True)
+        za, ze = (a[:, :c], a[:, c:]) if c % 4 == 0 else (z_tr, both[:, c:].contiguous())
+        loss, correct = _AggregateRowsHead.apply(za, ze, ba, csr, s_tr, s_ev, ytr, yev)
+        loss2, correct2 = _AggregateRowsHead.apply(za.detach(), ze, ba.detach(), csr, s_tr, s_ev, ytr, yev)
+        assert torch.equal(loss.detach(), loss2) and torch.equal(correct, correct2)
+        b = both.clone().requires_grad_(True)
+        bb = bias.clone().requires_grad_(True)
+        o_tr = gcn.aggregate_rows(b[:, :c], bb, csr, s_tr)
+        o_ev = gcn.spmm_rows(csr, s_ev, both[:, c:], bias)
+        want = F.nll_loss(F.log_softmax(o_tr, dim=1), ytr)
+        assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+        assert int(correct) == int(o_ev.max(1)[1].eq(yev).sum())
+        loss.backward()
+        want.backward()
+        got_z = (a.grad[:, :c] if c % 4 == 0 else z_tr.grad)
+        scale = b.grad[:, :c].abs().max().item()
+        assert (got_z - b.grad[:, :c]).abs().max().item() <= 2e-6 * scale
+        assert (ba.grad - bb.grad).abs().max().item() <= 1e-5 * bb.grad.abs().max().item()
+        only_tr = _AggregateRowsHead.apply(za.detach(), None, bias, csr, s_tr, None, ytr, None)
+        only_ev = _AggregateRowsHead.apply(None, ze, bias, csr, None, s_ev, None, yev)
+        assert torch.equal(only_tr[0], loss.detach()) and only_tr[1] is None and torch.equal(only_ev[1], correct) and only_ev[0] is None
+    # ties and NaNs in the evaluated rows
+    from dcr import _lib
+    import ctypes
+    lp = torch.tensor([[0.5, 0.5, 0.1], [0.1, 0.7, 0.7], [float('nan'), 1.0, 2.0], [1.0, float('nan'), float('nan')], [0.0, 0.0, 0.0]],
+                      device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    ws = gcn._head_workspace(lp.device, st)
+    for y in ([0, 1, 0, 1, 0], [1, 2, 2, 2, 2], [0, 1, 2, 0, 1]):
+        yt = torch.tensor(y, device='cuda')
+        out = torch.empty((), dtype=torch.int64, device='cuda')
+        _lib.check(_lib.lib().dcr_head_fwd_f32_dev(None, 3, None, 0, lp.data_ptr(), 3, yt.data_ptr(), 5, 3, None, out.data_ptr(), ws.data_ptr(),
+                                                   ws.numel() * 8, ctypes.c_void_p(st)))
+        assert int(out) == int(lp.max(1)[1].eq(yt).sum()), y
+    # the model: forward_head = forward_pair + the stock ops
+    model.train()
+    tr_idx, ev_idx = data.train_mask.nonzero().squeeze(1), data.val_mask.nonzero().squeeze(1)
+    loss, correct = model.forward_head(data, rows_train=tr_idx, y_train=y_tr, rows_eval=ev_idx, y_eval=y_ev)
+    loss.backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    lp_tr, lp_ev = model.forward_pair(data, rows_train=tr_idx, rows_eval=ev_idx)
+    want = F.nll_loss(lp_tr, y_tr)
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want))) and int(correct) == int(lp_ev.max(1)[1].eq(y_ev).sum())
+    for a, p in zip(got, model.parameters()):
+        assert (a - p.grad).abs().max().item() <= 1e-5 * max(p.grad.abs().max().item(), 1e-12)
+    model.zero_grad()
+    l_only = model.forward_head(data, rows_train=tr_idx, y_train=y_tr)[0]
+    model.eval()
+    with torch.no_grad():
+        c_only = model.forward_head(data, rows_eval=ev_idx, y_eval=y_ev)[1]
+    assert torch.equal(l_only.detach(), loss.detach()) and torch.equal(c_only, correct)
+
+
+def test_one_launch_adam_follows_torch_adam():
+    """experiment/adam.py::OneLaunchAdam (dcr_adam_step_f32_dev, round 5) against torch.optim.Adam on the reference's wiring
+    (save_models.py:78-82: two groups, weight decay on one): parameters and moments within float32 rounding after 25 steps,
+    the step counter on the device; and inside a captured HIP graph (the counter advances with every replay)."""
+    from experiment.adam import OneLaunchAdam
+    g = torch.Generator(device='cuda').manual_seed(6)
+    shapes = [(128, 256), (128,), (16, 128), (16,)]
+    init = [torch.randn(*s, device='cuda', generator=g) * 0.1 for s in shapes]
+    grads = [[torch.randn(*s, device='cuda', generator=g) for s in shapes] for _ in range(25)]
+
+    def build(cls, **kw):
+        ps = [t.clone().requires_grad_(True) for t in init]
+        return ps, cls([{'params': ps[2:], 'weight_decay': 0}, {'params': ps[:2], 'weight_decay': 5e-3}], lr=0.02, **kw)
+    pa, oa = build(OneLaunchAdam)
+    pb, ob = build(torch.optim.Adam)
+    for step in grads:
+        for p, q, gr in zip(pa, pb, step):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    assert float(oa._step) == 25.0
+    for p, q in zip(pa, pb):
+        assert (p - q).abs().max().item() <= 2e-6 * max(1.0, q.abs().max().item())
+        assert (oa.state[p]['exp_avg'] - ob.state[q]['exp_avg']).abs().max().item() <= 1e-6
+        assert (oa.state[p]['exp_avg_sq'] - ob.state[q]['exp_avg_sq']).abs().max().item() <= 1e-6
+    with pytest.raises(ValueError):
+        OneLaunchAdam([{'params': [init[0].clone().requires_grad_(True)], 'lr': 0.1}, {'params': [init[1].clone().requires_grad_(True)]}], lr=0.02)
+    # captured: three replays = three more steps
+    pc, oc = build(OneLaunchAdam)
+    static = [torch.zeros_like(t) for t in init]
+    for p, gr in zip(pc, static):
+        p.grad = gr
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for gr, src in zip(static, grads[0]):
+            gr.copy_(src)
+        oc.step()                                   # (eager warm-up: the state comes into being)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        oc.step()
+    for k in (1, 2, 3):
+        for gr, src in zip(static, grads[k]):
+            gr.copy_(src)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert float(oc._step) == 4.0
+    pd, od = build(OneLaunchAdam)
+    for k in range(4):
+        for p, gr in zip(pd, grads[k]):
+            p.grad = gr.clone()
+        od.step()
+    for p, q in zip(pc, pd):
+        assert torch.equal(p, q)
+
+
 def test_two_row_lists_in_one_launch():
     """dcr_spmm_csr_rows2_f32_dev (training rows of the first column block, validation rows of the second) against two
     dcr_spmm_csr_rows_f32_dev calls: the same bits, with and without a bias, including empty lists on either side."""

@@ -20,7 +20,8 @@ full size.  Every Balanced Forman curvature of these preferential-attachment gra
 2/d1 + 2/d2 - 2 <= -1.6 before the triangle terms), so none of the reference's removal bounds (utils/hyperparams.py: 0 ... 14.43)
 ever fires on them; the cases keep Citeseer's tau = 180 (hyperparams.py:19) and put the bound at -1.19, which 20 edges of the
 initial S100k graph exceed: the run removes for its first iterations and stops removing once the stale maximum falls under the
-bound, so both outcomes of `:62` are in the trace.  The generator asserts the number of removals.
+bound, so both outcomes of `:62` are in the trace (S1M, whose largest curvature is -1.238: bound -1.26, 17 edges above it, one
+iteration).  The generator asserts the number of removals.
 """
 import hashlib
 import json
@@ -42,7 +43,7 @@ CASES = {
     's1m': dict(n=1_000_000, m=10, seed=12345, iterations=3, sampled=5000, heaviest=300),
     's100k_removal': dict(n=100_000, m=10, seed=12345, iterations=40, sampled=5000, heaviest=300, tau=180.0, bound=-1.19,
                           min_removals=5, min_kept=5),
-    's1m_removal': dict(n=1_000_000, m=10, seed=12345, iterations=1, sampled=2000, heaviest=300, tau=180.0, bound=-1.19,
+    's1m_removal': dict(n=1_000_000, m=10, seed=12345, iterations=1, sampled=2000, heaviest=300, tau=180.0, bound=-1.26,
                         min_removals=1, min_kept=0),
 }
 TAU, BOUND, NP_SEED = 163.0, 0.95, 0
