@@ -364,7 +364,7 @@ __device__ inline void h2_retry_push(const H2Retry rt, int u, int d, int cls) { 
 
 #ifdef H2_UNIT_TIMES  // diagnostic build (tools/build_variant.sh ut -DH2_UNIT_TIMES): start and duration of every block-class unit
 constexpr unsigned H2_UT_CAP = 16384;
-__device__ int4 h2_ut[H2_UT_CAP];      // {node, class | partitions << 16 | partition, s_memtime ticks, start tick}
+__device__ int4 h2_ut[2 * H2_UT_CAP];  // {node, class | partitions << 16 | partition, s_memtime ticks, start tick / 16}, {ticks: clear + seed, sweep A, sweep B, third step}
 __device__ unsigned h2_ut_n;
 __device__ long long h2_ut_t0;
 __global__ void k_h2_ut_mark() { h2_ut_t0 = (long long)__builtin_amdgcn_s_memtime(); h2_ut_n = 0u; }
@@ -780,7 +780,15 @@ struct H2Tab {
     unsigned *key;  // [EXS] 4-slot buckets
     unsigned *cnt;  // [EXS / 2] their state, 16 bits each
     int *full;      // set when the table fills up
+#ifdef H2_UNIT_TIMES
+    long long *ut;  // [4] phase boundaries of the current unit (thread 0)
+#endif
 };
+#ifdef H2_UNIT_TIMES
+#define H2_UT_PHASE(i) { if (threadIdx.x == 0) t.ut[i] = (long long)__builtin_amdgcn_s_memtime(); }
+#else
+#define H2_UT_PHASE(i) {}
+#endif
 
 // M_u(w) and whether w is a member of N(u); {1, false} for a key this unit keeps no exact state for
 template <int L1, int EXS>
@@ -1193,9 +1201,14 @@ __device__ inline void h2_batch_begin(const H2Tasks tk, H2Alloc &al, H2Scratch *
 
 // third sweep, end of a batch (the queue is drained): partners to the pool, tasks, records.  i: this lane's position in
 // row u; k, rk: its member of N(u) and that one's row
+// items / [ifrom, ito): in list mode, the wave's exact-path items of this batch ({slot, row, batch}: h2_settle_items has just walked
+// them) — round 5: when the batch has more triangle partners than the LDS list holds, they are taken from these items in a second
+// pass instead of reading the rows again (a wave per long row, one after the other: 186 of the 407 us of the longest unit of the
+// bench graph, the unit that sets the length of the split class's kernel).  items == nullptr: streaming mode, rows are read again.
 template <int L1, int EXS, bool PARTS>
 __device__ inline void h2_batch_end(const View &g, const H2Tasks tk, H2Alloc &al, int u, int2 ru, int i, int k, int2 rk, int tbase,
-                                    int trow, int part, const H2Tab t, H2Scratch *sc, uint4 *rec) {
+                                    int trow, int part, const H2Tab t, H2Scratch *sc, uint4 *rec, const unsigned *items = nullptr,
+                                    int ifrom = 0, int ito = 0) {
     const int lane = threadIdx.x & 63;
     int T = sc->rowT[lane], pos = sc->rowPos[lane], mx = sc->rowMx[lane];
     const int rev = sc->rowRev[lane];
@@ -1222,6 +1235,16 @@ __device__ inline void h2_batch_end(const View &g, const H2Tasks tk, H2Alloc &al
             for (int j = lane; j < pln; j += 64) {
                 const int r = sc->plr[j];
                 if (sc->poff[r] >= 0) tk.part[atomicAdd(&sc->poff[r], 1)] = (int32_t)sc->plt[j];
+            }
+            h2_wave_sync();
+        } else if (items) {
+            // too many for the LDS list (rows of hubs): a second pass over the batch's items — every flagged one is a partner of its row
+            sc->poff[lane] = listed ? p0 + ep : -1;
+            h2_wave_sync();
+            for (int j = ifrom + lane; j < ito; j += 64) {
+                const unsigned item = items[j];
+                const int s2 = (int)(item & 0x1FFFu), r = (int)((item >> 13) & 63u);
+                if ((h2_cnt_get(t.cnt, s2) & 0x8000u) && sc->poff[r] >= 0) tk.part[atomicAdd(&sc->poff[r], 1)] = (int32_t)t.key[s2];
             }
             h2_wave_sync();
         } else {
@@ -1311,9 +1334,10 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
             h2_batch_begin(tk, al, sc, k, tbase, trow, ls.revs[bidx * 64 + lane]);
             h2_wave_sync();
             H2_STAMP(8)
+            const int lfrom = lcur;
             h2_settle_items<L1, EXS>(t, sc, ls, lcur, bidx, tk, al, tbase);
             H2_STAMP(9)
-            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
+            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec, ls.items, lfrom, lcur);
             h2_wave_sync();  // the scratch is rewritten by the next batch
             H2_STAMP(11)
             continue;
@@ -1432,6 +1456,7 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
     }
     __syncthreads();  // the tables are cleared
     H2_STAMP(0 + (PARTS ? 4 : 0))
+    H2_UT_PHASE(0)
     if (k >= 0) {     // the members of N(u): flagged table entries (in every partition's tables)
         const int sl = h2_insert<EXS>(t.key, (unsigned)k);
         if (sl < 0) *t.full = 1;
@@ -1455,6 +1480,7 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
     }
     __syncthreads();
     H2_STAMP(1 + (PARTS ? 4 : 0))
+    H2_UT_PHASE(1)
     // Sweep B: flagged entries are queued, the drain has one call site.  It lists its exact-path entries (slot and row) and
     // where u sits in each row; the third step is then one pass over that list (h2_settle_items) — unless the list overflowed:
     // that wave streams its rows for the third sweep (h2_stream, the path of the units that do not fit the registers).
@@ -1506,6 +1532,7 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
     }
     __syncthreads();
     H2_STAMP(2 + (PARTS ? 4 : 0))
+    H2_UT_PHASE(2)
     ok = *t.full == 0;  // uniform
     if (ok) {
         if (!ls.over) {  // uniform over the wave
@@ -1517,7 +1544,7 @@ __device__ inline bool h2_node_fast(const View &g, const H2Tasks tk, H2Alloc &al
             h2_wave_sync();
             h2_settle_items<L1, EXS>(t, sc, ls, lcur, 0, tk, al, tbase);
             H2_STAMP(13)
-            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec);
+            h2_batch_end<L1, EXS, PARTS>(g, tk, al, u, ru, i, k, rk, tbase, trow, part, t, sc, rec, ls.items, 0, lcur);
             H2_STAMP(15)
         } else {
             h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec, k, rk, ls);
@@ -1580,12 +1607,15 @@ __device__ inline bool h2_node(const View &g, const H2Tasks tk, H2Alloc &al, int
     }
     __syncthreads();
     H2_STAMP(8 - 8 + (PARTS ? 4 : 0))
+    H2_UT_PHASE(0)
     h2_stream<L1, EXS, NW, PARTS, 0>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0, ls);
     __syncthreads();
     H2_STAMP(1 + (PARTS ? 4 : 0))
+    H2_UT_PHASE(1)
     h2_stream<L1, EXS, NW, PARTS, 1>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0, ls);
     __syncthreads();
     H2_STAMP(2 + (PARTS ? 4 : 0))
+    H2_UT_PHASE(2)
     const bool ok = *t.full == 0;  // uniform
     if (ok) h2_stream<L1, EXS, NW, PARTS, 2>(g, tk, al, u, ru, part, nparts, t, sc, rec, k0, rk0, ls);
     __syncthreads();  // the tables are rewritten by the next unit
@@ -1610,7 +1640,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)
         row_ok(g, make_int2(-1, total), 37, 0, 0);
         return;
     }
+#ifdef H2_UNIT_TIMES
+    __shared__ long long ut_sh[4];
+    const H2Tab t{bits, bits + (1 << L1) / 32, key, cnt, &full, ut_sh};
+#else
     const H2Tab t{bits, bits + (1 << L1) / 32, key, cnt, &full};
+#endif
     H2Alloc al;
 #ifdef H2_PROF
     if ((threadIdx.x & 63) < 16) sc_all[wid].prof[threadIdx.x & 63] = 0ull;
@@ -1635,7 +1670,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)
         if (threadIdx.x == 0 && !is_retry) {
             const long long ut1 = (long long)__builtin_amdgcn_s_memtime();
             const unsigned slot = atomicAdd(&h2_ut_n, 1u);
-            if (slot < H2_UT_CAP) h2_ut[slot] = make_int4(u, (PARTS ? 0x40000000 : 0) | (nparts << 16) | part, (int)(ut1 - ut0), (int)((ut0 - h2_ut_t0) & 0x7FFFFFFF));
+            if (slot < H2_UT_CAP) {
+                h2_ut[2 * slot] = make_int4(u, (PARTS ? 0x40000000 : 0) | (nparts << 16) | part, (int)(ut1 - ut0), (int)((ut0 - h2_ut_t0) >> 4));
+                h2_ut[2 * slot + 1] = make_int4((int)(ut_sh[0] - ut0), (int)(ut_sh[1] - ut_sh[0]), (int)(ut_sh[2] - ut_sh[1]), (int)(ut1 - ut_sh[2]));
+            }
         }
 #endif
         if (!unit_ok) {
@@ -2159,35 +2197,39 @@ static void launch_h2_block(dcr_graph *g, const View &vw, const H2Tasks &tk, con
 static void h2_print_unit_times(dcr_graph *g) {
     (void)hipStreamSynchronize(g->stream);
     (void)hipDeviceSynchronize();
-    static int4 h[H2_UT_CAP];
+    static int4 h[2 * H2_UT_CAP];
     unsigned n = 0;
     (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(h2_ut_n), sizeof(n));
     if (n > H2_UT_CAP) n = H2_UT_CAP;
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(h2_ut), sizeof(int4) * n);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(h2_ut), sizeof(int4) * 2 * n);
     std::vector<int2> ri(g->n);
     std::vector<int32_t> wt(g->n);
     (void)hipMemcpy(ri.data(), g->rowinfo, sizeof(int2) * g->n, hipMemcpyDeviceToHost);
     (void)hipMemcpy(wt.data(), g->h2_weight, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost);
     for (int cls = 0; cls < 2; ++cls) {
-        std::vector<int4> v;
-        double sum = 0;
+        std::vector<unsigned> v;
+        double sum = 0, ph[4] = {0, 0, 0, 0};
+        long long first = -1, last = 0;
         for (unsigned i = 0; i < n; ++i)
-            if (((h[i].y >> 30) & 1) == cls) { v.push_back(h[i]); sum += h[i].z; }
-        std::sort(v.begin(), v.end(), [](const int4 &a, const int4 &b) { return a.z > b.z; });
-        fprintf(stderr, "[h2 units] class %s: %zu units, total %.1f us of unit time (s_memtime at 100 MHz), longest:\n", cls ? "L (split)" : "M", v.size(), sum / 100.0);
-        for (size_t i = 0; i < v.size() && i < 12; ++i)
-            fprintf(stderr, "    node %6d deg %5d W %8d part %d/%d: %7.1f us, started at %7.1f us\n", v[i].x, ri[v[i].x].y, wt[v[i].x] & 0x7FFFFFFF, v[i].y & 0xFFFF,
-                    (v[i].y >> 16) & 0x3FFF, v[i].z / 100.0, v[i].w / 100.0);
-        // histogram of durations and the last end
-        double last_end = 0;
-        int hist[8] = {0};
-        for (auto &e : v) {
-            last_end = std::max(last_end, (e.w + e.z) / 100.0);
-            const double us = e.z / 100.0;
-            hist[us < 10 ? 0 : us < 20 ? 1 : us < 40 ? 2 : us < 80 ? 3 : us < 160 ? 4 : us < 320 ? 5 : 6]++;
+            if (((h[2 * i].y >> 30) & 1) == cls) {
+                v.push_back(i);
+                sum += h[2 * i].z;
+                ph[0] += h[2 * i + 1].x; ph[1] += h[2 * i + 1].y; ph[2] += h[2 * i + 1].z; ph[3] += h[2 * i + 1].w;
+                const long long st = (long long)h[2 * i].w * 16, en = st + h[2 * i].z;
+                if (first < 0 || st < first) first = st;
+                if (en > last) last = en;
+            }
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end(), [&](unsigned a, unsigned b) { return h[2 * a].z > h[2 * b].z; });
+        fprintf(stderr, "[h2 units] class %s: %zu units; first start to last end %.0f kticks (= the kernel); sum of unit times %.0f kticks; phases (sum, kticks): clear + seed %.0f, "
+                "sweep A %.0f, sweep B %.0f, third step %.0f\n", cls ? "L (split)" : "M", v.size(), (last - first) / 1e3, sum / 1e3, ph[0] / 1e3, ph[1] / 1e3, ph[2] / 1e3, ph[3] / 1e3);
+        fprintf(stderr, "    unit time percentiles (kticks): 50%% %.1f  90%% %.1f  99%% %.1f  max %.1f\n", h[2 * v[v.size() / 2]].z / 1e3, h[2 * v[v.size() / 10]].z / 1e3,
+                h[2 * v[v.size() / 100]].z / 1e3, h[2 * v[0]].z / 1e3);
+        for (size_t i = 0; i < v.size() && i < 8; ++i) {
+            const int4 a = h[2 * v[i]], b = h[2 * v[i] + 1];
+            fprintf(stderr, "    node %6d deg %5d W %8d part %d/%d: %7.1f kticks (clear + seed %.1f, A %.1f, B %.1f, third %.1f), started at %.1f\n", a.x, ri[a.x].y,
+                    wt[a.x] & 0x7FFFFFFF, a.y & 0xFFFF, (a.y >> 16) & 0x3FFF, a.z / 1e3, b.x / 1e3, b.y / 1e3, b.z / 1e3, b.w / 1e3, (a.w * 16.0 - first) / 1e3);
         }
-        fprintf(stderr, "    durations <10 / <20 / <40 / <80 / <160 / <320 / more us: %d %d %d %d %d %d %d; last unit ends at %.1f us\n", hist[0], hist[1], hist[2],
-                hist[3], hist[4], hist[5], hist[6], last_end);
     }
 }
 #endif
@@ -2330,6 +2372,9 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         g->ext_part_n = (int)fb * 4;
         g->ext_part_valid = true;
         DCR_HIP(hipGetLastError());
+#ifdef H2_UNIT_TIMES
+        h2_print_unit_times(g);
+#endif
         return DCR_OK;
     }
     // Streams: the block classes (long units; the triangle step waits for them only) on two high-priority streams, the

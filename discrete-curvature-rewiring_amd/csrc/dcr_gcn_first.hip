@@ -339,11 +339,11 @@ template <int HM>
 __host__ __device__ constexpr int wide_kch() { return 16384 / (16 * HM); }   // columns of W1 per chunk: 64 KB in LDS
 
 template <int HM, bool TRAIN, bool EVAL>
-__global__ void __launch_bounds__(256) k_first_layer_wide(FirstArgs A, const float *__restrict__ w1, const float *__restrict__ b1,
+__global__ void __launch_bounds__(256, 2) k_first_layer_wide(FirstArgs A, const float *__restrict__ w1, const float *__restrict__ b1,
                                                           const float *__restrict__ w2, const uint64_t *__restrict__ offset_dev,
                                                           float *__restrict__ part, unsigned *__restrict__ tickets, int n_chunks,
                                                           int64_t n_groups, int64_t rows_padded) {
-    constexpr int H = 16 * HM, KCH = wide_kch<HM>(), FS = KCH, HS = H;
+    constexpr int H = 16 * HM, KCH = wide_kch<HM>(), FS = KCH, HS = H, NM = KCH / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int last_sh;
     float *w1s = lds;               // [H][FS]: this chunk's columns of W1
@@ -354,40 +354,66 @@ __global__ void __launch_bounds__(256) k_first_layer_wide(FirstArgs A, const flo
     const int chunk = blockIdx.y, k0 = chunk * KCH;
     const int kw = F16 - k0 < KCH ? F16 - k0 : KCH;   // columns of this chunk (a multiple of 16)
     const int n_m = kw / 16;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, gi = g ^ i;
+    const int64_t n_units = (A.n_rows + 15) / 16;
+    // At the sizes this kernel exists for (a few thousand rows) every phase is ONE round trip to memory deep, so each phase asks
+    // for everything it needs at once: the chunk's pieces of this wave's rows of Â·X first (they fly under the staging of W1) ...
+    auto load_rows = [&](int64_t unit, float4 (&a)[NM]) {
+        const float *ap = first_row_ptr(A, unit, i, g) + k0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) a[m] = m < n_m ? *reinterpret_cast<const float4 *>(ap + 16 * m) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 a[NM];
     {
+        const int64_t unit0 = (int64_t)blockIdx.x * 4 + wave;
+        load_rows(unit0 < n_units ? unit0 : 0, a);
+    }
+    {   // ... then W1's chunk: wave w stages rows w, w + 4, ...; lane = 16-byte chunk of the row (KCH / 4 of them); all the loads of a
+        // thread are issued before the first store (element by element the loop was a chain of dependent round trips: 25 us)
+        constexpr int CPR = KCH / 4, RPI = 256 / CPR, NIT = H / RPI;   // chunks per row, rows per iteration, iterations
+        const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR, c = k0 + 4 * c4;
         const bool vec = (F & 3) == 0 && (((uintptr_t)w1) & 15) == 0;
-        for (int e = threadIdx.x; e < H * (KCH / 4); e += 256) {
-            const int r = e / (KCH / 4), c4 = e - r * (KCH / 4), c = k0 + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (4 * c4 < kw) {
-                const float *src = w1 + (int64_t)r * F + c;
-                if (vec && c + 3 < F) {
-                    v = *reinterpret_cast<const float4 *>(src);
-                } else {
-                    if (c < F) v.x = src[0];
-                    if (c + 1 < F) v.y = src[1];
-                    if (c + 2 < F) v.z = src[2];
-                    if (c + 3 < F) v.w = src[3];
-                }
+        float4 v[NIT];
+        const bool in = 4 * c4 < kw;
+        if (vec) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                v[it] = (in && c + 3 < F) ? *reinterpret_cast<const float4 *>(w1 + (int64_t)(r0 + RPI * it) * F + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            // (any alignment: four 4-byte loads from clamped addresses, out-of-range elements replaced afterwards)
+            const int c0 = c < F ? c : F - 1, c1 = c + 1 < F ? c + 1 : F - 1, c2 = c + 2 < F ? c + 2 : F - 1, c3 = c + 3 < F ? c + 3 : F - 1;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float *src = w1 + (int64_t)(r0 + RPI * it) * F;
+                v[it] = make_float4(src[c0], src[c1], src[c2], src[c3]);
             }
-            *reinterpret_cast<float4 *>(w1s + r * FS + 4 * (c4 ^ (r & 15))) = v;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!in || c >= F) v[it].x = 0.f;
+                if (!in || c + 1 >= F) v[it].y = 0.f;
+                if (!in || c + 2 >= F) v[it].z = 0.f;
+                if (!in || c + 3 >= F) v[it].w = 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + RPI * it;
+            *reinterpret_cast<float4 *>(w1s + r * FS + 4 * (c4 ^ (r & 15))) = v[it];
         }
         for (int e = threadIdx.x; e < 16 * (H / 4); e += 256) {
-            const int r = e / (H / 4), c4 = e % (H / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = e / (H / 4), cc = e % (H / 4);
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < A.C) {
-                const float *src = w2 + (int64_t)r * H + 4 * c4;
-                v = make_float4(src[0], src[1], src[2], src[3]);
+                const float *src = w2 + (int64_t)r * H + 4 * cc;
+                t = make_float4(src[0], src[1], src[2], src[3]);
             }
-            *reinterpret_cast<float4 *>(w2s + r * HS + 4 * (c4 ^ (r & 15))) = v;
+            *reinterpret_cast<float4 *>(w2s + r * HS + 4 * (cc ^ (r & 15))) = t;
         }
         for (int e = threadIdx.x; e < H; e += 256) b1s[e] = b1 ? b1[e] : 0.f;
     }
     __syncthreads();
     if (TRAIN && offset_dev) A.offset += *offset_dev;
 
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6, gi = g ^ i;
-    const int64_t n_units = (A.n_rows + 15) / 16;
     const float *w1l = w1s + i * FS;
     const float *w2l = w2s + i * HS;
     const float *b1g = b1s + 4 * g;
@@ -398,69 +424,70 @@ __global__ void __launch_bounds__(256) k_first_layer_wide(FirstArgs A, const flo
             f32x4 acc[HM];
 #pragma unroll
             for (int t = 0; t < HM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float *ap = first_row_ptr(A, unit, i, g) + k0;
-            auto step = [&](const float4 av, int m) {
-                const float *wm = w1l + 4 * ((4 * m) ^ gi);
 #pragma unroll
-                for (int t = 0; t < HM; ++t) {
-                    const float4 w = *reinterpret_cast<const float4 *>(wm + 16 * t * FS);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, av.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, av.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, av.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, av.w, acc[t], 0, 0, 0);
+            for (int m = 0; m < NM; ++m) {
+                if (m < n_m) {   // uniform (a step past the chunk's end would multiply zeros: skipped, not computed)
+                    const float *wm = w1l + 4 * ((4 * m) ^ gi);
+#pragma unroll
+                    for (int t = 0; t < HM; ++t) {
+                        const float4 w = *reinterpret_cast<const float4 *>(wm + 16 * t * FS);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a[m].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a[m].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a[m].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a[m].w, acc[t], 0, 0, 0);
+                    }
                 }
-            };
-            // two pieces ahead: the whole chunk of a row is 0.5-1 KB, its latency is the kernel's time at these sizes
-            float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = n_m > 1 ? *reinterpret_cast<const float4 *>(ap + 16) : a0, a2;
-            int m = 0;
-            for (; m + 2 < n_m; ++m) {
-                a2 = *reinterpret_cast<const float4 *>(ap + 16 * (m + 2));
-                __builtin_amdgcn_sched_barrier(0);
-                step(a0, m);
-                __builtin_amdgcn_sched_barrier(0);
-                a0 = a1;
-                a1 = a2;
             }
-            if (m < n_m) step(a0, m);
-            if (m + 1 < n_m) step(a1, m + 1);
-            // the partial tile: register r of acc[t] is column 16t + 4g + r of row i
-            float *dst = part + ((int64_t)chunk * rows_padded + unit * 16 + i) * H + 4 * g;
+            // the partial tile: register r of acc[t] is column 16t + 4g + r of row i.  Written (and read back below) with
+            // agent-scope relaxed atomics, i.e. plain stores / loads that go THROUGH the XCD's L2 (sc1): the tiles are then
+            // visible to the other XCDs without an agent-scope release fence, which writes back and invalidates the whole L2 —
+            // 510 of them cost 45 of the kernel's 80 us at the Citeseer shape (tools/r05_probe9.sh; timing-only build without
+            // fences: 36 us).  What orders tile and ticket is the wait for the stores (workgroup-scope release) ahead of the barrier.
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(part + ((int64_t)chunk * rows_padded + unit * 16 + i) * H + 4 * g);
 #pragma unroll
-            for (int t = 0; t < HM; ++t) *reinterpret_cast<float4 *>(dst + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            for (int t = 0; t < HM; ++t) {
+                __hip_atomic_store(dst + 8 * t, ((unsigned long long)__float_as_uint(acc[t][1]) << 32) | __float_as_uint(acc[t][0]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 8 * t + 1, ((unsigned long long)__float_as_uint(acc[t][3]) << 32) | __float_as_uint(acc[t][2]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        __threadfence();    // (release, agent scope: the tile is visible before the ticket is)
+        // the next row group's pieces (large N: a workgroup keeps its chunk of W1 and walks row groups) fly under the ticket
+        if (rg + gridDim.x < n_groups) {
+            const int64_t un = (rg + gridDim.x) * 4 + wave;
+            load_rows(un < n_units ? un : 0, a);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // every wave's tile stores have completed ...
         __syncthreads();
-        if (threadIdx.x == 0) last_sh = atomicAdd(&tickets[rg], 1u) == (unsigned)(n_chunks - 1);
+        if (threadIdx.x == 0) last_sh = atomicAdd(&tickets[rg], 1u) == (unsigned)(n_chunks - 1);   // ... before the ticket is taken
         __syncthreads();
         if (last_sh) {      // uniform over the workgroup: every chunk's tiles of this row group are in memory
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (have) {
                 f32x4 acc[HM];
 #pragma unroll
                 for (int t = 0; t < HM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float *src = part + (unit * 16 + i) * H + 4 * g;
-                constexpr int CU_ = HM >= 8 ? 2 : 4;   // chunks in flight (HM float4 loads each)
-                int c = 0;
-                for (; c + CU_ <= n_chunks; c += CU_) {
-                    float4 v[CU_][HM];
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(part + (unit * 16 + i) * H + 4 * g);
+                constexpr int CU_ = 32 / HM;   // chunks in flight (2 HM 8-byte loads each: 128 registers)
+                for (int c = 0; c < n_chunks; c += CU_) {
+                    unsigned long long v[CU_][HM][2];
 #pragma unroll
                     for (int cc = 0; cc < CU_; ++cc)
 #pragma unroll
                         for (int t = 0; t < HM; ++t)
-                            v[cc][t] = *reinterpret_cast<const float4 *>(src + (int64_t)(c + cc) * rows_padded * H + 16 * t);
 #pragma unroll
-                    for (int cc = 0; cc < CU_; ++cc)   // (chunk order: the sum does not depend on which workgroup arrived last)
+                            for (int hh = 0; hh < 2; ++hh)
+                                v[cc][t][hh] = c + cc < n_chunks ? __hip_atomic_load(src + ((int64_t)(c + cc) * rows_padded * H) / 2 + 8 * t + hh,
+                                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
-                        for (int t = 0; t < HM; ++t) {
-                            acc[t][0] += v[cc][t].x; acc[t][1] += v[cc][t].y; acc[t][2] += v[cc][t].z; acc[t][3] += v[cc][t].w;
-                        }
+                    for (int cc = 0; cc < CU_; ++cc)   // (chunk order: the sum does not depend on which workgroup arrived last;
+                        if (c + cc < n_chunks)         //  a chunk past the end adds nothing — not even + 0.0, which would turn -0.0 into +0.0)
+#pragma unroll
+                            for (int t = 0; t < HM; ++t) {
+                                acc[t][0] += __uint_as_float((unsigned)v[cc][t][0]); acc[t][1] += __uint_as_float((unsigned)(v[cc][t][0] >> 32));
+                                acc[t][2] += __uint_as_float((unsigned)v[cc][t][1]); acc[t][3] += __uint_as_float((unsigned)(v[cc][t][1] >> 32));
+                            }
                 }
-                for (; c < n_chunks; ++c)
-#pragma unroll
-                    for (int t = 0; t < HM; ++t) {
-                        const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)c * rows_padded * H + 16 * t);
-                        acc[t][0] += v.x; acc[t][1] += v.y; acc[t][2] += v.z; acc[t][3] += v.w;
-                    }
                 first_epilogue<HM, TRAIN, EVAL>(A, unit, acc, w2l, b1g, i, g);
             }
             if (threadIdx.x == 0) tickets[rg] = 0u;   // (for the next call: the tickets are all-zero between launches)

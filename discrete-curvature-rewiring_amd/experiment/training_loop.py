@@ -177,6 +177,7 @@ class GraphedEpoch:
         # Checked once here (a host sync before anything is captured); labels they do not cover go the stock way.
         # Only the GRADIENT of the fused loss is bit-identical to F.nll_loss's (-1/m at the picked entries); the loss VALUE is
         # reduced in float64 and rounded once, so loss.item() may differ from the stock op in the last ulp.
+        self._one = torch.ones((), dtype=torch.float32, device=data.x.device)   # d loss / d loss, kept (no fill launch per step)
         self.fused_labels = bool(data.y.dtype == torch.int64 and self.y_train.is_contiguous() and self.y_val.is_contiguous()
                                  and self.y_train.numel() > 0 and int(self.y_train.min()) >= 0 and int(self.y_val.min()) >= 0)
         self._n_classes_checked = None
@@ -231,7 +232,7 @@ class GraphedEpoch:
         else:
             log_probs = self.model(self.data, rows=self.train_idx) if self.rows else self.model(self.data)
             loss = self._nll(log_probs)
-        loss.backward()
+        loss.backward(self._one if loss.dtype == torch.float32 else None)
         self.optimizer.step()
         return loss
 
@@ -305,7 +306,7 @@ class LaggedGraphedEpoch(GraphedEpoch):
         head = self._head(True, True)
         if head is not None:
             loss, correct_prev = head
-            loss.backward()
+            loss.backward(self._one)
             self.optimizer.step()
             return correct_prev
         if self.rows:

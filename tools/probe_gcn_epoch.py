@@ -9,8 +9,8 @@ from dcr.data import Data, Dataset
 from models.gcn import GCN
 from experiment.training_loop import make_epoch
 dev = torch.device('cuda', 0)
-n, F, H, C = int(os.environ.get('N', 1000000)), 256, 128, 16
-ei_np, n = synthetic.powerlaw_graph(n, 10, seed=12345)
+n, F, H, C = int(os.environ.get('N', 1000000)), int(os.environ.get('F', 256)), int(os.environ.get('H', 128)), int(os.environ.get('C', 16))
+ei_np, n = synthetic.powerlaw_graph(n, int(os.environ.get('M', 10)), seed=12345)
 ei = torch.from_numpy(ei_np).to(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(n, F, device=dev, generator=g)
@@ -19,10 +19,11 @@ r = torch.rand(n, device=dev, generator=g)
 data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=r < 0.1, val_mask=(r >= 0.1) & (r < 0.2))
 torch.manual_seed(0)
 model = GCN(Dataset(data, C), hidden=[H], dropout=0.5).to(dev)
-opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                        {'params': model.reg_params, 'weight_decay': 5e-4}], lr=0.01, capturable=True, fused=os.environ.get('ADAM_FUSED', '1') == '1')
-if os.environ.get('EAGER') == '1':
-    os.environ['DCR_EPOCH_GRAPH'] = '0'
+from experiment.save_models import make_adam
+mode = os.environ.get('DCR_FUSED_ADAM', '2')     # 2: experiment/adam.py (one launch), 1: torch fused, 0: torch stock
+os.environ['DCR_FUSED_ADAM'] = mode
+opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                 {'params': model.reg_params, 'weight_decay': 5e-4}], 0.01, dev, fused=None if mode == '2' else mode == '1')
 epoch = make_epoch(model, opt, data, lagged=True)
 for _ in range(6):
     epoch()
@@ -32,4 +33,4 @@ t = time.perf_counter()
 for _ in range(E):
     epoch()
 torch.cuda.synchronize()
-print(f'epoch ms {(time.perf_counter() - t) / E * 1e3:.3f} driver {type(epoch).__name__}', flush=True)
+print(f'epoch ms {(time.perf_counter() - t) / E * 1e3:.3f} driver {type(epoch).__name__} adam {type(opt).__name__} head {os.environ.get("DCR_FUSED_HEAD", "1")}', flush=True)

@@ -1,9 +1,9 @@
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pg && EAGER=1 EPOCHS=6 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/pg -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_gcn_epoch.py > /dev/null 2>&1; python3 - <<'PY'
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pg && EPOCHS=6 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/pg -o p -- python3 $GRAFT_REPO_ROOT/tools/probe_gcn_epoch.py > /dev/null 2>&1; python3 - <<'PY'
 import csv
 rows = list(csv.DictReader(open('/tmp/pg/p_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last epoch: from the last k_first_layer_fwd back to the one before
-idx = [i for i, r in enumerate(rows) if 'k_first_layer_fwd' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_first_layer_fwd' in r['Kernel_Name'] or 'k_first_layer_wide' in r['Kernel_Name']]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b]:
