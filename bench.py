@@ -332,7 +332,7 @@ def gcn_cpu_baseline(ei_np, n, F, H, C, epochs=1):
             'ms_per_epoch': el / epochs * 1e3}
 
 
-def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, epochs=200):
+def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, epochs=200, route=None):
     """BASELINE.json configs[3] shape (Citeseer-LCC: 2,120 nodes, 3,703 features, hidden 64, 6 classes; hyper-parameters
     of utils/hyperparams.py) on a synthetic graph of that size: epochs/sec of train step + validation forward."""
     import torch
@@ -349,23 +349,43 @@ def gcn_small_shape(n, m, n_feat, hidden, n_cls, dropout, lr, wd, local_rank, ep
     r = torch.rand(n, device=dev, generator=g)
     data = Data(x=x, edge_index=torch.from_numpy(ei_np).to(dev), y=y, num_nodes=n, train_mask=r < 0.1,
                 val_mask=(r >= 0.1) & (r < 0.4))
-    torch.manual_seed(0)
-    model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=dropout).to(dev)
-    from experiment.save_models import make_adam
-    opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
-                     {'params': model.reg_params, 'weight_decay': wd}], lr, dev,
-                    fused=None if os.environ.get('DCR_FUSED_ADAM', '2') == '2' else os.environ.get('DCR_FUSED_ADAM') == '1')
-    # the epoch as experiment/training_loop.py runs it: eager for the first calls, then two captured HIP graphs
-    epoch = make_epoch(model, opt, data, lagged=True)
-    for _ in range(10):
-        epoch()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(epochs):
-        epoch()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    # route: which first layer (models/gcn.py).  None: the package's choice — for these features (0.9 % non-zeros) Â·(X·W1ᵀ) over the
+    # non-zeros of X; 'dense_mfma': the K-chunked MFMA kernel on Â·X (DCR_SPARSE_X=0); 'library': the GEMM library on Â·X + the
+    # fused activation kernel (DCR_SPARSE_X=0 DCR_FIRST_FUSED=0: the route of rounds 1-4)
+    saved = {k: os.environ.get(k) for k in ('DCR_SPARSE_X', 'DCR_FIRST_FUSED')}
+    if route in ('dense_mfma', 'library'):
+        os.environ['DCR_SPARSE_X'] = '0'
+    if route == 'library':
+        os.environ['DCR_FIRST_FUSED'] = '0'
+    try:
+        torch.manual_seed(0)
+        model = GCN(Dataset(data, n_cls), hidden=[hidden], dropout=dropout).to(dev)
+        from experiment.save_models import make_adam
+        opt = make_adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                         {'params': model.reg_params, 'weight_decay': wd}], lr, dev,
+                        fused=None if os.environ.get('DCR_FUSED_ADAM', '2') == '2' else os.environ.get('DCR_FUSED_ADAM') == '1')
+        # the epoch as experiment/training_loop.py runs it: eager for the first calls, then the captured HIP graph
+        epoch = make_epoch(model, opt, data, lagged=True)
+        for _ in range(10):
+            epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            epoch()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        first_route = ('sparse input: X in CSR, pre = A_hat (X W1^T) + b1 (two aggregations), then dcr_act_linear_fwd_f32_dev'
+                       if model.layers[0].sparse_input(x) is not None else
+                       'dense, one MFMA kernel on A_hat X (K-chunked: dcr_first_layer_fwd_ws_f32_dev)' if os.environ.get('DCR_FIRST_FUSED', '1') != '0'
+                       else 'dense, GEMM library on A_hat X + dcr_act_linear_fwd_f32_dev')
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     return {'metric': 'GCN epochs/sec', 'value': epochs / el, 'unit': 'epochs/sec', 'ms_per_epoch': el / epochs * 1e3,
+            'first_layer_route': first_route, 'feature_density': float(torch.count_nonzero(x)) / x.numel(),
             'dtype': 'f32', 'hip_graph': type(epoch).__name__ in ('GraphedEpoch', 'LaggedGraphedEpoch'), 'epoch_driver': type(epoch).__name__, 'config': {'workload': f'Citeseer-shaped synthetic graph N={n} E={ei_np.shape[1] // 2}, '
                                                    f'F={n_feat}, hidden={hidden}, classes={n_cls}, dropout {dropout}, '
                                                    f'Adam lr {lr} wd {wd}; epoch = train step + val forward'}}
@@ -830,6 +850,11 @@ def main():
             if world == 1:
                 try:
                     out['gcn_citeseer_shape'] = gcn_small_shape(2120, 2, 3703, 64, 6, 0.4103, 0.0199, 0.4551, local_rank)
+                    # "measure both orders and keep the faster" (round-4 verdict): the same epoch through the other two first layers
+                    out['gcn_citeseer_shape']['other_routes_ms_per_epoch'] = {
+                        r: gcn_small_shape(2120, 2, 3703, 64, 6, 0.4103, 0.0199, 0.4551, local_rank, route=r)['ms_per_epoch']
+                        for r in ('dense_mfma', 'library')}
+                    out['gcn_cora_shape'] = gcn_small_shape(2485, 2, 1433, 128, 7, 0.3396, 0.0244, 0.1076, local_rank)
                 except Exception as ex:  # noqa: BLE001
                     out['gcn_citeseer_shape'] = {'error': f'{type(ex).__name__}: {ex}'[:400]}
         if world == 1 and not args.no_cpu_baseline:

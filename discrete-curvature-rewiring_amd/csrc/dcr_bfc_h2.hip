@@ -365,6 +365,7 @@ __device__ inline void h2_retry_push(const H2Retry rt, int u, int d, int cls) { 
 #ifdef H2_UNIT_TIMES  // diagnostic build (tools/build_variant.sh ut -DH2_UNIT_TIMES): start and duration of every block-class unit
 constexpr unsigned H2_UT_CAP = 16384;
 __device__ int4 h2_ut[2 * H2_UT_CAP];  // {node, class | partitions << 16 | partition, s_memtime ticks, start tick / 16}, {ticks: clear + seed, sweep A, sweep B, third step}
+__device__ int4 h2_ut2[H2_UT_CAP];     // wave 0 of the unit: {ticks in the second sweep's drains, drains, items drained, -}
 __device__ unsigned h2_ut_n;
 __device__ long long h2_ut_t0;
 __global__ void k_h2_ut_mark() { h2_ut_t0 = (long long)__builtin_amdgcn_s_memtime(); h2_ut_n = 0u; }
@@ -769,6 +770,10 @@ struct H2Scratch {
     unsigned char plr[H2_PLCAP];  // ... and the row each was met in
     int pln;                      // how many (counting past the capacity)
     unsigned char trank[64];      // rank of each row of the batch among the rows present (its task is tbase + rank)
+#ifdef H2_UNIT_TIMES
+    long long ut_drain;           // ticks this wave spent in the second sweep's drains (diagnostic)
+    int ut_ndrain, ut_nitems;
+#endif
 #ifdef H2_PROF
     unsigned long long prof[16];
 #endif
@@ -1117,6 +1122,10 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Ta
                                 int nparts) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef H2_UNIT_TIMES
+    const long long ut_d0 = (long long)__builtin_amdgcn_s_memtime();
+    if (PHASE == 1 && lane == 0) { sc->ut_ndrain += 1; sc->ut_nitems += n; }
+#endif
     h2_wave_sync();
     int pln = PHASE == 2 ? sc->pln : 0;  // uniform
     for (int base = 0; base < n; base += 64) {
@@ -1156,6 +1165,9 @@ __device__ inline void h2_drain(const H2Tab t, H2Scratch *sc, int &n, const H2Ta
     }
     if (PHASE == 2 && lane == 0) sc->pln = pln;
     h2_wave_sync();
+#ifdef H2_UNIT_TIMES
+    if (PHASE == 1 && lane == 0) sc->ut_drain += (long long)__builtin_amdgcn_s_memtime() - ut_d0;
+#endif
     n = 0;
 }
 
@@ -1664,6 +1676,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)
         H2List ls = h2_list_of(tk.lists, NW);  // (fresh per unit)
 #ifdef H2_UNIT_TIMES
         const long long ut0 = (long long)__builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) { sc_all[wid].ut_drain = 0; sc_all[wid].ut_ndrain = 0; sc_all[wid].ut_nitems = 0; }
 #endif
         const bool unit_ok = h2_node<L1, EXS, NW, PARTS>(g, tk, al, u, ru, part, nparts, t, &sc_all[wid], rec, ls);
 #ifdef H2_UNIT_TIMES
@@ -1673,6 +1686,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3)
             if (slot < H2_UT_CAP) {
                 h2_ut[2 * slot] = make_int4(u, (PARTS ? 0x40000000 : 0) | (nparts << 16) | part, (int)(ut1 - ut0), (int)((ut0 - h2_ut_t0) >> 4));
                 h2_ut[2 * slot + 1] = make_int4((int)(ut_sh[0] - ut0), (int)(ut_sh[1] - ut_sh[0]), (int)(ut_sh[2] - ut_sh[1]), (int)(ut1 - ut_sh[2]));
+                h2_ut2[slot] = make_int4((int)sc_all[0].ut_drain, sc_all[0].ut_ndrain, sc_all[0].ut_nitems, 0);
             }
         }
 #endif
@@ -2202,6 +2216,8 @@ static void h2_print_unit_times(dcr_graph *g) {
     (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(h2_ut_n), sizeof(n));
     if (n > H2_UT_CAP) n = H2_UT_CAP;
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(h2_ut), sizeof(int4) * 2 * n);
+    static int4 h2[H2_UT_CAP];
+    (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(h2_ut2), sizeof(int4) * n);
     std::vector<int2> ri(g->n);
     std::vector<int32_t> wt(g->n);
     (void)hipMemcpy(ri.data(), g->rowinfo, sizeof(int2) * g->n, hipMemcpyDeviceToHost);
@@ -2227,8 +2243,8 @@ static void h2_print_unit_times(dcr_graph *g) {
                 h[2 * v[v.size() / 100]].z / 1e3, h[2 * v[0]].z / 1e3);
         for (size_t i = 0; i < v.size() && i < 8; ++i) {
             const int4 a = h[2 * v[i]], b = h[2 * v[i] + 1];
-            fprintf(stderr, "    node %6d deg %5d W %8d part %d/%d: %7.1f kticks (clear + seed %.1f, A %.1f, B %.1f, third %.1f), started at %.1f\n", a.x, ri[a.x].y,
-                    wt[a.x] & 0x7FFFFFFF, a.y & 0xFFFF, (a.y >> 16) & 0x3FFF, a.z / 1e3, b.x / 1e3, b.y / 1e3, b.z / 1e3, b.w / 1e3, (a.w * 16.0 - first) / 1e3);
+            fprintf(stderr, "    node %6d deg %5d W %8d part %d/%d: %7.1f kticks (clear + seed %.1f, A %.1f, B %.1f, third %.1f); wave 0 in B: %d drains of %d items, %.1f kticks\n", a.x, ri[a.x].y,
+                    wt[a.x] & 0x7FFFFFFF, a.y & 0xFFFF, (a.y >> 16) & 0x3FFF, a.z / 1e3, b.x / 1e3, b.y / 1e3, b.z / 1e3, b.w / 1e3, h2[v[i]].y, h2[v[i]].z, h2[v[i]].x / 1e3);
         }
     }
 }

@@ -777,6 +777,68 @@ def first_layer_fused_ok(x, act_fn, first, lin2):
     return bool(_lib.lib().dcr_first_layer_fits(int(first.lin.weight.shape[1]), int(first.lin.weight.shape[0]), int(lin2.weight.shape[0])))
 
 
+class SparseInput:
+    """The node features as a sparse operand (round 5).  Planetoid features are row-normalised bags of words, ~0.9 % dense
+    (experiment/data_loader.py reads them; bench.py generates that density): X·W1ᵀ over the non-zeros is ~100 x fewer products
+    than the dense contraction of the propagated Â·X (which is ~4-5 % dense), so for such inputs the first layer keeps PyG's
+    order of operations — lin first, then the aggregation — with X in CSR and, for the weight gradient, Xᵀ in CSR:
+        forward   pre = Â·(X·W1ᵀ) + b1            two aggregations (dcr_spmm_csr_f32_dev), the first over X's non-zeros
+        backward  dW1ᵀ = Xᵀ·(Âᵀ·dpre)            two more
+    Built once per (x, graph) by ``GCNConv.sparse_input``."""
+
+    def __init__(self, x):
+        n, f = x.shape
+        idx = x.nonzero()                                   # row-major order
+        rows, cols = idx[:, 0], idx[:, 1]
+        self.n, self.f, self.nnz = n, f, int(rows.numel())
+        self.val = x[rows, cols].contiguous()
+        self.rowptr = torch.zeros(n + 1, dtype=torch.int64, device=x.device)
+        torch.cumsum(torch.bincount(rows, minlength=n), 0, out=self.rowptr[1:])
+        self.col = cols.to(torch.int32).contiguous()
+        order = torch.argsort(cols * n + rows)              # Xᵀ: by column, rows ascending inside one
+        self.rowptr_t = torch.zeros(f + 1, dtype=torch.int64, device=x.device)
+        torch.cumsum(torch.bincount(cols, minlength=f), 0, out=self.rowptr_t[1:])
+        self.col_t = rows[order].to(torch.int32).contiguous()
+        self.val_t = self.val[order].contiguous()
+
+
+class _SparseFirstFn(torch.autograd.Function):
+    """pre = Â·(X·W1ᵀ) + b1 with X sparse (``SparseInput``); see there."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, xs, csr):
+        w1t = w1.t().contiguous()                           # [F, H]: the rows the non-zeros of X gather
+        h = spmm(xs.rowptr, xs.col, xs.val, w1t, xs.n)
+        ctx.xs, ctx.csr, ctx.has_bias = xs, csr, b1 is not None
+        return spmm(csr.rowptr, csr.col, csr.val, h, csr.n_rows, bias=b1)
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, csr = ctx.xs, ctx.csr
+        g = g.contiguous()
+        gw1 = gb1 = None
+        if ctx.needs_input_grad[0]:
+            dh = spmm(csr.rowptr_t, csr.col_t, csr.val_t, g, csr.n_cols)
+            gw1 = spmm(xs.rowptr_t, xs.col_t, xs.val_t, dh, xs.f).t()    # [H, F] as a view of the [F, H] product
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            ready = getattr(g, '_dcr_colsum', None)         # left there by the kernel that produced this gradient
+            if ready is not None and ready[:2] == (g.data_ptr(), g._version):
+                gb1 = ready[2]
+                _LinearFn.colsum_handoffs += 1
+            else:
+                gb1 = g.sum(0)
+        return gw1, gb1, None, None
+
+
+def sparse_input_density():
+    """Largest share of non-zeros for which the first layer takes the sparse-input route (``DCR_SPARSE_X``, default 0.1;
+    0 switches it off)."""
+    try:
+        return float(os.environ.get('DCR_SPARSE_X', '0.1'))
+    except ValueError:
+        return 0.1
+
+
 class _Linear(torch.nn.Module):
     """torch_geometric.nn.dense.linear.Linear(in, out, bias=False, weight_initializer='glorot')."""
 
@@ -818,6 +880,7 @@ class GCNConv(torch.nn.Module):
         self._ax_key = None
         self._ax = None
         self._ax_ref = None
+        self._xs_key = self._xs = self._xs_ref = None
         self._rowsel = {}
 
     def reset_parameters(self):
@@ -844,10 +907,25 @@ class GCNConv(torch.nn.Module):
             self._ax_ref = x
         return self._ax
 
+    def sparse_input(self, x):
+        """``SparseInput`` of x when the first layer should take the sparse route (few non-zeros, fp32 on the GPU, HIP backend),
+        else None; decided and built once per tensor (same storage, same version: the tensor is held), one host sync."""
+        thr = sparse_input_density()
+        if not (thr > 0 and _AGG_BACKEND == 'hip' and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] >= 64
+                and not x.requires_grad):
+            return None
+        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), str(x.device), thr)
+        if key != self._xs_key:
+            dense = int(torch.count_nonzero(x))
+            self._xs = SparseInput(x) if dense <= thr * x.numel() else None
+            self._xs_key, self._xs_ref = key, x
+        return self._xs
+
     def invalidate(self):
         """Drop the cached Â and Â·x (they are rebuilt at the next forward)."""
         self._cache_key = self._cache_csr = self._cache_ref = None
         self._ax_key = self._ax = self._ax_ref = None
+        self._xs_key = self._xs = self._xs_ref = None
         self._rowsel = {}
 
     def row_selection(self, rows, csr):
@@ -877,6 +955,9 @@ class GCNConv(torch.nn.Module):
     def forward(self, x, edge_index, edge_weight=None):
         csr = self.norm_csr(edge_index, edge_weight, x.shape[0])
         if self.propagate_input_first and not x.requires_grad and x.dtype == torch.float32:
+            xs = self.sparse_input(x)
+            if xs is not None:                                           # Â·(X·Wᵀ) + b over X's non-zeros (SparseInput)
+                return _SparseFirstFn.apply(self.lin.weight, self.bias, xs, csr)
             return self.lin(self.propagated_input(x, csr), self.bias)   # (Â·X)·Wᵀ + b: one GEMM
         z = self.lin(x)                       # dense contraction on MFMA via the GEMM library
         return aggregate(z, self.bias, csr)   # sparse aggregation + bias: HIP kernel
@@ -919,6 +1000,8 @@ class GCN(torch.nn.Module):
             return None                                   # evaluation mode WITH a gradient: the stock modules
         if not first_layer_fused_ok(x, self.act_fn, first, second.lin):
             return None
+        if first.sparse_input(x) is not None:
+            return None                                   # few non-zeros: Â·(X·W1ᵀ) over them (GCNConv.forward), then act_then_linear
         csr = first.norm_csr(data.edge_index, data.edge_attr, x.shape[0])
         ax = first.propagated_input(x, csr, pad16=True)
         if want_train:

@@ -102,7 +102,7 @@ def _s1m_inputs(dev):
     return torch.from_numpy(ei).to(dev), n, x
 
 
-def _training_step_against_fp64(ei, n, x, n_cls, hidden, p, frac_train, tol=1e-5):
+def _training_step_against_fp64(ei, n, x, n_cls, hidden, p, frac_train, tol=1e-5, route='dense'):
     """One training step (experiment/training_loop.py:48-54: model.train(), NLL on the training rows, backward) through the
     one-kernel first layer + the row-selected aggregation: logits of the training rows and dW1, db1, dW2, db2 against a float64
     evaluation from the raw edge list, <= tol of the largest reference entry.  The float64 side uses the product's OWN
@@ -125,44 +125,52 @@ def _training_step_against_fp64(ei, n, x, n_cls, hidden, p, frac_train, tol=1e-5
         model.layers[0].bias.uniform_(-0.1, 0.1)
     model.train()
     assert gcn.first_layer_fused_ok(x, model.act_fn, model.layers[0], model.layers[1].lin)
+    sparse = model.layers[0].sparse_input(x) is not None        # few non-zeros: Â·(X·W1ᵀ) over them, then the activation kernel
+    assert sparse == (route == 'sparse'), (route, sparse)
     calls = {'n': 0}
-    real = gcn._FirstLayerFn.apply
+    fn = gcn._SparseFirstFn if sparse else gcn._FirstLayerFn
+    real = fn.apply
 
     def counting(*a):
         calls['n'] += 1
         return real(*a)
-    gcn._FirstLayerFn.apply = staticmethod(counting)
+    fn.apply = staticmethod(counting)
     try:
         ctr = gcn._dropout_counter(dev)
         c0 = ctr.clone()
         logp = model(data, rows=train_rows)                     # (the last aggregation at the rows the loss reads: the epoch's route)
     finally:
-        gcn._FirstLayerFn.apply = real
-    assert calls['n'] == 1                                      # the first layer went through the one kernel
+        fn.apply = real
+    assert calls['n'] == 1                                      # the first layer went through the route under test
     torch.nn.functional.nll_loss(logp, y[train_rows]).backward()
     got = {name: q.grad.double() for name, q in model.named_parameters()}
     # the product's activation pattern: the float32 pre-activation from the same kernel on the same inputs, the keep mask of
     # dropout call c0 from the stand-alone kernel (same Philox counters and bit layout: tests/test_gcn.py pins that)
-    ax = model.layers[0]._ax
     feats = x.shape[1]
     w1, b1, w2 = model.layers[0].lin.weight.detach(), model.layers[0].bias.detach(), model.layers[1].lin.weight.detach()
-    words = ctypes.c_int64()
-    _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n * hidden, ctypes.byref(words)))
-    bits = torch.zeros(words.value, dtype=torch.int64, device=dev)
-    pre = torch.empty(n, hidden, device=dev)
-    z = torch.empty(n, n_cls, device=dev)
-    ctr.copy_(c0)
-    cur = torch.cuda.current_stream(dev).cuda_stream
-    ws = gcn._first_layer_workspace(dev, cur, n, feats, hidden)
-    _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(ax.data_ptr(), ax.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), pre.data_ptr(),
-                                                         z.data_ptr(), None, n_cls, bits.data_ptr(), n, feats, hidden, n_cls, p,
-                                                         torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr(),
-                                                         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
-                                                         ctypes.c_void_p(cur)))
+    if sparse:
+        with torch.no_grad():
+            pre = gcn._SparseFirstFn.apply(w1, b1, model.layers[0].sparse_input(x), model.layers[0]._cache_csr)
+    else:
+        ax = model.layers[0]._ax
+        words = ctypes.c_int64()
+        _lib.check(_lib.lib().dcr_relu_dropout_bits_words(n * hidden, ctypes.byref(words)))
+        bits = torch.zeros(words.value, dtype=torch.int64, device=dev)
+        pre = torch.empty(n, hidden, device=dev)
+        z = torch.empty(n, n_cls, device=dev)
+        ctr.copy_(c0)
+        cur = torch.cuda.current_stream(dev).cuda_stream
+        ws = gcn._first_layer_workspace(dev, cur, n, feats, hidden)
+        _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(ax.data_ptr(), ax.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), pre.data_ptr(),
+                                                             z.data_ptr(), None, n_cls, bits.data_ptr(), n, feats, hidden, n_cls, p,
+                                                             torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr(),
+                                                             None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                                             ctypes.c_void_p(cur)))
+        del bits, z
     ctr.copy_(c0)
     keep = _ReluDropoutFn.apply(torch.ones(n, hidden, device=dev), p) != 0
     pattern = ((pre > 0) & keep).double() / (1.0 - p)
-    del pre, bits, z, keep
+    del pre, keep
     ref = [(l.lin.weight.detach().clone().double().requires_grad_(), l.bias.detach().clone().double().requires_grad_())
            for l in model.layers]
     (rw1, rb1), (rw2, rb2) = ref
@@ -198,8 +206,9 @@ def test_s1m_training_step_gradients_against_fp64():
     _training_step_against_fp64(ei, n, x, 16, 128, 0.5, 0.1)
 
 
+@pytest.mark.parametrize('route', ['dense', 'sparse'])
 @pytest.mark.parametrize('name,n,n_feat,n_cls', [('Citeseer', 2120, 3703, 6), ('Cora', 2485, 1433, 7)])
-def test_reference_dataset_shapes_training_step_through_the_one_kernel_first_layer(name, n, n_feat, n_cls):
+def test_reference_dataset_shapes_training_step_through_the_one_kernel_first_layer(name, n, n_feat, n_cls, route, monkeypatch):
     """configs[3] (round 5): the reference's own dataset shapes — Citeseer 3,703 -> 64 -> 6, Cora 1,433 -> 128 -> 7, hidden widths,
     dropout and rewiring parameters from utils/hyperparams.py — take the one-kernel first layer (W1 streamed through LDS in K
     chunks; before, the GEMM library): a training step on the REWIRED graph, logits and all four gradients <= 1e-5 of a float64
@@ -215,7 +224,10 @@ def test_reference_dataset_shapes_training_step_through_the_one_kernel_first_lay
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(n, n_feat, generator=g) < 0.0086).float()
     x = x / x.sum(1, keepdim=True).clamp_min(1.0)
-    _training_step_against_fp64(rewired.cuda(), n, x.cuda(), n_cls, hp['hidden_dim'], hp['dropout'], 0.3)
+    # route 'dense': the K-chunked MFMA kernel on Â·X (DCR_SPARSE_X=0); 'sparse' (the default for such features): Â·(X·W1ᵀ) over
+    # the non-zeros of X, then the fused activation kernel — "measure both orders and keep the faster" (bench.py reports both)
+    monkeypatch.setenv('DCR_SPARSE_X', '0' if route == 'dense' else '0.1')
+    _training_step_against_fp64(rewired.cuda(), n, x.cuda(), n_cls, hp['hidden_dim'], hp['dropout'], 0.3, route=route)
 
 
 def _s1m_worker(rank, world, port, rows_path, ret):

@@ -14,6 +14,9 @@ ei_np, n = synthetic.powerlaw_graph(n, int(os.environ.get('M', 10)), seed=12345)
 ei = torch.from_numpy(ei_np).to(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(n, F, device=dev, generator=g)
+if os.environ.get('SPARSEX') == '1':   # a row-normalised bag of words of Planetoid's density
+    x = (torch.rand(n, F, device=dev, generator=g) < 0.009).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1.0)
 y = torch.randint(0, C, (n,), device=dev, generator=g)
 r = torch.rand(n, device=dev, generator=g)
 data = Data(x=x, edge_index=ei, y=y, num_nodes=n, train_mask=r < 0.1, val_mask=(r >= 0.1) & (r < 0.2))
