@@ -843,6 +843,9 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
             for (int c = 0; c < 5; ++c) g->h2_last_count[c] = g->hres->h2_count[c];
         }
         if (g->hres->h2_status != 0) g->ext_part_valid = false;  // (the closing kernel wrote nothing)
+        // (advisor, round 4) a two-hop pass that ended with a status may have left its edge set partly patched (k_h2_eset_apply
+        // clears the journal before it applies it): the next two-hop pass rebuilds the set instead of trusting it
+        if (g->hres->h2_status != 0) g->h2_eset_valid = false;
         if (g->hres->h2_status != 0 && g->hres->misc[0] == 0) {
             // a table of the two-hop pass filled up (keys of a split node hashed unevenly) or a unit list overflowed:
             // nothing it wrote is kept, the node-centric kernels redo the whole pass
