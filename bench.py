@@ -28,9 +28,9 @@ for p in (REPO, PKG):
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 F32_MATRIX_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (MI355X_MICROARCH.md)
-PMC_PROFILE = 'r04_pmc_traffic.json'  # written by tools/pmc_traffic.sh on the GPU box, copied into profiles/
-PMC_BOUND = 'r04_pmc_bound.json'      # SQ wait / issue / LDS counters per kernel (tools/pmc_bound.sh): what binds the pass
-KERNEL_TIMES = 'r04_kernel_times.json'  # rocprofv3 --kernel-trace --stats of this bench (tools/kernel_times.sh), same hash rule
+PMC_PROFILE = 'r05_pmc_traffic.json'  # written by tools/pmc_traffic.sh on the GPU box, copied into profiles/
+PMC_BOUND = 'r05_pmc_bound.json'      # SQ wait / issue / LDS counters per kernel (tools/pmc_bound.sh): what binds the pass
+KERNEL_TIMES = 'r05_kernel_times.json'  # rocprofv3 --kernel-trace --stats of this bench (tools/kernel_times.sh), same hash rule
 
 
 def cpu_baseline(ei, n, E, budget_s=12.0):
