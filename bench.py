@@ -242,6 +242,29 @@ def gcn_bench(args, rank, world, local_rank, dist, gcn_graph=None):
             del model2, opt2, epoch2
         finally:
             os.environ.pop('DCR_GCN_ALL_ROWS', None)
+    if dist is None and not args.no_cpu_baseline:
+        # a deeper model on the same graph: Pubmed's hidden_depth = 3 (utils/hyperparams.py:23-30) — three hidden layers of 128, so
+        # two full aggregations at the hidden width per direction are on the epoch (the 2-layer model has none: A_hat X is
+        # pre-propagated and the last aggregation runs at the class width on the selected rows)
+        try:
+            torch.manual_seed(0)
+            model3 = GCN(Dataset(data, C), hidden=[H, H, H], dropout=0.5).to(dev)
+            opt3 = make_adam([{'params': model3.non_reg_params, 'weight_decay': 0},
+                              {'params': model3.reg_params, 'weight_decay': 5e-4}], 0.01, dev, fused=fused_adam)
+            epoch3 = make_epoch(model3, opt3, data, lagged=True)
+            for _ in range(6):
+                epoch3()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                epoch3()
+            sync()
+            res['hidden_depth_3'] = {'ms_per_epoch': (time.perf_counter() - t0) / 10 * 1e3, 'hidden': [H, H, H],
+                                     'epoch_driver': type(epoch3).__name__,
+                                     'note': 'Pubmed depth (hidden_depth 3): the hidden-width aggregations are on this epoch'}
+            del model3, opt3, epoch3
+        except Exception as ex:  # noqa: BLE001
+            res['hidden_depth_3'] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
     if dist is not None:
         res['rccl_ranks'] = dist.get_world_size()
         res['backend'] = dist.get_backend()

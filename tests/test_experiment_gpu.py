@@ -438,6 +438,39 @@ def test_head_kernels_against_the_stock_ops():
     assert torch.equal(l_only.detach(), loss.detach()) and torch.equal(c_only, correct)
 
 
+def test_forward_head_on_a_deeper_model():
+    """GCN.forward_head with three hidden layers (Pubmed's depth, utils/hyperparams.py:23-30): loss, count and gradients within
+    float32 rounding of forward_pair + the stock ops; a captured epoch of it runs."""
+    import torch.nn.functional as F
+    from dcr.data import Dataset
+    from experiment.training_loop import make_epoch, LaggedGraphedEpoch
+    from models.gcn import GCN
+    _, _, data = _gcn_case(0.0)
+    torch.manual_seed(4)
+    model = GCN(Dataset(data, 5), hidden=[64, 64, 64], dropout=0.0).to('cuda')
+    tr_idx, ev_idx = data.train_mask.nonzero().squeeze(1), data.val_mask.nonzero().squeeze(1)
+    y_tr, y_ev = data.y[tr_idx].contiguous(), data.y[ev_idx].contiguous()
+    model.train()
+    loss, correct = model.forward_head(data, rows_train=tr_idx, y_train=y_tr, rows_eval=ev_idx, y_eval=y_ev)
+    loss.backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    lp_tr, lp_ev = model.forward_pair(data, rows_train=tr_idx, rows_eval=ev_idx)
+    want = F.nll_loss(lp_tr, y_tr)
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want))) and int(correct) == int(lp_ev.max(1)[1].eq(y_ev).sum())
+    for a, p in zip(got, model.parameters()):
+        assert (a - p.grad).abs().max().item() <= 1e-5 * max(p.grad.abs().max().item(), 1e-12)
+    # (a fresh model for the captured epoch: this one has run eager backward passes on the default stream)
+    torch.manual_seed(4)
+    model2 = GCN(Dataset(data, 5), hidden=[64, 64, 64], dropout=0.5).to('cuda')
+    opt = torch.optim.Adam(model2.parameters(), lr=0.01, capturable=True)
+    epoch = make_epoch(model2, opt, data, lagged=True)
+    assert isinstance(epoch, LaggedGraphedEpoch)
+    accs = [epoch() for _ in range(8)]
+    assert all(0.0 <= a <= 1.0 for a in accs)
+
+
 def test_one_launch_adam_follows_torch_adam():
     """experiment/adam.py::OneLaunchAdam (dcr_adam_step_f32_dev, round 5) against torch.optim.Adam on the reference's wiring
     (save_models.py:78-82: two groups, weight decay on one): parameters and moments within float32 rounding after 25 steps,
