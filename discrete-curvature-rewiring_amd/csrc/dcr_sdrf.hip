@@ -573,7 +573,9 @@ __global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int
     if (threadIdx.x == 0) {
         cnt_sh = 0;
         c1_sh = 0;
-        if (a < dx) B.clsx[a] = cls;
+        // (what the closing workgroup reads of this one — clsx, rowcount, c1 — is stored through the L2 with agent-scope relaxed
+        //  atomics: see the ticket below)
+        if (a < dx) __hip_atomic_store(&B.clsx[a], cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const bool counting = curv_type == DCR_CURV_BFC && cls == 0;
@@ -630,11 +632,13 @@ __global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int
     if ((threadIdx.x & 63) == 0 && adm) atomicAdd(&cnt_sh, adm);
     __syncthreads();
     if (threadIdx.x == 0) {
-        B.rowcount[a] = cnt_sh;
-        if (a < dx) B.c1[a] = counting ? c1_sh : 0;
-#ifndef DCR_IMP_NOFENCE  // (timing-only build: is it the fences?)
-        __threadfence();  // this workgroup's results, then its ticket
-#endif
+        // Round 5: an agent-scope release fence writes back the whole L2 of its XCD (csrc/dcr_gcn_first.hip found 45 us of them in one
+        // kernel; here 1,400 workgroups' fences were 11 of this kernel's 44 us: the round-4 timing-only build).  The three words the
+        // closing workgroup reads of this one go through the L2 instead (sc1 stores), c2 is updated by device-scope atomics anyway,
+        // and all that orders them against the ticket is the wait for the stores (a workgroup-scope release).
+        __hip_atomic_store(&B.rowcount[a], cnt_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a < dx) __hip_atomic_store(&B.c1[a], counting ? c1_sh : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         last_sh = atomicAdd(&stp->done_rows, 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
@@ -819,7 +823,7 @@ __global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__
     __shared__ int last_sh;
     draw_block_sum(imp, res, tau, bsum);
     if (threadIdx.x == 0) {
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the block sum's store (sc1) has completed before the ticket is taken
         last_sh = atomicAdd(&st->done_draw, 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
@@ -843,7 +847,7 @@ __device__ void draw_block_sum(const double *__restrict__ imp, const DevResult *
         if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) __hip_atomic_store(&bsum[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (through the L2: no agent fence below)
 }
 
 __device__ void draw_pick_block(const double *__restrict__ imp, const int32_t *__restrict__ ci, const int32_t *__restrict__ cj,
