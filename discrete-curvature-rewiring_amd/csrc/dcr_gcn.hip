@@ -919,6 +919,23 @@ __device__ __forceinline__ float head_lse(const float (&o)[C], int classes) {
     return mx + logf(s);
 }
 
+// a row of raw outputs into registers: 16-byte loads where the row stride and the width allow (a thread reads its own 64-byte row:
+// one instruction per 16 bytes instead of one per float — the loads are what the kernel's time is)
+template <int C>
+__device__ __forceinline__ void head_load_row(const float *__restrict__ base, int64_t i, int64_t ld, int classes, bool vec, float (&o)[C]) {
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * q < classes) v = *reinterpret_cast<const float4 *>(base + i * ld + 4 * q);
+            o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = c < classes ? base[i * ld + c] : 0.f;
+    }
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) k_head_fwd(const float *__restrict__ o_tr, int64_t ld_tr, const int64_t *__restrict__ y_tr, int64_t m_tr,
                                                   int nb_tr, const float *__restrict__ o_ev, int64_t ld_ev, const int64_t *__restrict__ y_ev,
@@ -932,10 +949,10 @@ __global__ void __launch_bounds__(256) k_head_fwd(const float *__restrict__ o_tr
     unsigned long long hits = 0ull;
     if (b < nb_tr) {
         const int64_t per = (m_tr + nb_tr - 1) / nb_tr, lo = (int64_t)b * per, hi = lo + per < m_tr ? lo + per : m_tr;
+        const bool vec = (classes & 3) == 0 && (ld_tr & 3) == 0 && (((uintptr_t)o_tr) & 15) == 0;
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
             float o[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) o[c] = c < classes ? o_tr[i * ld_tr + c] : 0.f;
+            head_load_row<C>(o_tr, i, ld_tr, classes, vec, o);
             const int64_t t = y_tr[i];
             float pick = 0.f;
 #pragma unroll
@@ -946,11 +963,15 @@ __global__ void __launch_bounds__(256) k_head_fwd(const float *__restrict__ o_tr
     } else {
         const int be = b - nb_tr;
         const int64_t per = (m_ev + nb_ev - 1) / nb_ev, lo = (int64_t)be * per, hi = lo + per < m_ev ? lo + per : m_ev;
+        const bool vec = (classes & 3) == 0 && (ld_ev & 3) == 0 && (((uintptr_t)o_ev) & 15) == 0;
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-            const float *r = o_ev + i * ld_ev;
+            float r[C];
+            head_load_row<C>(o_ev, i, ld_ev, classes, vec, r);
             float best = r[0];
             int arg = 0;
-            for (int c = 1; c < classes; ++c) {  // first maximum; a NaN counts as the maximum (torch.max)
+#pragma unroll
+            for (int c = 1; c < C; ++c) {  // first maximum; a NaN counts as the maximum (torch.max)
+                if (c >= classes) break;
                 const float v = r[c];
                 if (!(best != best) && (v > best || v != v)) {
                     best = v;
@@ -971,14 +992,15 @@ __global__ void __launch_bounds__(256) k_head_fwd(const float *__restrict__ o_tr
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        ws->loss_part[b] = red[0];
-        ws->hit_part[b] = redh[0];
-        __threadfence();
+        // (the partials go through the L2 — sc1 stores — so that no agent-scope fence, an L2 write-back per block, is needed ahead
+        //  of the ticket: csrc/dcr_gcn_first.hip, round 5)
+        __hip_atomic_store(&ws->loss_part[b], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->hit_part[b], redh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         last_sh = atomicAdd(&ws->ticket_fwd, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last_sh) return;
-    __threadfence();
     // at most 256 partials of each kind (head_blocks): one per thread, then the same fixed tree as above.  (First version: one
     // thread adding them one after the other — 782 dependent L2 round trips, 111 us for a kernel whose work is 5 us.)
     red[threadIdx.x] = (int)threadIdx.x < nb_tr ? __hip_atomic_load(&ws->loss_part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
@@ -1010,19 +1032,26 @@ __global__ void __launch_bounds__(256) k_head_bwd(const float *__restrict__ o_tr
     float cs[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) cs[c] = 0.f;
+    const bool vec = (classes & 3) == 0 && (ld_tr & 3) == 0 && (((uintptr_t)o_tr) & 15) == 0 && (((uintptr_t)grad) & 15) == 0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        float o[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = c < classes ? o_tr[i * ld_tr + c] : 0.f;
+        float o[C], gv[C];
+        head_load_row<C>(o_tr, i, ld_tr, classes, vec, o);
         const float lse = head_lse<C>(o, classes);
         const int64_t t = y_tr[i];
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            if (c < classes) {
-                const float v = (expf(o[c] - lse) - ((int64_t)c == t ? 1.f : 0.f)) * scale;
-                grad[i * classes + c] = v;
-                cs[c] += v;
-            }
+        for (int c = 0; c < C; ++c) {
+            gv[c] = c < classes ? (expf(o[c] - lse) - ((int64_t)c == t ? 1.f : 0.f)) * scale : 0.f;
+            cs[c] += gv[c];
+        }
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q)
+                if (4 * q < classes) *reinterpret_cast<float4 *>(grad + i * classes + 4 * q) = make_float4(gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if (c < classes) grad[i * classes + c] = gv[c];
+        }
     }
     // column sums: inside a wave by a fixed butterfly, the four waves in wave order, the blocks in block order
 #pragma unroll
@@ -1034,15 +1063,13 @@ __global__ void __launch_bounds__(256) k_head_bwd(const float *__restrict__ o_tr
     }
     __syncthreads();
     if (threadIdx.x < (unsigned)HEAD_MAXC)
-        ws->col_part[blockIdx.x][threadIdx.x] = threadIdx.x < (unsigned)C ? ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x] : 0.f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last_sh = atomicAdd(&ws->ticket_bwd, 1u) == gridDim.x - 1;
-    }
+        __hip_atomic_store(&ws->col_part[blockIdx.x][threadIdx.x],
+                           threadIdx.x < (unsigned)C ? ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x] : 0.f,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();   // (waits for every thread's stores: the barrier carries a workgroup-scope fence)
+    if (threadIdx.x == 0) last_sh = atomicAdd(&ws->ticket_bwd, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!last_sh) return;
-    __threadfence();
     // the blocks' column sums: thread (column c, group j) adds blocks j, j + 8, ... (at most 32 independent loads), the eight
     // groups are then added in group order
     __shared__ float fin[8][HEAD_MAXC];
