@@ -42,6 +42,7 @@ struct FirstArgs {
     int64_t n_rows;
     int F, C;
     float scale; uint32_t threshold; uint64_t seed, offset;
+    const unsigned long long *dwords;   // the dropout decisions of this call drawn beforehand (dcr_dropout_words_dev; layout of `bits`), or null
 };
 
 // the lane's pointer into row (unit·16 + i) of Â·X (rows past the end read row 0: columns of the MFMA are independent, nothing
@@ -55,6 +56,23 @@ template <int CNT>
 __device__ __forceinline__ void first_load(const FirstArgs &A, int64_t u, int i, int g, float4 (&a0)[CNT]) {
 #pragma unroll
     for (int rt = 0; rt < CNT; ++rt) a0[rt] = *reinterpret_cast<const float4 *>(first_row_ptr(A, u + rt, i, g));
+}
+
+// The stamp behind the drawn decisions (k_dropout_words): the call they were drawn for.  A call whose (offset, seed, threshold,
+// rows) differ — the counter moved because something else drew from it, another seed — draws in line as if it had been
+// given none: correctness does not depend on the caller's discipline, only the time does.
+template <int HM>
+__device__ __forceinline__ bool dropout_words_current(const FirstArgs &A) {
+    constexpr int RPW = 64 / (4 * HM);
+    const unsigned long long *stamp = A.dwords + (A.n_rows + RPW - 1) / RPW * 4;
+    return stamp[0] == A.offset && stamp[1] == A.seed && stamp[2] == (unsigned long long)A.threshold && stamp[3] == (unsigned long long)A.n_rows;
+}
+// ... and, in the word after the stamp, the offset the NEXT call is expected to have: where the caller points the next
+// dcr_dropout_words_dev (its offset_dev), so that drawing ahead reads no counter another stream may be moving.
+template <int HM>
+__device__ __forceinline__ void dropout_words_next(const FirstArgs &A) {
+    constexpr int RPW = 64 / (4 * HM);
+    const_cast<unsigned long long *>(A.dwords)[(A.n_rows + RPW - 1) / RPW * 4 + 4] = A.offset + 1;
 }
 
 // The epilogue of one 16-row unit: + b1, pre stored, then k_act_linear_fwd's body (csrc/dcr_gcn.hip) on the registers — same
@@ -86,7 +104,23 @@ __device__ __forceinline__ void first_epilogue(const FirstArgs &A, int64_t unit,
     // the two halves of the same calls: each draws HM / 2 of the pair's HM calls and the words change lanes through
     // ds_bpermute (the LDS pipe) — half the Philox instructions, which on this chip are matrix-core time.
     uint32_t rw[HM][4];
-    if (TRAIN) {
+    // Round 5: the decisions may come drawn beforehand (A.dwords: one bit per element, packed exactly as `bits` is) by a kernel of
+    // their own that runs beside the request-rate-bound aggregations of the epoch before (experiment/training_loop.py): on this
+    // chip the Philox instructions of this epilogue add to the matrix core's time.
+    const bool drawn = TRAIN && A.dwords != nullptr;   // uniform
+    uint32_t fld[4] = {0u, 0u, 0u, 0u};
+    if (drawn) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long word = live ? A.dwords[(row / RPW) * 4 + q] : 0ull;
+            fld[q] = (uint32_t)(word >> ((row % RPW) * LPR));
+        }
+#pragma unroll
+        for (int t = 0; t < HM; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rw[t][q] = (fld[q] >> (4 * t + g)) & 1u;   // (the decision itself)
+    }
+    if (TRAIN && !drawn) {
         constexpr int HC = HM / 2;
         const int s = g & 1;
         uint32_t mine[HC][4], theirs[HC][4];
@@ -114,7 +148,7 @@ __device__ __forceinline__ void first_epilogue(const FirstArgs &A, int64_t unit,
             const uint32_t (&r)[4] = rw[t];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool keep = live && v[t][q] > 0.f && r[q] >= A.threshold;
+                const bool keep = live && v[t][q] > 0.f && (drawn ? r[q] != 0u : r[q] >= A.threshold);
                 o[q] = keep ? v[t][q] * A.scale : 0.f;
                 part[q] |= keep ? (1u << (4 * t + g)) : 0u;
             }
@@ -260,6 +294,11 @@ __global__ void __launch_bounds__(64 * FIRST_WAVES) k_first_layer_fwd(FirstArgs 
     }
     __syncthreads();
     if (TRAIN && offset_dev) A.offset += *offset_dev;
+    if (TRAIN && A.dwords) {
+        const bool current = dropout_words_current<HM>(A);
+        if (blockIdx.x == 0 && threadIdx.x == 0) dropout_words_next<HM>(A);
+        if (!current) A.dwords = nullptr;   // decisions of another call: draw in line
+    }
 
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t n_units = (A.n_rows + 15) / 16;
@@ -288,7 +327,8 @@ static size_t first_layer_lds_bytes(int F, int H) { return sizeof(float) * ((siz
 template <int HM, int NR>
 static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2, float *pre,
                               float *z_train, float *z_eval, int64_t ldz, unsigned long long *bits, int64_t n_rows, int F, int C, float scale,
-                              uint32_t threshold, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, hipStream_t st) {
+                              uint32_t threshold, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
+                              const unsigned long long *dwords, hipStream_t st) {
     static int cus_dev[64] = {};   // per device (advisor, round 4: a process may drive several GPUs)
     int dev = 0;
     DCR_HIP(hipGetDevice(&dev));
@@ -303,7 +343,7 @@ static int launch_first_layer(bool train, bool eval, const float *ax, int64_t ld
     if (grid > cus) grid = cus;
     const int64_t waves = grid * FIRST_WAVES;
     const int64_t upw = (n_units + waves - 1) / waves;
-    FirstArgs args{ax, ldx, pre, z_train, z_eval, ldz, bits, n_rows, F, C, scale, threshold, seed, offset};
+    FirstArgs args{ax, ldx, pre, z_train, z_eval, ldz, bits, n_rows, F, C, scale, threshold, seed, offset, dwords};
 #define DCR_FIRST_LAUNCH(TR, EV)                                                                                                       \
     do {                                                                                                                              \
         auto kern = k_first_layer_fwd<HM, NR, TR, EV>;                                                                                \
@@ -413,6 +453,11 @@ __global__ void __launch_bounds__(256, 2) k_first_layer_wide(FirstArgs A, const 
     }
     __syncthreads();
     if (TRAIN && offset_dev) A.offset += *offset_dev;
+    if (TRAIN && A.dwords) {
+        const bool current = dropout_words_current<HM>(A);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dropout_words_next<HM>(A);
+        if (!current) A.dwords = nullptr;   // decisions of another call: draw in line
+    }
 
     const float *w1l = w1s + i * FS;
     const float *w2l = w2s + i * HS;
@@ -508,7 +553,7 @@ template <int HM>
 static int launch_first_layer_wide(bool train, bool eval, const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2,
                                    float *pre, float *z_train, float *z_eval, int64_t ldz, unsigned long long *bits, int64_t n_rows, int F,
                                    int C, float scale, uint32_t threshold, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
-                                   float *ws, hipStream_t st) {
+                                   const unsigned long long *dwords, float *ws, hipStream_t st) {
     constexpr int H = 16 * HM;
     int dev = 0, cus = 0;
     DCR_HIP(hipGetDevice(&dev));
@@ -523,7 +568,7 @@ static int launch_first_layer_wide(bool train, bool eval, const float *ax, int64
     const size_t lds = sizeof(float) * ((size_t)H * wide_kch<HM>() + 16 * (size_t)H + H);
     float *part = ws;
     unsigned *tickets = reinterpret_cast<unsigned *>(ws + n_chunks * rows_padded * H);
-    FirstArgs args{ax, ldx, pre, z_train, z_eval, ldz, bits, n_rows, F, C, scale, threshold, seed, offset};
+    FirstArgs args{ax, ldx, pre, z_train, z_eval, ldz, bits, n_rows, F, C, scale, threshold, seed, offset, dwords};
 #define DCR_WIDE_LAUNCH(TR, EV)                                                                                                        \
     do {                                                                                                                              \
         auto kern = k_first_layer_wide<HM, TR, EV>;                                                                                   \
@@ -541,6 +586,45 @@ static int launch_first_layer_wide(bool train, bool eval, const float *ax, int64
 #undef DCR_WIDE_LAUNCH
     DCR_HIP(hipGetLastError());
     return DCR_OK;
+}
+
+// The dropout decisions of ONE call of the kernels above, drawn by a kernel of their own (round 5): thread per row, the row's
+// H / 8 Philox calls (call c = row · H/8 + k holds the element-quads 2k and 2k + 1 of the row in the low and high halves of its
+// four words), one keep bit per element packed as first_epilogue packs `bits`: bit e of the row's field of word q is the decision
+// for hidden column 4e + q — exactly what the kernels draw in line for the same (seed, offset); tests/test_gcn.py compares the
+// two bit for bit.
+template <int HM>
+__global__ void __launch_bounds__(256) k_dropout_words(unsigned long long *__restrict__ dwords, int64_t n_rows, uint32_t threshold, uint64_t seed,
+                                                       uint64_t offset, const uint64_t *__restrict__ offset_dev) {
+    constexpr int H = 16 * HM, LPR = H / 4, RPW = 64 / LPR, CALLS = LPR / 2;
+    if (offset_dev) offset += *offset_dev;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the call these decisions belong to (dropout_words_current)
+        unsigned long long *stamp = dwords + (n_rows + RPW - 1) / RPW * 4;
+        stamp[0] = offset; stamp[1] = seed; stamp[2] = threshold; stamp[3] = (unsigned long long)n_rows;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += (int64_t)gridDim.x * 256) {
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+        for (int k = 0; k < CALLS; ++k) {
+            uint32_t r[4];
+            philox4x32_10((uint64_t)(row * CALLS + k), offset, seed, r);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                m[q] |= ((r[q] & 0xFFFFu) >= threshold ? 1u : 0u) << (2 * k);
+                m[q] |= ((r[q] >> 16) >= threshold ? 1u : 0u) << (2 * k + 1);
+            }
+        }
+        // the row's LPR-bit field of the four 64-bit words of its group of RPW rows (little-endian halves / quarters of a word)
+        if (LPR == 32) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(dwords + (row / RPW) * 4) + (row % RPW);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[2 * q] = m[q];
+        } else {
+            uint16_t *dst = reinterpret_cast<uint16_t *>(dwords + (row / RPW) * 4) + (row % RPW);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[4 * q] = (uint16_t)m[q];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -902,15 +986,43 @@ extern "C" int dcr_first_layer_fwd_workspace(int64_t n_rows, int in_features, in
     return DCR_OK;
 }
 
+extern "C" int dcr_dropout_words_count(int64_t n_rows, int hidden, int64_t *words) {
+    if (!words || n_rows < 0 || (hidden != 64 && hidden != 128)) DCR_FAIL(DCR_EINVAL, "bad dropout_words_count arguments (hidden 64 or 128)");
+    const int rpw = 64 / (hidden / 4);
+    *words = (n_rows + rpw - 1) / rpw * 4 + 8;   // one bit per element, rows in groups of rpw; the stamp of the call; the next call's offset
+    return DCR_OK;
+}
+
+extern "C" int dcr_dropout_words_dev(uint64_t *dwords, int64_t n_rows, int hidden, double p, uint64_t seed, uint64_t offset,
+                                     const uint64_t *offset_dev, void *hip_stream) {
+    if (!dwords || n_rows < 0 || (hidden != 64 && hidden != 128) || !(p >= 0.0 && p < 1.0) || ((uintptr_t)dwords & 7))
+        DCR_FAIL(DCR_EINVAL, "bad dropout_words arguments (hidden 64 or 128, 0 <= p < 1)");
+    if (n_rows == 0) return DCR_OK;
+    const uint32_t threshold = dcr::dropout_threshold16(p);
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > 256) blocks = 256;   // a workgroup per CU, rows in a grid stride: beside another stream's kernels it takes the fewest wave slots
+                                      // (measured in the epoch: 8192 blocks 1.60 ms, 256 blocks 1.585 — profiles/r05_dropout_ahead.txt)
+    if (hidden == 128)
+        hipLaunchKernelGGL((dcr::k_dropout_words<8>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, (unsigned long long *)dwords,
+                           n_rows, threshold, seed, offset, offset_dev);
+    else
+        hipLaunchKernelGGL((dcr::k_dropout_words<4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, (unsigned long long *)dwords,
+                           n_rows, threshold, seed, offset, offset_dev);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
 extern "C" int dcr_first_layer_fwd_ws_f32_dev(const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2, float *pre,
-                                              float *z_train, float *z_eval, int64_t ldz, uint64_t *bits, int64_t n_rows, int in_features,
-                                              int hidden, int classes, double p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
-                                              float *ws, int64_t ws_floats, void *hip_stream) {
+                                              float *z_train, float *z_eval, int64_t ldz, uint64_t *bits, uint64_t *dwords_in,
+                                              int64_t n_rows, int in_features, int hidden, int classes, double p, uint64_t seed,
+                                              uint64_t offset, const uint64_t *offset_dev, float *ws, int64_t ws_floats, void *hip_stream) {
+    const unsigned long long *dwords = (const unsigned long long *)dwords_in;
     const bool train = z_train != nullptr, eval = z_eval != nullptr;
     const int f16 = (in_features + 15) / 16 * 16;
     if (!ax || !w1 || !w2 || n_rows < 0 || (!train && !eval) || ldx < f16) DCR_FAIL(DCR_EINVAL, "bad first_layer_fwd arguments (ldx >= in_features rounded up to 16)");
     if (train && (!bits || !pre || !(p >= 0.0 && p < 1.0)))
         DCR_FAIL(DCR_EINVAL, "first_layer_fwd: the training output needs bits, pre (the backward pass reads both) and 0 <= p < 1");
+    if (dwords && (!train || ((uintptr_t)dwords & 7))) DCR_FAIL(DCR_EINVAL, "first_layer_fwd: dropout words go with the training output (8-byte aligned)");
     if (!dcr_first_layer_fits(in_features, hidden, classes) || ldz < classes)
         DCR_FAIL(DCR_EINVAL, "first_layer_fwd: hidden 64 or 128, at most 16 classes, ldz >= classes (other shapes take the GEMM library and "
                              "dcr_act_linear_fwd_f32_dev)");
@@ -924,18 +1036,18 @@ extern "C" int dcr_first_layer_fwd_ws_f32_dev(const float *ax, int64_t ldx, cons
         if ((uintptr_t)w1 & 15) DCR_FAIL(DCR_EINVAL, "first_layer_fwd: 16-byte aligned W1 expected");
         if (hidden == 128)
             return launch_first_layer<8, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
-                                                       in_features, classes, scale, threshold, seed, offset, offset_dev, st);
+                                                       in_features, classes, scale, threshold, seed, offset, offset_dev, dwords, st);
         return launch_first_layer<4, DCR_FIRST_NR>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows,
-                                                   in_features, classes, scale, threshold, seed, offset, offset_dev, st);
+                                                   in_features, classes, scale, threshold, seed, offset, offset_dev, dwords, st);
     }
     if (!ws || ((uintptr_t)ws & 15) || ws_floats < dcr::wide_ws_floats(n_rows, in_features, hidden))
         DCR_FAIL(DCR_EINVAL, "first_layer_fwd: this width takes the K-chunked kernel, which needs dcr_first_layer_fwd_workspace floats (16-byte "
                              "aligned; the trailing tickets zero before the first use — every launch leaves them zero)");
     if (hidden == 128)
         return launch_first_layer_wide<8>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, in_features,
-                                          classes, scale, threshold, seed, offset, offset_dev, ws, st);
+                                          classes, scale, threshold, seed, offset, offset_dev, dwords, ws, st);
     return launch_first_layer_wide<4>(train, eval, ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, (unsigned long long *)bits, n_rows, in_features,
-                                      classes, scale, threshold, seed, offset, offset_dev, ws, st);
+                                      classes, scale, threshold, seed, offset, offset_dev, dwords, ws, st);
 }
 
 extern "C" int dcr_first_layer_fwd_f32_dev(const float *ax, int64_t ldx, const float *w1, const float *b1, const float *w2, float *pre,
@@ -943,8 +1055,8 @@ extern "C" int dcr_first_layer_fwd_f32_dev(const float *ax, int64_t ldx, const f
                                            int hidden, int classes, double p, uint64_t seed, uint64_t offset, const uint64_t *offset_dev,
                                            void *hip_stream) {
     // (the entry point of round 4: shapes whose W1 stays resident in LDS need no workspace)
-    return dcr_first_layer_fwd_ws_f32_dev(ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, bits, n_rows, in_features, hidden, classes, p, seed, offset,
-                                          offset_dev, nullptr, 0, hip_stream);
+    return dcr_first_layer_fwd_ws_f32_dev(ax, ldx, w1, b1, w2, pre, z_train, z_eval, ldz, bits, nullptr, n_rows, in_features, hidden, classes, p, seed,
+                                          offset, offset_dev, nullptr, 0, hip_stream);
 }
 
 extern "C" int dcr_first_layer_bwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats) {

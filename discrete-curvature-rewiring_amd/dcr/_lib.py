@@ -81,8 +81,10 @@ SIGNATURES = {
     'dcr_first_layer_fwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _f64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     'dcr_first_layer_fwd_workspace': (ctypes.c_int, [_i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
-    'dcr_first_layer_fwd_ws_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, ctypes.c_int, ctypes.c_int,
+    'dcr_first_layer_fwd_ws_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int,
                                                       ctypes.c_int, _f64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp, _i64, _vp]),
+    'dcr_dropout_words_count': (ctypes.c_int, [_i64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
+    'dcr_dropout_words_dev': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _f64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     'dcr_first_layer_bwd_workspace': (ctypes.c_int, [_i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]),
     'dcr_first_layer_bwd_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _f64, _vp]),

@@ -152,6 +152,14 @@ def evaluate(model, data, test):
     return {f'{split}_acc': _accuracy(log_probs, data.y, data[f'{split}_mask']) for split in splits}
 
 
+def _join_side_streams():
+    """A capture ends with every stream it forked joined: the side stream models/gcn.py draws the next epoch's dropout
+    decisions on (joined by the first layer's backward already; this covers a step without one)."""
+    from models import gcn as _gcn
+    if hasattr(_gcn, 'join_dropout_ahead'):
+        _gcn.join_dropout_ahead()
+
+
 class GraphedEpoch:
     """One epoch (training step, then validation accuracy) of a fixed (model, optimizer, data) triple.  The first
     ``WARMUP`` calls run eagerly on a side stream (they are real epochs: library handles, caches and the optimiser state
@@ -267,6 +275,7 @@ class GraphedEpoch:
             self.train_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.train_graph, stream=self.stream):
                 self.loss = self._train_step()
+                _join_side_streams()
             self.model.eval()
             self.eval_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.eval_graph, stream=self.stream):
@@ -341,6 +350,7 @@ class LaggedGraphedEpoch(GraphedEpoch):
             self.model.train()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.correct_prev = self._fused_step()
+                _join_side_streams()
         self.graph.replay()
         return self.correct_prev
 

@@ -644,6 +644,72 @@ def act_then_linear(x, act_fn, dropout, lin, want_train=True, want_eval=False):
     return z_tr, z_ev
 
 
+class _DropoutAhead:
+    """The dropout decisions of the NEXT training call of the one-kernel first layer, drawn on a side stream while the rest of
+    the current epoch runs (dcr_dropout_words_dev; round 5).  The Philox instructions of the decisions were most of the vector
+    work of k_first_layer_fwd, and on this chip vector instructions add to the matrix cores' time; drawn by a kernel of their
+    own they overlap the aggregations, which leave the vector units idle (they wait on their gathers).  The words carry the
+    stamp of the call they were drawn for — a call with another stamp (the counter moved: a second model, a forward without
+    the expected successor) draws in line, so the result never depends on this object, only the time does.
+
+    One per (device, rows, hidden, p); the side stream forks after the forward kernel and is joined before the next use of the
+    words: at the start of the layer's backward, or by ``join_dropout_ahead()`` (the epoch drivers call it before a capture
+    ends), or at the next forward."""
+
+    def __init__(self, device, n, hidden, p):
+        from dcr import _lib
+        words = ctypes.c_int64()
+        _lib.check(_lib.lib().dcr_dropout_words_count(n, hidden, ctypes.byref(words)))
+        self.words = torch.zeros(words.value, dtype=torch.int64, device=device)   # (stamp of no call: rows = 0)
+        self.next_offset_ptr = self.words.data_ptr() + 8 * (words.value - 4)
+        self.stream = torch.cuda.Stream(device)
+        self.device, self.n, self.hidden, self.p = device, int(n), int(hidden), float(p)
+        self.forked = False
+
+    def draw(self):
+        from dcr import _lib
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        _lib.check(_lib.lib().dcr_dropout_words_dev(self.words.data_ptr(), self.n, self.hidden, self.p,
+                                                    torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, self.next_offset_ptr,
+                                                    ctypes.c_void_p(self.stream.cuda_stream)))
+        self.forked = True
+
+    def join(self):
+        if self.forked:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self.forked = False
+
+
+_AHEAD = {}
+
+
+def _dropout_ahead(device, n, hidden, p):
+    """The _DropoutAhead of this shape, or None: not switched on (``DCR_DROPOUT_AHEAD=1``; OFF by default — measured on the
+    MI355X at the 1M-node shape, the forward kernel gains 23 us of its 700 inside the epoch (82 us back to back, where the
+    clock is lower) and the aggregation beside the drawing kernel loses 14: 1.585 ms per epoch against 1.589, within the noise;
+    profiles/r05_dropout_ahead.txt), or it would have to be created inside a stream capture (the epoch drivers run eager
+    epochs first, which create it)."""
+    if os.environ.get('DCR_DROPOUT_AHEAD', '0') != '1':
+        return None
+    key = (str(device), int(n), int(hidden), float(p))
+    ahead = _AHEAD.get(key)
+    if ahead is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if len(_AHEAD) >= 4:
+            old = _AHEAD.pop(next(iter(_AHEAD)))
+            old.join()
+        ahead = _AHEAD[key] = _DropoutAhead(device, n, hidden, p)
+    return ahead
+
+
+def join_dropout_ahead():
+    """Join every side stream drawing dropout decisions ahead into the current stream (before a stream capture ends)."""
+    for ahead in _AHEAD.values():
+        ahead.join()
+
+
 class _FirstLayerFn(torch.autograd.Function):
     """The first layer's GEMM on Â·X, bias, ReLU (+ dropout) and the second layer's lin in ONE kernel on the matrix cores
     (csrc/dcr_gcn_first.hip, dcr_first_layer_fwd_f32_dev): models/gcn.py:36-42 from ``x`` of the first GCNConv to the
@@ -682,14 +748,21 @@ class _FirstLayerFn(torch.autograd.Function):
             ctr = _dropout_counter(ax.device)
             pre = torch.empty((n, hidden), dtype=ax.dtype, device=ax.device)
         ws = _first_layer_workspace(ax.device, stream, n, feats, hidden)
+        ahead = _dropout_ahead(ax.device, n, hidden, p) if (want_train and p > 0.0 and n > 0) else None
+        if ahead is not None:
+            ahead.join()
         _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(
             ax.data_ptr(), ldx, w1.data_ptr(), None if b1 is None else b1.data_ptr(), w2.data_ptr(),
             None if pre is None else pre.data_ptr(), z_tr.data_ptr() if want_train else None,
-            z_ev.data_ptr() if want_eval else None, ldz, bits.data_ptr() if want_train else None, n, feats, hidden, classes,
+            z_ev.data_ptr() if want_eval else None, ldz, bits.data_ptr() if want_train else None,
+            None if ahead is None else ahead.words.data_ptr(), n, feats, hidden, classes,
             float(p), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr() if want_train else None,
             None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), ctypes.c_void_p(stream)))
+        ctx.ahead = ahead
         if want_train:
             ctr.add_(1)
+            if ahead is not None:
+                ahead.draw()   # the next call's decisions, beside whatever this stream does next
             ctx.save_for_backward(ax, w2)
             ctx.pre, ctx.bits, ctx.p, ctx.has_bias, ctx.feats = pre, bits, float(p), b1 is not None, feats
         if want_eval:
@@ -700,6 +773,8 @@ class _FirstLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_tr, g_ev):
         from dcr import _lib
+        if ctx.ahead is not None:
+            ctx.ahead.join()   # (inside the same capture as the fork, when there is one)
         if g_tr is None:
             return None, None, None, None, None, None, None
         ax, w2 = ctx.saved_tensors

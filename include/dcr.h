@@ -289,9 +289,23 @@ int dcr_act_linear_bwd_colsum_f32_dev(const float *dz_dev, const float *w_dev, c
 int dcr_first_layer_fits(int in_features, int hidden, int classes);
 int dcr_first_layer_fwd_workspace(int64_t n_rows, int in_features, int hidden, int64_t *floats);
 int dcr_first_layer_fwd_ws_f32_dev(const float *ax_dev, int64_t ldx, const float *w1_dev, const float *b1_dev, const float *w2_dev,
-                                   float *pre_dev, float *z_train_dev, float *z_eval_dev, int64_t ldz, uint64_t *bits_dev, int64_t n_rows,
-                                   int in_features, int hidden, int classes, double p, uint64_t seed, uint64_t offset,
-                                   const uint64_t *offset_dev, float *ws_dev, int64_t ws_floats, void *hip_stream);
+                                   float *pre_dev, float *z_train_dev, float *z_eval_dev, int64_t ldz, uint64_t *bits_dev,
+                                   uint64_t *dwords_dev, int64_t n_rows, int in_features, int hidden, int classes, double p,
+                                   uint64_t seed, uint64_t offset, const uint64_t *offset_dev, float *ws_dev, int64_t ws_floats,
+                                   void *hip_stream);
+/* The dropout decisions of one training call of the kernels above, drawn ahead of it (round 5): dwords_dev
+ * [dcr_dropout_words_count words, 8-byte aligned] gets one bit per element of the n_rows x hidden activation, packed as
+ * bits_dev is — 1 where the Philox stream of (seed, offset + *offset_dev) keeps the element (F.dropout's mask,
+ * models/gcn.py:40, before the activation's sign is known) — followed by a stamp of the call it belongs to (offset + *offset_dev,
+ * seed, p, n_rows).  Handed to dcr_first_layer_fwd_ws_f32_dev as dwords_dev, a call with that very stamp reads its decisions
+ * there and gives bit for bit what it gives with dwords_dev == NULL; a call with any other stamp draws in line as if it had
+ * been given none.  Every training call given a dwords_dev also leaves, in word [dcr_dropout_words_count - 4], its own
+ * offset + 1: pointing the next dcr_dropout_words_dev's offset_dev there (offset 0) draws for the call expected next without
+ * reading a counter that other work may be moving.  models/gcn.py draws the next epoch's words on a side stream while the
+ * current epoch's aggregations run. */
+int dcr_dropout_words_count(int64_t n_rows, int hidden, int64_t *words);
+int dcr_dropout_words_dev(uint64_t *dwords_dev, int64_t n_rows, int hidden, double p, uint64_t seed, uint64_t offset,
+                          const uint64_t *offset_dev, void *hip_stream);
 int dcr_first_layer_fwd_f32_dev(const float *ax_dev, int64_t ldx, const float *w1_dev, const float *b1_dev, const float *w2_dev,
                                 float *pre_dev, float *z_train_dev, float *z_eval_dev, int64_t ldz, uint64_t *bits_dev, int64_t n_rows,
                                 int in_features, int hidden, int classes, double p, uint64_t seed, uint64_t offset,

@@ -471,6 +471,40 @@ def test_forward_head_on_a_deeper_model():
     assert all(0.0 <= a <= 1.0 for a in accs)
 
 
+def test_dropout_decisions_drawn_ahead_give_the_same_epochs(monkeypatch):
+    """``DCR_DROPOUT_AHEAD=1`` (models/gcn.py::_DropoutAhead: the next epoch's dropout decisions drawn on a side stream of the
+    captured epoch by dcr_dropout_words_dev, F.dropout of models/gcn.py:40): the same parameters bit for bit as drawing in line,
+    after eager and replayed epochs; the decisions in the buffer are the ones for the counter's next value."""
+    from dcr.data import Dataset
+    from experiment.training_loop import make_epoch, LaggedGraphedEpoch
+    from models import gcn
+    _, _, data = _gcn_case(0.5)
+    dev = data.x.device
+
+    def run(ahead):
+        monkeypatch.setenv('DCR_DROPOUT_AHEAD', '1' if ahead else '0')
+        gcn._AHEAD.clear()
+        gcn._dropout_counter(dev).zero_()
+        torch.manual_seed(8)
+        model = gcn.GCN(Dataset(data, 5), hidden=[64], dropout=0.5).to(dev)
+        opt = torch.optim.Adam([{'params': model.non_reg_params, 'weight_decay': 0},
+                                {'params': model.reg_params, 'weight_decay': 5e-3}], lr=0.02, capturable=True)
+        epoch = make_epoch(model, opt, data, lagged=True)
+        assert isinstance(epoch, LaggedGraphedEpoch)
+        accs = [epoch() for _ in range(7)]
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in model.parameters()], [float(a) for a in accs]
+    p_off, a_off = run(False)
+    assert not gcn._AHEAD
+    p_on, a_on = run(True)
+    (ahead,) = gcn._AHEAD.values()
+    assert int(ahead.words[-8].item()) == int(gcn._dropout_counter(dev).item()) >= 7   # drawn for the next call
+    assert a_on == a_off
+    for a, b in zip(p_on, p_off):
+        assert torch.equal(a, b)
+    gcn._AHEAD.clear()
+
+
 def test_one_launch_adam_follows_torch_adam():
     """experiment/adam.py::OneLaunchAdam (dcr_adam_step_f32_dev, round 5) against torch.optim.Adam on the reference's wiring
     (save_models.py:78-82: two groups, weight decay on one): parameters and moments within float32 rounding after 25 steps,

@@ -671,12 +671,25 @@ def test_first_layer_activation_and_next_lin_in_one_kernel(feats, hidden, classe
     assert (ws is None) == resident
     ws_ptr, ws_n = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
 
-    def forward(pre_t, both_t, bits_t):
+    def forward(pre_t, both_t, bits_t, dwords=None):
         ctr.copy_(c0)
         _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(axp.data_ptr(), f16, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), pre_t.data_ptr(),
                                                              both_t.data_ptr(), both_t.data_ptr() + 4 * classes, 2 * classes, bits_t.data_ptr(),
+                                                             None if dwords is None else dwords.data_ptr(),
                                                              n, feats, hidden, classes, p, seed, 0, ctr.data_ptr(), ws_ptr, ws_n, st))
     forward(pre, both, bits)
+    # the dropout decisions drawn ahead of the call (dcr_dropout_words_dev, the epoch driver's side stream): the same bits
+    dwords = torch.full_like(bits, -1)
+    ctr.copy_(c0)
+    _lib.check(_lib.lib().dcr_dropout_words_dev(dwords.data_ptr(), n, hidden, p, seed, 0, ctr.data_ptr(), st))
+    pre_d, both_d, bits_d = torch.empty_like(pre), torch.empty_like(both), torch.zeros_like(bits)
+    forward(pre_d, both_d, bits_d, dwords)
+    assert torch.equal(pre_d, pre) and torch.equal(bits_d, bits) and torch.equal(both_d, both)
+    assert torch.equal(bits & ~dwords, torch.zeros_like(bits))                     # bits = decisions AND (pre > 0)
+    rc = _lib.lib().dcr_first_layer_fwd_ws_f32_dev(axp.data_ptr(), f16, w1.data_ptr(), None, w2.data_ptr(), None, None, both_d.data_ptr(), classes,
+                                                   None, dwords.data_ptr(), n, feats, hidden, classes, 0.0, 0, 0, None, ws_ptr, ws_n, st)
+    assert rc != 0                                                                 # decisions without a training output
+    del pre_d, both_d, bits_d
     if ws is not None:
         n_groups = ((n + 15) // 16 + 3) // 4
         assert int(ws[-n_groups:].view(torch.int32).abs().sum().item()) == 0      # the tickets are zero again
@@ -746,7 +759,7 @@ def test_first_layer_activation_and_next_lin_in_one_kernel(feats, hidden, classe
     assert lib.dcr_first_layer_fits(3703, 64, 6) == 1 and lib.dcr_first_layer_fits(1433, 128, 7) == 1
     assert lib.dcr_first_layer_fits(256, 96, 16) == 0 and lib.dcr_first_layer_fits(256, 128, 17) == 0
     rc = lib.dcr_first_layer_fwd_ws_f32_dev(axp.data_ptr(), f16 - 4, w1.data_ptr(), None, w2.data_ptr(), None, None, both.data_ptr(),
-                                            classes, None, n, feats, hidden, classes, 0.0, 0, 0, None, ws_ptr, ws_n, st)
+                                            classes, None, None, n, feats, hidden, classes, 0.0, 0, 0, None, ws_ptr, ws_n, st)
     assert rc != 0                                                             # row stride below the padded width
     if ws is not None:
         rc = lib.dcr_first_layer_fwd_f32_dev(axp.data_ptr(), f16, w1.data_ptr(), None, w2.data_ptr(), None, None, both.data_ptr(),

@@ -162,7 +162,7 @@ def _training_step_against_fp64(ei, n, x, n_cls, hidden, p, frac_train, tol=1e-5
         cur = torch.cuda.current_stream(dev).cuda_stream
         ws = gcn._first_layer_workspace(dev, cur, n, feats, hidden)
         _lib.check(_lib.lib().dcr_first_layer_fwd_ws_f32_dev(ax.data_ptr(), ax.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), pre.data_ptr(),
-                                                             z.data_ptr(), None, n_cls, bits.data_ptr(), n, feats, hidden, n_cls, p,
+                                                             z.data_ptr(), None, n_cls, bits.data_ptr(), None, n, feats, hidden, n_cls, p,
                                                              torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 0, ctr.data_ptr(),
                                                              None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
                                                              ctypes.c_void_p(cur)))

@@ -37,3 +37,6 @@ for _ in range(E):
     epoch()
 torch.cuda.synchronize()
 print(f'epoch ms {(time.perf_counter() - t) / E * 1e3:.3f} driver {type(epoch).__name__} adam {type(opt).__name__} head {os.environ.get("DCR_FUSED_HEAD", "1")}', flush=True)
+from models import gcn as _g
+for key, ahead in getattr(_g, '_AHEAD', {}).items():   # decisions drawn ahead: the stamp's offset is the counter's value when the draw hit
+    print('dropout ahead', key, 'stamp', ahead.words[-8:-4].tolist(), 'next', int(ahead.words[-4].item()), 'counter', int(_g._dropout_counter(dev).item()), flush=True)
