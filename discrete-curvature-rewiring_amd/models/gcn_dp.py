@@ -75,6 +75,13 @@ class _GatherRows(torch.autograd.Function):
         return mine[:ctx.rows].contiguous(), None, None, None
 
 
+def chunked_gather():
+    """``DCR_DP_CHUNKED_GATHER=1``: the [Z_train | Z_eval] exchange of ``forward_pair`` as two asynchronous all-gathers, the
+    second under the first half's aggregation (off by default: DESIGN §5 — it hides at most the training half's
+    aggregation, and an asynchronous collective inside the captured epoch has never run on two GPUs here)."""
+    return os.environ.get('DCR_DP_CHUNKED_GATHER', '0') == '1'
+
+
 def _pad_rows(z, per):
     if z.shape[0] == per:
         return z
@@ -95,6 +102,25 @@ class _GatherAggregatePair(torch.autograd.Function):
         f = z_train.shape[1]
         ctx.csr, ctx.group, ctx.per, ctx.rows, ctx.has_bias = csr, group, per, z_train.shape[0], bias is not None
         ctx.sel = sel_train
+        if chunked_gather():
+            # The exchange in two halves (round 5, ``DCR_DP_CHUNKED_GATHER=1``): the training operand's all-gather, then the
+            # evaluation operand's, both asynchronous on the backend's own stream; the training half's aggregation runs
+            # while the evaluation half is still on the links.  The same bits: each half is aggregated exactly as the
+            # halves of the joint buffer are (``spmm_pair`` / ``dcr_spmm_csr_rows2_f32_dev``: "every block as a call of its own").
+            halves, works = [], []
+            for z in (z_train, z_eval):
+                local = _pad_rows(z, per).contiguous()
+                full = torch.empty((world * per, f), dtype=local.dtype, device=local.device)
+                works.append(dist.all_gather_into_tensor(full, local, group=group, async_op=True))
+                halves.append((full, local))          # (the send buffer stays alive until its wait)
+            outs = []
+            for (full, _), work, sel in zip(halves, works, (sel_train, sel_eval)):
+                work.wait()
+                if sel_train is not None:
+                    outs.append(spmm_rows(csr, sel, full[:n_total], bias))
+                else:
+                    outs.append(spmm(csr.rowptr, csr.col, csr.val, full[:n_total], csr.n_rows, bias))
+            return outs[0], outs[1]
         local = _pad_rows(torch.cat([z_train, z_eval], 1), per).contiguous()
         full = torch.empty((world * per, 2 * f), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(full, local, group=group)

@@ -265,6 +265,72 @@ def test_data_parallel_ranks_gloo(world):
         assert err_fwd < TOL and err_w < TOL and dacc < 1e-6, (rank, err_fwd, err_w, dacc)
 
 
+def _dp_chunked_worker(rank, world, port, ret):
+    """``DCR_DP_CHUNKED_GATHER=1`` (models/gcn_dp.py: the [Z_train | Z_eval] exchange as two asynchronous all-gathers, the
+    second under the first half's aggregation) against the one-shot exchange: the same bits in both outputs of
+    forward_pair — all rows and selected rows — and the same weights after two train_eval_step epochs."""
+    import copy
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dcr import synthetic
+    from dcr.data import Data, Dataset
+    from models import gcn as gcn_mod
+    from models.gcn import GCN
+    from models.gcn_dp import ShardedGCN
+    gcn_mod.set_aggregate_backend('torch')
+    ei_np, n = synthetic.powerlaw_graph(1501, 4, seed=23)                  # 1501: uneven blocks at 2 and at 8 ranks
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 12, generator=g)
+    y = torch.randint(0, 4, (n,), generator=g)
+    r = torch.rand(n, generator=g)
+    data = Data(x=x, edge_index=torch.from_numpy(ei_np), y=y, num_nodes=n, train_mask=r < 0.3, val_mask=(r >= 0.3) & (r < 0.6))
+    torch.manual_seed(9)
+    start = GCN(Dataset(data, 4), hidden=[16, 8], dropout=0.0)             # two exchanges per pass
+
+    def run(chunked):
+        os.environ['DCR_DP_CHUNKED_GATHER'] = '1' if chunked else '0'
+        model = copy.deepcopy(start)
+        sh = ShardedGCN(model, data.edge_index, n)
+        xl, yl, tl, vl = sh.shard(data.x), sh.shard(data.y), sh.shard(data.train_mask), sh.shard(data.val_mask)
+        sh.train()
+        with torch.no_grad():
+            all_rows = sh.forward_pair(xl)
+            s_tr, s_ev = sh.row_selection(tl.nonzero().squeeze(1)), sh.row_selection(vl.nonzero().squeeze(1))
+            some_rows = sh.forward_pair(xl, rows_train=s_tr, rows_eval=s_ev)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        stats = [sh.train_eval_step(opt, xl, yl, tl, vl, int(data.train_mask.sum())).clone() for _ in range(2)]
+        return all_rows, some_rows, [p.detach().clone() for p in model.parameters()], stats
+    real, n_async = dist.all_gather_into_tensor, [0]
+
+    def counting(*args, **kw):
+        n_async[0] += bool(kw.get('async_op'))
+        return real(*args, **kw)
+    dist.all_gather_into_tensor = counting
+    a = run(False)
+    assert n_async[0] == 0
+    b = run(True)
+    assert n_async[0] == 2 * 2 * 4                                          # two halves x two exchanges x (two forwards + two epochs)
+    dist.all_gather_into_tensor = real
+    os.environ.pop('DCR_DP_CHUNKED_GATHER')
+    same = (all(torch.equal(u, v) for u, v in zip(a[0], b[0])) and all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
+            and all(torch.equal(u, v) for u, v in zip(a[2], b[2])) and all(torch.equal(u, v) for u, v in zip(a[3], b[3])))
+    ret[rank] = (bool(same), int(a[1][0].shape[0]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_data_parallel_chunked_exchange_gloo(world):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_chunked_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    assert all(same for same, _ in ret.values()), dict(ret)
+    assert sum(rows for _, rows in ret.values()) > 0
+
+
 def _dp_world8_worker(rank, world, port, ret):
     """One of eight gloo ranks on a 20k-node power-law graph: degree-dealt partition, block-streamed set-up, logits of the
     sharded model against the single-process model (models/gcn.py:32-44) and one training step's weights."""

@@ -12,8 +12,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('world', [2, 4, 8])
-def test_nccl_ranks_graphed_epoch_equals_eager(world):
+@pytest.mark.parametrize('world,chunked', [(2, False), (4, False), (8, False), (2, True), (8, True)])
+def test_nccl_ranks_graphed_epoch_equals_eager(world, chunked):
+    """``chunked``: the same with ``DCR_DP_CHUNKED_GATHER=1`` (the exchange as two asynchronous all-gathers inside the capture)."""
     import torch
     if torch.cuda.device_count() < world:  # (counting devices does not initialise the GPU in this process)
         pytest.skip(f'needs {world} GPUs')
@@ -24,7 +25,8 @@ def test_nccl_ranks_graphed_epoch_equals_eager(world):
     procs = []
     for r in range(world):                 # fresh child processes, one per rank
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   DCR_DP_CHUNKED_GATHER='1' if chunked else '0')
         procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
