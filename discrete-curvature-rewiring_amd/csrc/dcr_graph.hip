@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(256) k_sdrf_tail(int2 *rowinfo, const int32_t 
                                                     int edit_rem) {
     const int tid = threadIdx.x;
     if (tid < 64) dev_add_edge(rowinfo, rowcap, col, u, v, res, tid);
-    __threadfence();
-    __syncthreads();
+    __threadfence_block();   // (one workgroup: its waves share the CU's cache, nothing has to reach the L2 before the barrier;
+    __syncthreads();         //  the agent-scope fences that stood here wrote the L2 back twice per iteration)
     int32_t au = u, av = v;
     bool mark = true;
     if (u == -2) {
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) k_sdrf_tail(int2 *rowinfo, const int32_t 
     if (st_add == 1 || st_add == 3) return;  // (uniform) add overflowed: replayed after a re-layout / no draw
     const bool doit = res->ext_slot >= 0 && res->ext_val > bound;
     if (doit) dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit_rem, tid, 256);
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
     if (tid >= 64) return;
     if (!doit) {

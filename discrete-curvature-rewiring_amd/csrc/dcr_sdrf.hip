@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(256) k_argext_edges_both(RowView g, int64_t ca
     if (threadIdx.x == 0) part_max[blockIdx.x] = ext_make(hi_v, hi_s);
 }
 
-__global__ void __launch_bounds__(1024) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
-                                                        DevResult *res) {
+// the one-workgroup reduction of the partial extrema into the result block (any workgroup size)
+__device__ inline void argext_final_body(const RowView &g, const Ext *partial, int nparts, int want_max, DevResult *res) {
     __shared__ double shv[16];
     __shared__ int shs[16];
     double best_v = 0.0;
@@ -147,6 +147,11 @@ __global__ void __launch_bounds__(1024) k_argext_final(RowView g, const Ext *par
         res->ext_du = best_s >= 0 ? g.rowinfo[eu].y : 0;
         res->ext_dv = best_s >= 0 ? g.rowinfo[ev].y : 0;
     }
+}
+
+__global__ void __launch_bounds__(1024) k_argext_final(RowView g, const Ext *partial, int nparts, int want_max,
+                                                        DevResult *res) {
+    argext_final_body(g, partial, nparts, want_max, res);
 }
 
 // first maximum of a plain array (np.argmax of the improvements, utils/softmax.py:7)
@@ -285,10 +290,19 @@ struct ImpBuf {
 // row y go into the table concurrently — a key met in both rows (a triangle node) is inserted by whichever thread comes first
 // and found by the other; which of the two it was does not matter, posx / posy are separate arrays.  The classes (0: in its
 // own row only, 1: in both, 2: the other endpoint) are resolved by the next kernel, when the table is complete.
-__global__ void k_imp_insert(RowView g, ImpBuf B, int x, int y, unsigned mask) {
+// Round 5: the removal step's stale arg-max (the reduction of the partial maxima the pass's closing kernel left; it depends on
+// nothing in the pipeline and writes other fields of the result block) rides on this launch as ONE MORE workgroup instead of
+// being a launch of its own between the pipeline and the draw (5.4 us of the iteration: profiles/r05_step_timeline.txt).
+__global__ void __launch_bounds__(256) k_imp_insert(RowView g, ImpBuf B, int x, int y, unsigned mask, const Ext *amax_parts, int amax_n,
+                                                     DevResult *res) {
+    const int nblocks = (int)gridDim.x - (amax_parts ? 1 : 0);
+    if ((int)blockIdx.x == nblocks) {  // (uniform: the extra workgroup)
+        argext_final_body(g, amax_parts, amax_n, 1, res);
+        return;
+    }
     const int2 rx = g.rowinfo[x], ry = g.rowinfo[y];
     const int total = rx.y + ry.y;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += nblocks * blockDim.x) {
         const bool isx = t < rx.y;
         const int p = isx ? t : t - rx.y;
         const int k = g.col[(isx ? rx.x : ry.x) + p];
@@ -643,7 +657,10 @@ __global__ void __launch_bounds__(256) k_imp_rows_count(RowView g, ImpBuf B, int
     }
     __syncthreads();
     if (!last_sh) return;  // uniform
-    __threadfence();       // every other workgroup's results are visible from here on
+    // every other workgroup's results are visible from here on: they went through the L2 (sc1 stores, device-scope atomics) before
+    // the tickets; this workgroup only has to drop what its own caches may hold (an agent-scope ACQUIRE: buffer_inv, no write-back
+    // of the L2 as __threadfence() has it)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     imp_close_stats(B, curv_type, shi);
     // exclusive scan of rowcount[0 .. rows): the candidates are emitted row by row (sdrf_no_cuda.py:32-37: outer loop over x_nb)
     const int rows = (int)gridDim.x;
@@ -828,7 +845,8 @@ __global__ void __launch_bounds__(256) k_draw_partial(const double *__restrict__
     }
     __syncthreads();
     if (!last_sh) return;  // uniform
-    __threadfence();
+    // (no agent fence: the block sums are read through the L2 — sc1 loads in draw_pick_block — and everything else this
+    //  workgroup reads was written by earlier kernels)
     draw_pick_block(imp, ci, cj, res, tau, u, bsum, margin_scale);
 }
 
@@ -942,7 +960,9 @@ using namespace dcr;
 
 // the improvement pipeline of one edge (x, y), enqueued on the library stream: candidates and their improvements end up in
 // g->imp_out / imp_ci / imp_cj, their number in the result block (n_cand); *upper_out = the bound (dx + 1)(dy + 1) on it
-static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_t *upper_out) {
+// amax_from_parts: the stale arg-max of the removal step reduced from the pass's partial maxima by one more workgroup of the
+// first launch (the caller has checked g->ext_part_valid and sets g->amax_valid)
+static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_t *upper_out, bool amax_from_parts = false) {
     int dx, dy;
     if (g->am_valid && g->am_x == x && g->am_y == y) {  // the arg-min step already brought the degrees over
         dx = g->am_dx;
@@ -1029,7 +1049,9 @@ static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_
     }
     g->imp_table_dirty = true;  // (until k_imp_emit below has been enqueued)
     const int gi = (dx + dy + 255) / 256 > 0 ? (dx + dy + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_imp_insert, dim3(gi), dim3(256), 0, g->stream, vw, B, x, y, mask);
+    const Ext *amax_parts = amax_from_parts ? (const Ext *)g->ext_part + EXT_PART_BLOCKS : nullptr;
+    hipLaunchKernelGGL(k_imp_insert, dim3(gi + (amax_parts ? 1 : 0)), dim3(256), 0, g->stream, vw, B, x, y, mask, amax_parts,
+                       amax_parts ? g->ext_part_n : 0, g->dres);
     hipLaunchKernelGGL(k_imp_rows_count, dim3(rows), dim3(256), (size_t)words * 4, g->stream, vw, B, x, y, mask, words, curv_type,
                        g->dres);
     if (dx + dy > 0)
@@ -1327,10 +1349,10 @@ int dcr_sdrf_iteration_device_draw(dcr_graph *g, int32_t x, int32_t y, int curv_
         DCR_HIP(hipEventRecord(g->ev_join[0], g->side[0]));
     }
     int64_t upper = 0;
-    DCR_TRY(imp_enqueue(g, x, y, curv_type, &upper));
+    if (amax_parts) g->amax_valid = false;  // the ext fields of the result block are about to be overwritten
+    DCR_TRY(imp_enqueue(g, x, y, curv_type, &upper, amax_parts));
     if (amax_parts) {
-        DCR_TRY(launch_argext_from_parts(g, 1));
-        g->amax_valid = true;
+        g->amax_valid = true;   // (reduced by one more workgroup of the pipeline's first launch)
     } else if (amax) {
         DCR_HIP(hipStreamWaitEvent(g->stream, g->ev_join[0], 0));
         g->amax_valid = true;
