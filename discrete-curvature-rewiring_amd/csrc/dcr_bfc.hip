@@ -803,11 +803,14 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     g->amax_valid = false;
     g->ext_part_valid = false;  // (set again by the two-hop pass's closing kernel)
     // first minimum in G.edges order, same host sync as the pass: from the closing kernel's per-block minima when it left some
+    bool dirty_clear_pending = false;   // the node flags still to be zeroed: by the sweep for the extrema when one follows
     auto argmin_after_pass = [&]() -> int {
         // (a pass of the node-centric kernels — incremental ones above all — leaves no partial extrema: ONE sweep takes both,
         //  the stale arg-max of the removal step then is a 5 us reduction as behind the two-hop pass; DCR_ARGEXT_BOTH=0: two sweeps)
         static const bool both = !(getenv("DCR_ARGEXT_BOTH") && atoi(getenv("DCR_ARGEXT_BOTH")) == 0);
-        if (!g->ext_part_valid && both) DCR_TRY(launch_argext_both(g));
+        if (!g->ext_part_valid && both) DCR_TRY(launch_argext_both(g, nullptr, dirty_clear_pending));
+        else if (dirty_clear_pending) DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+        dirty_clear_pending = false;
         return g->ext_part_valid ? launch_argext_from_parts(g, 0) : launch_argext(g, 0, -1, -1);
     };
     // incremental is only sound on top of a complete buffer of the same curvature kind whose later edits were all
@@ -817,7 +820,10 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     g->h2_cleared_dirty = false;
     DCR_TRY(launch_curvature_pass(g, curv_type, incremental));
     // (the two-hop launch zeroes the flags in its first kernel: one fill launch less at the tail of every pass)
-    if (!(g->last_engine == 0 && g->h2_cleared_dirty)) DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+    if (!(g->last_engine == 0 && g->h2_cleared_dirty)) {
+        if (with_argmin) dirty_clear_pending = true;
+        else DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+    }
     g->dirty_tracked = true;
     g->pending_edits = 0;
     if (g->profile) DCR_HIP(hipEventRecord(g->ev1, g->stream));

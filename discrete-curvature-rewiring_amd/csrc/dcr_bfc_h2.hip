@@ -1310,7 +1310,6 @@ __device__ inline void h2_stream(const View &g, const H2Tasks tk, H2Alloc &al, i
                                  const H2Tab t, H2Scratch *sc, uint4 *rec, int k0, int2 rk0, H2List &ls) {
     const int lane = threadIdx.x & 63;
     const int wid = (int)(threadIdx.x >> 6);
-    const unsigned long long below = (1ull << lane) - 1ull;
     int qn = 0;  // queued items (uniform)
     int lcur = 0;  // third step from the list: next item (uniform)
     if (PHASE == 0 && ru.y > 64 * NW * H2_REV_BATCHES) ls.over = true;  // more batches than the list's row array holds

@@ -137,6 +137,9 @@ __device__ inline unsigned cnt_add(unsigned *cnt, int h) {
 // equality compares and a "bucket full" compare per id (nc_probe_flags).  Pieces are compared raw; ids outside the row,
 // slack included, are masked off afterwards.  What passes the test is queued for the full look-up (slot position, walk
 // to the next bucket, slot counter update), see NC_QCAP below.
+#ifdef NC_DIRTY_STATS  // diagnostic build (tools/build_variant.sh dstats -DNC_DIRTY_STATS): what an incremental pass's units hold
+__device__ unsigned long long nc_dstats[4 * 8];  // per class of table size: units, units with an edge to compute, such edges, their rows' entries
+#endif
 #ifdef NC_STATS  // diagnostic build (tools/build_variant.sh stats -DNC_STATS): how often the fast test fails
 __device__ unsigned long long nc_stats[8];
 #define NC_STATS_COUNT(look_any)                                                             \
@@ -556,6 +559,20 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
             if (own && g.dirty) own = edge_dirty(g.dirty[u], g.dirty[v]);
         }
     }
+#ifdef NC_DIRTY_STATS
+    if (g.dirty) {
+        const unsigned long long m = __ballot(own);
+        int len = own ? rv.y : 0;
+        for (int off = 32; off > 0; off >>= 1) len += __shfl_xor(len, off);
+        if (lane == 0) {
+            const int c = SLOTS == 256 ? 0 : SLOTS == 512 ? 1 : SLOTS == 2048 ? 2 : 3;
+            atomicAdd(&nc_dstats[c * 8 + 0], 1ull);
+            atomicAdd(&nc_dstats[c * 8 + 1], m ? 1ull : 0ull);
+            atomicAdd(&nc_dstats[c * 8 + 2], (unsigned long long)__popcll(m));
+            atomicAdd(&nc_dstats[c * 8 + 3], (unsigned long long)len);
+        }
+    }
+#endif
     const bool trivial = curv_type == DCR_CURV_BFC && (ru.y < rv.y ? ru.y : rv.y) == 1;  // bfc_naive.py:18-19
     if (own && trivial && u < v) {
         curv[ru.x + p] = 0.0;  // the slot is in the owner's own row: nothing to look up
@@ -838,6 +855,10 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
         wave_off = __shfl(wave_off, 0);
         if (bkt == b) my_off = wave_off + incl - nunits;
     }
+    // (round 5: the bucket totals come into LDS with ONE load per bucket, all in flight together; the sums over them below ran as
+    //  chains of up to 15 dependent L2 round trips per thread — 46 us for this kernel against 7 for PHASE 0)
+    __shared__ int bucket_sh[NC_BUCKETS];
+    if (PHASE == 1 && threadIdx.x >= 128 && threadIdx.x < 128 + NC_BUCKETS) bucket_sh[threadIdx.x - 128] = res->nc_bucket[threadIdx.x - 128];
     __syncthreads();
     if (threadIdx.x < NC_BUCKETS) {
         const int b = threadIdx.x, c = blk_count[b];
@@ -846,7 +867,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
         } else {
             int before = 0;
             for (int h = b + 1; h < NC_BUCKETS; ++h)  // heavier buckets of the same class come first
-                if (nc_bucket_class(h) == nc_bucket_class(b)) before += res->nc_bucket[h];
+                if (nc_bucket_class(h) == nc_bucket_class(b)) before += bucket_sh[h];
             blk_base[b] = before + (c ? atomicAdd(&res->nc_fill[b], c) : 0);
         }
     }
@@ -854,7 +875,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
     if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + NC_CLASSES) {
         int tot = 0;
         for (int b = 0; b < NC_BUCKETS; ++b)
-            if (nc_bucket_class(b) == (int)threadIdx.x - 64) tot += res->nc_bucket[b];
+            if (nc_bucket_class(b) == (int)threadIdx.x - 64) tot += bucket_sh[b];
         res->nc_count[threadIdx.x - 64] = tot;
     }
     __syncthreads();
@@ -879,7 +900,13 @@ __global__ void __launch_bounds__(256) k_nc_touch(View g, uint8_t *touch) {
     if (v >= 0 && v < g.n && edge_dirty(g.dirty[u], g.dirty[v])) touch[u] = 1;
 }
 
-__global__ void k_nc_clear(DevResult *res) {
+// (round 5: also the dequeue cursors and, for an incremental pass, the per-node flags k_nc_touch sets — two fill launches of
+//  4 us each at the head of every pass before)
+__global__ void __launch_bounds__(256) k_nc_clear(DevResult *res, int32_t *queues, int n_queue_ints, unsigned *touch_words, int64_t n_touch_words) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    for (int64_t i = tid; i < n_queue_ints; i += nth) queues[i] = 0;
+    for (int64_t i = tid; i < n_touch_words; i += nth) touch_words[i] = 0u;
+    if (blockIdx.x != 0) return;
     if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
     if (threadIdx.x < 16) {
         res->nc_bucket[threadIdx.x] = 0;
@@ -974,10 +1001,15 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         L.cap[c] = g->nc_cap[c];
     }
     if (!g->nc_queues) DCR_TRY(dev_alloc(&g->nc_queues, 2 * NC_QUEUES * NC_QUEUE_STRIDE));
-    DCR_HIP(hipMemsetAsync(g->nc_queues, 0, sizeof(int32_t) * 2 * NC_QUEUES * NC_QUEUE_STRIDE, g->stream));
-    hipLaunchKernelGGL(k_nc_clear, dim3(1), dim3(64), 0, g->stream, g->dres);
+    {
+        const int64_t touch_words = incremental ? (g->n + 3) / 4 : 0;   // (the buffer holds n + 64 bytes)
+        int64_t cb = (touch_words + 1023) / 1024;
+        if (cb < 1) cb = 1;
+        if (cb > 256) cb = 256;
+        hipLaunchKernelGGL(k_nc_clear, dim3((unsigned)cb), dim3(256), 0, g->stream, g->dres, g->nc_queues, 2 * NC_QUEUES * NC_QUEUE_STRIDE,
+                           reinterpret_cast<unsigned *>(g->nc_touch), touch_words);
+    }
     if (incremental) {
-        DCR_HIP(hipMemsetAsync(g->nc_touch, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
         const int64_t blocks = (g->cap_total + 255) / 256;
         if (blocks > 0) hipLaunchKernelGGL(k_nc_touch, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, g->nc_touch);
     }
@@ -1013,6 +1045,18 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
         }
     }
     DCR_HIP(hipGetLastError());
+#ifdef NC_DIRTY_STATS
+    if (incremental) {
+        unsigned long long h[32];
+        DCR_HIP(hipStreamSynchronize(g->stream));
+        DCR_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(nc_dstats), sizeof(h)));
+        for (int c = 0; c < 4; ++c)
+            fprintf(stderr, "[nc dirty stats] class %d: units %llu, with work %llu, edges %llu, row entries %llu\n", c, h[c * 8], h[c * 8 + 1],
+                    h[c * 8 + 2], h[c * 8 + 3]);
+        unsigned long long z[32] = {0};
+        DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nc_dstats), z, sizeof(z)));
+    }
+#endif
 #ifdef NC_STATS
     {
         unsigned long long h[8];

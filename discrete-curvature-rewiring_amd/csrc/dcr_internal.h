@@ -337,7 +337,7 @@ void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit);  // flag t
 int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_t st = nullptr);  // st: default the library stream
 // the same from the per-block extrema of the last two-hop pass (g->ext_part_valid), without sweeping the edges again
 int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st = nullptr);
-int launch_argext_both(dcr_graph *g, hipStream_t st = nullptr);
+int launch_argext_both(dcr_graph *g, hipStream_t st = nullptr, bool clear_dirty = false);
 // reductions of per-workgroup partial results shared by the GCN kernels (csrc/dcr_gemm.hip, csrc/dcr_gcn.hip)
 void launch_slab_reduce(const float *part, float *C, int64_t mn, int N, int64_t ldc, int splits, hipStream_t st);
 void launch_slab_reduce_cols(const float *part, float *C, int64_t mn, int N, int ncols, int64_t ldc, int splits, hipStream_t st);
