@@ -540,6 +540,15 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
 #endif
 __host__ __device__ constexpr int nc_lanes(int c) { return c < 2 ? NC_LANES_SMALL : NC_LANES_BIG; }
 __host__ __device__ constexpr int nc_lanes_for_slots(int slots) { return slots <= 512 ? NC_LANES_SMALL : NC_LANES_BIG; }
+// Round 5: an incremental pass behind an SDRF edit recomputes about a hundred edges spread over a few hundred units
+// (tools/build_variant.sh dstats -DNC_DIRTY_STATS) on a thousand waves: it is as long as its longest unit, whose edges one wave
+// streams one after the other.  Units of 4 positions there (View::nc_fine): the class of 63-254 neighbours 178 -> 107 us, the
+// iteration 0.33 -> 0.26 ms (profiles/r05_incremental_lanes_ab.txt); one position per unit gains nothing more (101 us: the
+// floor is a near-empty persistent launch, 55 us).  Full passes keep 16 / 8: a table build per 4 edges costs them 10 %.
+#ifndef NC_LANES_FINE
+#define NC_LANES_FINE 4
+#endif
+__device__ inline int nc_lanes_rt(const View &g, int coarse) { return g.nc_fine ? (coarse < NC_LANES_FINE ? coarse : NC_LANES_FINE) : coarse; }
 
 template <int SLOTS, int MODE>
 __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub, const unsigned *tab, unsigned *cnt,
@@ -550,7 +559,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
     int v = -1;
     int2 rv = make_int2(0, 0);
     bool own = false;
-    if (lane < nc_lanes_for_slots(SLOTS) && p < ru.y) {
+    if (lane < nc_lanes_rt(g, nc_lanes_for_slots(SLOTS)) && p < ru.y) {
         v = g.col[ru.x + p];
         if (v >= 0 && v < g.n && v != u) {
             rv = g.rowinfo[v];
@@ -674,9 +683,11 @@ __global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2
     // The unit list is dealt round-robin to NC_QUEUES queues, each with its own cursor on its own cache line: one
     // cursor for all waves saturates at ~90 dequeues per microsecond on MI355X and was 40 % of the pass.  A wave
     // starts on the queue of its workgroup (blockIdx % 8: workgroups that share an XCD) and moves on when it is empty.
-    for (int qi = 0; qi < NC_QUEUES; ++qi) {
-        const int q = (int)((blockIdx.x + qi) % NC_QUEUES);
-        const int count_q = total > q ? (total - q + NC_QUEUES - 1) / NC_QUEUES : 0;
+    // (fine units — a few hundred in all: two queues; a wave that finds nothing has made two dependent atomics, not eight)
+    const int nq = g.nc_fine ? 2 : NC_QUEUES;
+    for (int qi = 0; qi < nq; ++qi) {
+        const int q = (int)((blockIdx.x + qi) % nq);
+        const int count_q = total > q ? (total - q + nq - 1) / nq : 0;
         int32_t *cursor = next + q * NC_QUEUE_STRIDE;
         const int max_rounds = count_q / CHUNK + 2;
         for (int round = 0; round < max_rounds; ++round) {
@@ -686,7 +697,7 @@ __global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2
             if (first >= count_q || first < 0) break;
             const int last = first + CHUNK < count_q ? first + CHUNK : count_q;
             for (int t = first; t < last; ++t) {
-                const int it = q + t * NC_QUEUES;
+                const int it = q + t * nq;
                 const int2 un = units[it];
                 const int u = un.x, sub = un.y;
                 if (u < 0 || u >= g.n || sub < 0) {
@@ -695,7 +706,8 @@ __global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2
                 }
                 int2 ru = g.rowinfo[u];
                 if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;  // the plan keeps the load <= 1/2
-                const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
+                const int ln = nc_lanes_rt(g, nc_lanes_for_slots(SLOTS));
+                const int nsub = (ru.y + ln - 1) / ln;
                 if (sub >= nsub) continue;
                 for (int i = lane; i < SLOTS; i += 64) tab[i] = NC_EMPTY;
                 if (lane == 0) sc->spilled = 0;
@@ -757,7 +769,8 @@ __device__ inline void nc_block_units(const View &g, const int2 *units, const in
             if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k, &sc_all[0].spilled);
         }
         __syncthreads();
-        const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
+        const int ln = nc_lanes_rt(g, nc_lanes_for_slots(SLOTS));
+        const int nsub = (ru.y + ln - 1) / ln;
         const int sub = sub0 + wid;
         if (wid < W && sub < nsub)
             nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_base + wid * (SLOTS / 2), &sc_all[wid], &sc_all[0].spilled,
@@ -835,7 +848,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
         if (d > 0 && d <= NC_MAXD && (!g.dirty || touch[u])) bkt = nc_bucket_of(d);
     }
     const int cls = bkt < 0 ? -1 : nc_bucket_class(bkt);
-    const int L_ = cls < 0 ? 16 : nc_lanes(cls);
+    const int L_ = cls < 0 ? 16 : nc_lanes_rt(g, nc_lanes(cls));
     const int nsub = (d + L_ - 1) / L_;
     // wave classes: one unit per sub-unit; block classes: one unit per group of W sub-units
     const int W = cls >= 2 ? nc_waves(cls) : 1;
@@ -919,7 +932,8 @@ __global__ void __launch_bounds__(256) k_nc_clear(DevResult *res, int32_t *queue
 
 static int ensure_nc(dcr_graph *g) {
     // units per class, from the smallest degree a member node can have and its sub-units (16 or 4 positions each)
-    const int64_t need[NC_CLASSES] = {g->n * 4 + 64, g->cap_total / 3 + 64, g->cap_total / 6 + 64,
+    // (class 0 with units of NC_LANES_FINE positions: at most d / 4 + 1 units per node; the other classes' bounds cover theirs)
+    const int64_t need[NC_CLASSES] = {std::max<int64_t>(g->n * 4, g->cap_total / NC_LANES_FINE + g->n) + 64, g->cap_total / 3 + 64, g->cap_total / 6 + 64,
                                       g->cap_total / 3 + 64, g->cap_total / 6 + 64};
     for (int c = 0; c < NC_CLASSES; ++c) {
         if (g->nc_cap[c] < need[c]) {
@@ -988,7 +1002,7 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
             g->num_cu = prop.multiProcessorCount;
     }
     View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr,
-            (int32_t)g->n, 1, nullptr};
+            (int32_t)g->n, 1, nullptr, (incremental && g->pending_edits <= DIRTY_EDITS) ? 1 : 0};
     static const bool want_trace = getenv("DCR_NC_TRACE") != nullptr;
     if (want_trace) {
         if (!g->nc_trace) DCR_TRY(dev_alloc(&g->nc_trace, NC_CLASSES * 16384 * 2));

@@ -806,12 +806,23 @@ namespace dcr {
 // (deterministic).  As one workgroup of 1,024 threads every thread walked ~100 rows of the bench's training split one
 // dependent pair of loads after the other: 92 us per epoch for a 100k-element gather.  The partial sums live in a buffer of
 // the library (one per device and process: calls are expected on one stream at a time, as the epoch's graph issues them).
+// Round 5 (advisor, round 4): the partial sums and the ticket live in the CALLER's workspace (the head kernels' HeadWs below:
+// one buffer per device and stream, tickets zero before the first use and left zero by every launch) — as process-global
+// device variables two loss calls in flight on different streams mixed their partials.
 constexpr int PICKED_BLOCKS = 256;
-__device__ double picked_partial[PICKED_BLOCKS];
-__device__ unsigned picked_ticket;
+constexpr int HEAD_MAXC = 32, HEAD_MAXB = 1024;
+struct HeadWs {
+    double loss_part[HEAD_MAXB];
+    unsigned long long hit_part[HEAD_MAXB];
+    float col_part[HEAD_MAXB][HEAD_MAXC];
+    unsigned ticket_fwd, ticket_bwd;
+    unsigned pad[2];
+};
 
 __global__ void __launch_bounds__(256) k_picked_mean_fwd(const float *__restrict__ lp, int64_t ld, const int64_t *__restrict__ y,
-                                                          int64_t m, int C, float *__restrict__ out) {
+                                                          int64_t m, int C, float *__restrict__ out, HeadWs *ws) {
+    double *picked_partial = ws->loss_part;
+    unsigned &picked_ticket = ws->ticket_fwd;
     __shared__ double red[256];
     __shared__ int last_sh;
     const int64_t per = (m + gridDim.x - 1) / gridDim.x;
@@ -828,13 +839,12 @@ __global__ void __launch_bounds__(256) k_picked_mean_fwd(const float *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        picked_partial[blockIdx.x] = red[0];
-        __threadfence();
+        __hip_atomic_store(&picked_partial[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (through the L2, as the head kernels)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         last_sh = atomicAdd(&picked_ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (!last_sh) return;
-    __threadfence();
     red[threadIdx.x] = (int)threadIdx.x < (int)gridDim.x
                            ? __hip_atomic_load(&picked_partial[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     __syncthreads();
@@ -897,14 +907,6 @@ __global__ void __launch_bounds__(256) k_count_argmax_equal(const float *__restr
 // The last block to finish (a ticket behind an agent-scope fence) closes each reduction; partials and tickets live in a
 // workspace of the CALLER (advisor, round 4: the round-4 loss kernel kept them in process-global device variables, shared by
 // every stream) whose tickets are zero before the first use and left zero by every launch.
-constexpr int HEAD_MAXC = 32, HEAD_MAXB = 1024;
-struct HeadWs {
-    double loss_part[HEAD_MAXB];
-    unsigned long long hit_part[HEAD_MAXB];
-    float col_part[HEAD_MAXB][HEAD_MAXC];
-    unsigned ticket_fwd, ticket_bwd;
-    unsigned pad[2];
-};
 
 template <int C>
 __device__ __forceinline__ float head_lse(const float (&o)[C], int classes) {
@@ -1166,12 +1168,13 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamArgs A, float *__restric
 }  // namespace dcr
 
 extern "C" int dcr_nll_picked_mean_fwd_f32_dev(const float *lp, int64_t ld, const int64_t *y, int64_t m, int classes, float *out_loss,
-                                               void *hip_stream) {
-    if (!lp || !y || !out_loss || m <= 0 || classes < 1 || ld < classes) DCR_FAIL(DCR_EINVAL, "bad nll arguments");
+                                               void *ws, void *hip_stream) {
+    if (!lp || !y || !out_loss || !ws || ((uintptr_t)ws & 7) || m <= 0 || classes < 1 || ld < classes)
+        DCR_FAIL(DCR_EINVAL, "bad nll arguments (a workspace of dcr_head_workspace bytes)");
     int64_t blocks = (m + 255) / 256;
     if (blocks > dcr::PICKED_BLOCKS) blocks = dcr::PICKED_BLOCKS;
     hipLaunchKernelGGL(dcr::k_picked_mean_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, lp, ld, y, m, classes,
-                       out_loss);
+                       out_loss, (dcr::HeadWs *)ws);
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }

@@ -1002,7 +1002,7 @@ static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_
     }
     const int64_t rows_need = (int64_t)(dx > dy ? dx : dy) + 2;
     if (rows_need > g->imp_rows_cap) {
-        const int64_t nc = rows_need + rows_need / 2 + 64;
+        const int64_t nc = 2 * rows_need + 64;
         for (int32_t **p : {&g->imp_c1, &g->imp_c2, &g->imp_rowcount, &g->imp_rowoff, &g->scan_a, &g->scan_b}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
@@ -1015,14 +1015,15 @@ static int imp_enqueue(dcr_graph *g, int32_t x, int32_t y, int curv_type, int64_
         }
         g->imp_rows_cap = nc;
     }
-    DCR_TRY(dev_regrow(&g->imp_adjbits, &g->imp_bits_cap, (int64_t)rows * words));
+    if ((int64_t)rows * words > g->imp_bits_cap) DCR_TRY(dev_regrow(&g->imp_adjbits, &g->imp_bits_cap, 2 * (int64_t)rows * words));
     if (upper > g->imp_out_cap) {
         if (g->imp_out) (void)hipFree(g->imp_out);
         if (g->imp_ci) (void)hipFree(g->imp_ci);
         if (g->imp_cj) (void)hipFree(g->imp_cj);
         g->imp_out = nullptr;
         g->imp_ci = g->imp_cj = nullptr;
-        const int64_t nc = upper + upper / 4 + 1024;
+        const int64_t nc = 2 * upper + 1024;   // (doubling: a re-allocation is a device synchronisation + two driver calls, ~0.3 ms —
+                                               //  a few of them inside a 20-iteration measurement are 1-2 % of it)
         DCR_TRY(dev_alloc(&g->imp_out, nc));
         DCR_TRY(dev_alloc(&g->imp_ci, nc));
         DCR_TRY(dev_alloc(&g->imp_cj, nc));

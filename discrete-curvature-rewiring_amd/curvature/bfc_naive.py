@@ -10,7 +10,12 @@ from dcr.graph import DcrGraph
 
 def bfc_edge(G, v1, v2):
     g = as_dcr_graph(G, check=(v1, v2))
-    if min(g.degree(v1), g.degree(v2)) == 1:
+    if isinstance(G, DcrGraph):
+        d1, d2 = g.degree(v1), g.degree(v2)
+    else:   # (the device copy has just been checked against these very degrees: no round trip for them)
+        a1, a2 = G._adj[v1], G._adj[v2]
+        d1, d2 = len(a1) - (v1 in a1), len(a2) - (v2 in a2)
+    if min(d1, d2) == 1:
         return 0  # bfc_naive.py:18-19 returns the int 0
     return g.curvature_edge(v1, v2, 'bfc')
 

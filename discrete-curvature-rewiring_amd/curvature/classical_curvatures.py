@@ -21,7 +21,9 @@ CURV_TYPES = ('1d', 'augmented', 'haantjes', 'bfc')
 # delete in place: same adjacency order); every other mutating method drops the copy, which is then rebuilt at the next
 # call.  Edits that bypass the methods (writing into G.adj / G._adj directly) are caught where they change a degree that the
 # next call compares (_stale); otherwise pass refresh=True.  DCR_MIRROR=0: no mirroring at all.
-_MIRRORS = None      # WeakKeyDictionary: networkx graph -> [DcrGraph or None]
+_MIRRORS = None      # WeakKeyDictionary: networkx graph -> [DcrGraph or None, the device copy's degrees as a host list]
+#                      (round 5, advisor: the stale check compared the graph's degrees with g.degree(u) — a device round trip
+#                       per endpoint and call; the mirroring methods keep a host copy of what the device holds instead)
 _MIRROR_CLASS = {}   # networkx class -> its mirroring subclass
 
 
@@ -43,6 +45,8 @@ def _mirror_class(cls):
         cls.add_edge(self, u, v, **attr)
         if fresh:
             m[0].add_edge(int(u), int(v))
+            m[1][int(u)] += 1
+            m[1][int(v)] += 1
 
     def remove_edge(self, u, v):
         m = _MIRRORS.get(self)
@@ -52,6 +56,8 @@ def _mirror_class(cls):
                 m[0] = None
             else:
                 m[0].remove_edge(int(u), int(v))
+                m[1][int(u)] -= 1
+                m[1][int(v)] -= 1
 
     def _dropping(name):
         base = getattr(cls, name)
@@ -101,7 +107,7 @@ def as_dcr_graph(G, device=0, refresh=False, check=None):
         _MIRRORS = weakref.WeakKeyDictionary()
     m = _MIRRORS.get(G)
     if m is not None and m[0] is not None and not refresh:
-        if not _stale(G, m[0], check):
+        if not _stale(G, m, check):
             return m[0]
         m[0] = None       # edited behind the mirroring methods: uploaded again below
     g = _upload(G, device)
@@ -112,25 +118,27 @@ def as_dcr_graph(G, device=0, refresh=False, check=None):
         if type(G) is nx.Graph or type(G) in _MIRROR_CLASS.values():
             if type(G) is nx.Graph:
                 G.__class__ = _mirror_class(nx.Graph)
-            _MIRRORS[G] = [g]
+            _MIRRORS[G] = [g, [len(row) - (u in row) for u, row in G._adj.items()]]
     except ImportError:
         pass
     return g
 
 
-def _stale(G, g, check):
-    """Whether the device copy ``g`` disagrees with ``G`` on the degrees of the nodes named by ``check``."""
+def _stale(G, m, check):
+    """Whether the device copy ``m[0]`` disagrees with ``G`` on the degrees of the nodes named by ``check`` (its degrees: the
+    host list ``m[1]`` the mirroring methods keep beside it — no device round trip)."""
     if check is None:
         return False
+    deg = m[1]
     adj = G._adj
-    if len(adj) != g.number_of_nodes():
+    if len(adj) != len(deg):
         return True
     if isinstance(check, str):    # 'all': one pass over the rows (the callers that use it are O(E) anyway)
         edges = sum(len(row) - (u in row) for u, row in adj.items())
-        return edges != 2 * g.number_of_edges()
+        return edges != sum(deg)
     for u in check:
         row = adj.get(u)
-        if row is None or len(row) - (u in row) != g.degree(int(u)):
+        if row is None or not (0 <= int(u) < len(deg)) or len(row) - (u in row) != deg[int(u)]:
             return True
     return False
 

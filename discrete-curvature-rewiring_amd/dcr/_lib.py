@@ -69,7 +69,7 @@ SIGNATURES = {
     'dcr_relu_dropout_bwd_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _i64, _f64, _vp]),
     'dcr_act_linear_fwd_f32_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, ctypes.c_int, ctypes.c_int, _f64, ctypes.c_uint64,
                                                    ctypes.c_uint64, _vp, _vp]),
-    'dcr_nll_picked_mean_fwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp]),
+    'dcr_nll_picked_mean_fwd_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'dcr_nll_picked_mean_bwd_f32_dev': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'dcr_count_argmax_equal_f32_dev': (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp]),
     'dcr_adam_step_f32_dev': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),

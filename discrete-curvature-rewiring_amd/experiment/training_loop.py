@@ -37,8 +37,10 @@ class _PickedMean(torch.autograd.Function):
         lp = log_probs.contiguous()
         out = torch.empty((), dtype=torch.float32, device=lp.device)
         stream = torch.cuda.current_stream(lp.device).cuda_stream
+        from models.gcn import _head_workspace
         _lib.check(_lib.lib().dcr_nll_picked_mean_fwd_f32_dev(lp.data_ptr(), lp.shape[1], y.data_ptr(), lp.shape[0], lp.shape[1],
-                                                              out.data_ptr(), ctypes.c_void_p(stream)))
+                                                              out.data_ptr(), _head_workspace(lp.device, stream).data_ptr(),
+                                                              ctypes.c_void_p(stream)))
         ctx.y, ctx.shape = y, tuple(lp.shape)
         return out
 

@@ -339,7 +339,7 @@ int dcr_act_linear_bwd_fused_f32_dev(const float *dz_dev, const float *w_dev, co
  * gradient (what the stock kernels produce); :64-71 log_probs[mask].max(1)[1].eq(y[mask]).sum() as out_count[0] (first maximum
  * per row). */
 int dcr_nll_picked_mean_fwd_f32_dev(const float *lp_dev, int64_t ld, const int64_t *y_dev, int64_t m, int classes, float *out_loss_dev,
-                                    void *hip_stream);
+                                    void *ws_dev, void *hip_stream);   /* ws_dev: as dcr_head_fwd_f32_dev's (may be the same buffer) */
 /* Round 5: the head of an epoch in ONE kernel per direction, from the RAW outputs o = (Â·Z + b)[rows] of the last aggregation
  * (models/gcn.py:44 log_softmax + experiment/training_loop.py:51 F.nll_loss on the training rows; :64-71 arg-max accuracy on the
  * evaluated rows — the arg-max of log-probabilities is the arg-max of the logits):
