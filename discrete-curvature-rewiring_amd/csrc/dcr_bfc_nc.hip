@@ -1107,7 +1107,273 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
     return DCR_OK;
 }
 
+// =====================================================================================================================
+// Round 5: the incremental pass behind a few exactly flagged edits (an SDRF iteration), edge by edge
+// =====================================================================================================================
+// Such a pass recomputes about a hundred edges (tools/build_variant.sh dstats -DNC_DIRTY_STATS).  Through the class kernels
+// above it cost what their longest unit costs: a wave builds a table and streams its unit's edges one after the other, the
+// rows of a long edge batch by batch (class of 63-254 neighbours: 178 us with units of 16 positions, 102 with 4), behind a
+// sweep over the slots for the touched nodes and the two plan launches.  Here: ONE sweep over the slots lists the edges to
+// recompute (owner, position in its row) — the same ownership rule, the same dirty test as nc_chunk — and ONE kernel gives
+// every listed edge a workgroup of four waves: the table of the owner's neighbours is built by all of them (one size, the
+// largest class's, for every owner), the two sweeps over the other endpoint's row are dealt to the waves in batches of 64
+// rows (the slot counters are LDS atomics, every statistic a sum or a maximum: nc_edge with its loops strided by the wave
+// index).  Same integers, same closing expression.  DCR_NC_FINE=0: the class kernels with units of NC_LANES_FINE positions.
+constexpr int NCF_SLOTS = 16384;
+constexpr int NCF_W = 4;
+struct NcFineAcc {
+    int T, posu, s1, gam, s2, spilled;
+};
+
+__global__ void __launch_bounds__(256) k_nc_fine_list(View g, int curv_type, double *curv, int2 *list, int64_t cap, int32_t *count) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= g.cap_total) return;
+    const int u = g.slot_row[s];
+    if (u < 0 || u >= g.n) return;
+    const int2 ru = g.rowinfo[u];
+    if (s < ru.x || (int)(s - ru.x) >= ru.y || ru.y > NC_MAXD) return;
+    const int v = g.col[s];
+    if (v < 0 || v >= g.n || v == u) return;
+    if (!edge_dirty(g.dirty[u], g.dirty[v])) return;  // no edit can have changed it: the stored value is still exact
+    const int2 rv = g.rowinfo[v];
+    if (!row_ok(g, rv, 12, v, u)) return;
+    const bool bfc = curv_type == DCR_CURV_BFC;
+    if (!(rv.y > 0 && nc_owns(u, ru.y, v, rv.y, bfc))) return;
+    if (bfc && (ru.y < rv.y ? ru.y : rv.y) == 1 && u < v) {  // bfc_naive.py:18-19 (as nc_chunk: the slot is in the owner's own row)
+        curv[s] = 0.0;
+        return;
+    }
+    const int idx = atomicAdd(count, 1);
+    if (idx >= 0 && idx < cap) list[idx] = make_int2(u, (int)(s - ru.x));
+}
+
+// nc_edge by the NCF_W waves of a workgroup: `tab` (N(u)), `cnt` and `acc` are the workgroup's, `sc` this wave's
+template <int SLOTS, int MODE>
+__device__ inline NcEdge nc_edge_wg(const View &g, int u, int v, int2 rv, const unsigned *tab, unsigned *cnt, NcScratch *sc,
+                                    NcFineAcc *acc, bool ovf) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int32_t *rowv = g.col + rv.x;
+    NcEdge out;
+    out.T = out.s1 = out.s2 = out.gam = 0;
+    out.posu = -1;
+    if (MODE == MODE_BFC) {
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+        for (int i = threadIdx.x; i < SLOTS / 8; i += 64 * NCF_W) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (threadIdx.x == 0) {
+        acc->T = 0;
+        acc->posu = -1;
+        acc->s1 = 0;
+        acc->gam = 0;
+        acc->s2 = 0;
+    }
+    __syncthreads();
+    if (MODE == MODE_BFC && threadIdx.x == 0) {
+        const int hv = nc_find<SLOTS>(tab, (unsigned)v);  // v is a neighbour of u: never counted as a hit
+        if (hv >= 0) cnt_flag(cnt, hv);
+    }
+    // sweep 1 over N(v): triangles (flagged), where u sits in row v
+    int T = 0;
+    for (int base = 64 * wid; base < rv.y; base += 64 * NCF_W) {
+        const int i = base + lane;
+        const int k = i < rv.y ? rowv[i] : -1;
+        const bool isu = k == u;
+        const unsigned long long mu = __ballot(isu);
+        if (mu && lane == 0) acc->posu = base + __ffsll((long long)mu) - 1;
+        const int h = (k >= 0 && !isu) ? nc_find<SLOTS>(tab, (unsigned)k) : -1;
+        if (MODE == MODE_BFC && h >= 0) cnt_flag(cnt, h);
+        T += __popcll(__ballot(h >= 0));
+    }
+    if (lane == 0 && T) atomicAdd(&acc->T, T);
+    __syncthreads();  // every flag is set before the first hit is counted
+    out.T = acc->T;
+    out.posu = acc->posu;
+    if (MODE != MODE_BFC) return out;
+    // sweep 2 over N(v): the rows of DY, 64 members at a time, the batches dealt to the waves
+    int s1 = 0, gam = 0, s2 = 0;
+    int qn = 0;  // queued full look-ups (uniform per wave)
+    auto drain = [&]() {
+        wave_sync();
+        for (int qb = 0; qb < qn; qb += 64) {
+            const int qi = qb + lane;
+            if (qi < qn) {
+                const int h = nc_find<SLOTS>(tab, sc->qk[qi]);
+                if (h >= 0) {
+                    const unsigned old = cnt_add(cnt, h);
+                    if (!(old & 0x8000u)) {  // not a member of N(v): a 4-cycle u-z-w-v
+                        atomicAdd(&sc->rowcnt[sc->qrow[qi]], 1);
+                        s1 += (old == 0u);
+                        gam = (int)old + 1 > gam ? (int)old + 1 : gam;
+                    }
+                }
+            }
+        }
+        wave_sync();
+        qn = 0;
+    };
+    for (int base = 64 * wid; base < rv.y; base += 64 * NCF_W) {
+        const int i = base + lane;
+        const int k = i < rv.y ? rowv[i] : -1;
+        const bool in_nu = k >= 0 && nc_find<SLOTS>(tab, (unsigned)k) >= 0;
+        const bool member = k >= 0 && k < g.n && k != u && !in_nu;
+        int2 rk = make_int2(0, 0);
+        if (member) {
+            rk = g.rowinfo[k];
+            if (!row_ok(g, rk, 11, k, v)) rk = make_int2(0, 0);
+        }
+        const int np = rk.y > 0 ? ((rk.x + rk.y + 3) >> 2) - (rk.x >> 2) : 0;
+        int incl = np;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const int P = __shfl(incl, 63);
+        sc->desc[lane] = rk;
+        sc->poff[lane] = incl - np;
+        const int poff_lane = incl - np;
+        sc->rowcnt[lane] = 0;
+        if (lane == 0) sc->poff[64] = P;
+        wave_sync();
+        for (int j0 = 0; j0 < P; j0 += 64 * NC_Q) {
+            int4 w[NC_Q];
+            int rr[NC_Q], aa[NC_Q];
+#pragma unroll
+            for (int q = 0; q < NC_Q; ++q) {
+                const int j = j0 + 64 * q + lane;
+                rr[q] = -1;
+                aa[q] = 0;
+                w[q] = make_int4(0, 0, 0, 0);
+                const int jf = j0 + 64 * q, jl = jf + 63 < P ? jf + 63 : P - 1;
+                if (jf >= P) continue;  // uniform
+                const int r = piece_row(sc->poff, poff_lane, j < P ? j : jl, jf, jl);
+                if (j < P) {
+                    const int2 d = sc->desc[r];
+                    const int a = (d.x & ~3) + 4 * (j - sc->poff[r]);
+                    w[q] = load_piece(g.col, a);
+                    rr[q] = r;
+                    aa[q] = a;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NC_Q; ++q) {
+                if (j0 + 64 * q >= P) continue;  // uniform
+                unsigned f = 0u;
+                if (rr[q] >= 0) {
+                    const int2 d = sc->desc[rr[q]];
+                    f = nc_probe_flags<SLOTS>(tab, w[q], piece_mask(aa[q], d.x, d.x + d.y), ovf, (unsigned)v);
+                }
+                if (__ballot(f != 0u)) nc_queue_push(sc, qn, f, w[q], rr[q], drain);  // uniform; rare per lane, common per wave
+            }
+        }
+        if (qn > 0) drain();
+        wave_sync();
+        const int c = sc->rowcnt[lane];
+        s2 += __popcll(__ballot(c > 0));
+        gam = c > gam ? c : gam;
+        wave_sync();  // the scratch is rewritten by the next batch
+    }
+    if (s1 > 0) atomicAdd(&acc->s1, s1);
+    if (gam > 0) atomicMax(&acc->gam, gam);
+    if (lane == 0 && s2 > 0) atomicAdd(&acc->s2, s2);
+    __syncthreads();
+    out.s1 = acc->s1;
+    out.gam = acc->gam;
+    out.s2 = acc->s2;
+    return out;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64 * NCF_W) k_nc_fine_edges(View g, const int2 *list, const int32_t *count, int64_t cap, int curv_type,
+                                                               double *curv) {
+    __shared__ __attribute__((aligned(16))) unsigned tab[NCF_SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned cnt[NCF_SLOTS / 2];
+    __shared__ NcScratch sc_all[NCF_W];
+    __shared__ NcFineAcc acc;
+    const int total = *count;
+    if (total < 0 || total > cap) {  // uniform (more edges than slots / 2: the adjacency is not symmetric)
+        row_ok(g, make_int2(-1, total), 21, 0, 0);
+        return;
+    }
+    for (int e = blockIdx.x; e < total; e += gridDim.x) {
+        const int2 it = list[e];
+        const int u = it.x, p = it.y;
+        bool ok = u >= 0 && u < g.n && p >= 0;
+        int2 ru = make_int2(0, 0), rv = make_int2(0, 0);
+        int v = -1;
+        if (ok) {
+            ru = g.rowinfo[u];
+            ok = row_ok(g, ru, 22, u, e) && p < ru.y && ru.y <= NCF_SLOTS / 2 - 2;
+        }
+        if (ok) {
+            v = g.col[ru.x + p];
+            ok = v >= 0 && v < g.n && v != u;
+        }
+        if (ok) {
+            rv = g.rowinfo[v];
+            ok = row_ok(g, rv, 23, v, u) && rv.y > 0;
+        }
+        if (!ok) continue;  // uniform
+        for (int i = threadIdx.x; i < NCF_SLOTS; i += 64 * NCF_W) tab[i] = NC_EMPTY;
+        if (threadIdx.x == 0) acc.spilled = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ru.y; i += 64 * NCF_W) {
+            const int k = g.col[ru.x + i];
+            if (k >= 0) nc_insert<NCF_SLOTS>(tab, (unsigned)k, &acc.spilled);
+        }
+        __syncthreads();
+        const bool ovf = acc.spilled != 0;
+        const NcEdge r = nc_edge_wg<NCF_SLOTS, MODE>(g, u, v, rv, tab, cnt, &sc_all[threadIdx.x >> 6], &acc, ovf);
+        if (threadIdx.x == 0) {
+            int64_t slot = -1;
+            if (u < v) slot = (int64_t)ru.x + p;
+            else if (r.posu >= 0) slot = (int64_t)rv.x + r.posu;
+            if (slot < 0 || slot >= g.cap_total) {
+                row_ok(g, make_int2(-1, r.posu), 13, u, v);  // adjacency not symmetric: report, never write
+            } else if (MODE == MODE_BFC) {
+                const bool trivial = (ru.y < rv.y ? ru.y : rv.y) == 1;  // bfc_naive.py:18-19
+                curv[slot] = trivial ? 0.0 : bfc_formula(ru.y, rv.y, r.T, r.s1, r.s2, r.gam);
+            } else {
+                curv[slot] = curv_type == DCR_CURV_AUGMENTED ? (double)(4 - ru.y - rv.y + 3 * r.T) : (double)r.T;
+            }
+        }
+        __syncthreads();  // table, counters and totals are rewritten for the next edge
+    }
+}
+
+template <int MODE>
+static int run_nc_fine(dcr_graph *g, int curv_type) {
+    if (g->num_cu <= 0) {
+        g->num_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) g->num_cu = prop.multiProcessorCount;
+    }
+    const int64_t need = g->cap_total / 2 + 64;  // every edge has one owner
+    if (g->nc_fine_cap < need) {
+        if (g->nc_fine_list) (void)hipFree(g->nc_fine_list);
+        g->nc_fine_list = nullptr;
+        DCR_TRY(dev_alloc(&g->nc_fine_list, need));
+        g->nc_fine_cap = need;
+    }
+    if (!g->nc_queues) DCR_TRY(dev_alloc(&g->nc_queues, 2 * NC_QUEUES * NC_QUEUE_STRIDE));
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, g->dirty, (int32_t)g->n, 1, nullptr, 1};
+    hipLaunchKernelGGL(k_nc_clear, dim3(1), dim3(256), 0, g->stream, g->dres, g->nc_queues, 0, (unsigned *)nullptr, (int64_t)0);
+    const int64_t blocks = (g->cap_total + 255) / 256;
+    if (blocks > 0)
+        hipLaunchKernelGGL(k_nc_fine_list, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, curv_type, g->curv, g->nc_fine_list,
+                           g->nc_fine_cap, &g->dres->nc_count[0]);
+    hipLaunchKernelGGL((k_nc_fine_edges<MODE>), dim3((unsigned)g->num_cu), dim3(64 * NCF_W), 0, g->stream, vw, g->nc_fine_list,
+                       &g->dres->nc_count[0], g->nc_fine_cap, curv_type, g->curv);
+    DCR_HIP(hipGetLastError());
+    return DCR_OK;
+}
+
 int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental) {
+    static const bool fine_on = !(getenv("DCR_NC_FINE") && atoi(getenv("DCR_NC_FINE")) == 0);
+    if (incremental && fine_on && g->pending_edits <= DIRTY_EDITS && !getenv("DCR_NC_TRACE")) {
+        if (curv_type == DCR_CURV_BFC) return run_nc_fine<MODE_BFC>(g, curv_type);
+        return run_nc_fine<MODE_TRI>(g, curv_type);
+    }
     if (curv_type == DCR_CURV_BFC) return run_nc<MODE_BFC>(g, curv_type, incremental);
     return run_nc<MODE_TRI>(g, curv_type, incremental);
 }

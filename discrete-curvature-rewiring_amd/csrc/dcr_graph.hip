@@ -501,7 +501,7 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->imp_table, g->imp_posx, g->imp_posy, g->imp_c1, g->imp_c2, g->imp_b, g->imp_c,
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
                         g->imp_stats, g->draw_bsum, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
-                        g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_trace, g->nc_queues, g->giant_list,
+                        g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_fine_list, g->nc_trace, g->nc_queues, g->giant_list,
                         g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
                         g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_units[3], g->h2_units[4], g->h2_retry, g->h2_task, g->h2_cand, g->h2_part, g->h2_bloom,
                         g->h2_rec, g->h2_eset, g->ext_part, g->h2_lists};

@@ -219,6 +219,8 @@ struct dcr_graph {
     int32_t *nc_queues = nullptr;  // dequeue cursors of the two wave-class kernels, one cache line each
     uint8_t *nc_touch = nullptr;  // [n] incremental pass: node has a flagged neighbour
     int64_t nc_touch_cap = 0;
+    int2 *nc_fine_list = nullptr;  // incremental pass behind a few exactly flagged edits: the edges to recompute {owner, position}
+    int64_t nc_fine_cap = 0;
     double sum_deg2 = 0.0;        // sum of squared degrees when the graph was created (engine choice: size of the 2-hop neighbourhoods)
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
     int pass_impl = 0;            // 0: automatic (default: two-hop kernels for full Balanced Forman passes of graphs large enough to
