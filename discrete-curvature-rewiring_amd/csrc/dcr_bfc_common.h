@@ -19,8 +19,6 @@ struct View {
     int32_t n;             // number of nodes
     int32_t nc_handles;    // 1: the node-centric kernels take every edge within their degree limits
     long long *trace;      // diagnostic build aid (DCR_NC_TRACE): per wave {first, last} s_memrealtime stamps, else nullptr
-    int32_t nc_fine;       // node-centric kernels: 1 = units of NC_LANES_FINE positions (an incremental pass behind a few exactly
-                           // flagged edits: a hundred edges in all, the pass is as long as its longest unit)
 };
 
 __device__ inline bool row_ok(const View &g, const int2 rk, int code, int a, int b) {

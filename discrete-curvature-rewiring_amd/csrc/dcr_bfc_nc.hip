@@ -540,15 +540,10 @@ __device__ inline void nc_edge_batch(const View &g, int u, int v, int2 rv, const
 #endif
 __host__ __device__ constexpr int nc_lanes(int c) { return c < 2 ? NC_LANES_SMALL : NC_LANES_BIG; }
 __host__ __device__ constexpr int nc_lanes_for_slots(int slots) { return slots <= 512 ? NC_LANES_SMALL : NC_LANES_BIG; }
-// Round 5: an incremental pass behind an SDRF edit recomputes about a hundred edges spread over a few hundred units
-// (tools/build_variant.sh dstats -DNC_DIRTY_STATS) on a thousand waves: it is as long as its longest unit, whose edges one wave
-// streams one after the other.  Units of 4 positions there (View::nc_fine): the class of 63-254 neighbours 178 -> 107 us, the
-// iteration 0.33 -> 0.26 ms (profiles/r05_incremental_lanes_ab.txt); one position per unit gains nothing more (101 us: the
-// floor is a near-empty persistent launch, 55 us).  Full passes keep 16 / 8: a table build per 4 edges costs them 10 %.
-#ifndef NC_LANES_FINE
-#define NC_LANES_FINE 4
-#endif
-__device__ inline int nc_lanes_rt(const View &g, int coarse) { return g.nc_fine ? (coarse < NC_LANES_FINE ? coarse : NC_LANES_FINE) : coarse; }
+// (Round 5 measured smaller units for the incremental pass behind an SDRF edit — about a hundred edges over a few hundred units,
+//  the pass as long as its longest unit: 4 positions per unit take the class of 63-254 neighbours from 178 to 107 us, one
+//  position to 101, profiles/r05_incremental_lanes_ab.txt — and then replaced the class kernels there by the edge-by-edge pass
+//  at the end of this file.)
 
 template <int SLOTS, int MODE>
 __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub, const unsigned *tab, unsigned *cnt,
@@ -559,7 +554,7 @@ __device__ inline void nc_chunk(const View &g, int u, int2 ru, int sub, int nsub
     int v = -1;
     int2 rv = make_int2(0, 0);
     bool own = false;
-    if (lane < nc_lanes_rt(g, nc_lanes_for_slots(SLOTS)) && p < ru.y) {
+    if (lane < nc_lanes_for_slots(SLOTS) && p < ru.y) {
         v = g.col[ru.x + p];
         if (v >= 0 && v < g.n && v != u) {
             rv = g.rowinfo[v];
@@ -683,11 +678,9 @@ __global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2
     // The unit list is dealt round-robin to NC_QUEUES queues, each with its own cursor on its own cache line: one
     // cursor for all waves saturates at ~90 dequeues per microsecond on MI355X and was 40 % of the pass.  A wave
     // starts on the queue of its workgroup (blockIdx % 8: workgroups that share an XCD) and moves on when it is empty.
-    // (fine units — a few hundred in all: two queues; a wave that finds nothing has made two dependent atomics, not eight)
-    const int nq = g.nc_fine ? 2 : NC_QUEUES;
-    for (int qi = 0; qi < nq; ++qi) {
-        const int q = (int)((blockIdx.x + qi) % nq);
-        const int count_q = total > q ? (total - q + nq - 1) / nq : 0;
+    for (int qi = 0; qi < NC_QUEUES; ++qi) {
+        const int q = (int)((blockIdx.x + qi) % NC_QUEUES);
+        const int count_q = total > q ? (total - q + NC_QUEUES - 1) / NC_QUEUES : 0;
         int32_t *cursor = next + q * NC_QUEUE_STRIDE;
         const int max_rounds = count_q / CHUNK + 2;
         for (int round = 0; round < max_rounds; ++round) {
@@ -697,7 +690,7 @@ __global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2
             if (first >= count_q || first < 0) break;
             const int last = first + CHUNK < count_q ? first + CHUNK : count_q;
             for (int t = first; t < last; ++t) {
-                const int it = q + t * nq;
+                const int it = q + t * NC_QUEUES;
                 const int2 un = units[it];
                 const int u = un.x, sub = un.y;
                 if (u < 0 || u >= g.n || sub < 0) {
@@ -706,8 +699,7 @@ __global__ void __launch_bounds__(256, NC_WAVE_OCC) k_nc_wave(View g, const int2
                 }
                 int2 ru = g.rowinfo[u];
                 if (!row_ok(g, ru, 16, u, it) || ru.y > SLOTS / 2 - 2) continue;  // the plan keeps the load <= 1/2
-                const int ln = nc_lanes_rt(g, nc_lanes_for_slots(SLOTS));
-                const int nsub = (ru.y + ln - 1) / ln;
+                const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
                 if (sub >= nsub) continue;
                 for (int i = lane; i < SLOTS; i += 64) tab[i] = NC_EMPTY;
                 if (lane == 0) sc->spilled = 0;
@@ -769,8 +761,7 @@ __device__ inline void nc_block_units(const View &g, const int2 *units, const in
             if (k >= 0) nc_insert<SLOTS>(tab, (unsigned)k, &sc_all[0].spilled);
         }
         __syncthreads();
-        const int ln = nc_lanes_rt(g, nc_lanes_for_slots(SLOTS));
-        const int nsub = (ru.y + ln - 1) / ln;
+        const int nsub = (ru.y + nc_lanes_for_slots(SLOTS) - 1) / nc_lanes_for_slots(SLOTS);
         const int sub = sub0 + wid;
         if (wid < W && sub < nsub)
             nc_chunk<SLOTS, MODE>(g, u, ru, sub, nsub, tab, cnt_base + wid * (SLOTS / 2), &sc_all[wid], &sc_all[0].spilled,
@@ -848,7 +839,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) k_nc_plan(View g, NcLists L, con
         if (d > 0 && d <= NC_MAXD && (!g.dirty || touch[u])) bkt = nc_bucket_of(d);
     }
     const int cls = bkt < 0 ? -1 : nc_bucket_class(bkt);
-    const int L_ = cls < 0 ? 16 : nc_lanes_rt(g, nc_lanes(cls));
+    const int L_ = cls < 0 ? 16 : nc_lanes(cls);
     const int nsub = (d + L_ - 1) / L_;
     // wave classes: one unit per sub-unit; block classes: one unit per group of W sub-units
     const int W = cls >= 2 ? nc_waves(cls) : 1;
@@ -932,8 +923,7 @@ __global__ void __launch_bounds__(256) k_nc_clear(DevResult *res, int32_t *queue
 
 static int ensure_nc(dcr_graph *g) {
     // units per class, from the smallest degree a member node can have and its sub-units (16 or 4 positions each)
-    // (class 0 with units of NC_LANES_FINE positions: at most d / 4 + 1 units per node; the other classes' bounds cover theirs)
-    const int64_t need[NC_CLASSES] = {std::max<int64_t>(g->n * 4, g->cap_total / NC_LANES_FINE + g->n) + 64, g->cap_total / 3 + 64, g->cap_total / 6 + 64,
+    const int64_t need[NC_CLASSES] = {g->n * 4 + 64, g->cap_total / 3 + 64, g->cap_total / 6 + 64,
                                       g->cap_total / 3 + 64, g->cap_total / 6 + 64};
     for (int c = 0; c < NC_CLASSES; ++c) {
         if (g->nc_cap[c] < need[c]) {
@@ -1002,7 +992,7 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
             g->num_cu = prop.multiProcessorCount;
     }
     View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr,
-            (int32_t)g->n, 1, nullptr, (incremental && g->pending_edits <= DIRTY_EDITS) ? 1 : 0};
+            (int32_t)g->n, 1, nullptr};
     static const bool want_trace = getenv("DCR_NC_TRACE") != nullptr;
     if (want_trace) {
         if (!g->nc_trace) DCR_TRY(dev_alloc(&g->nc_trace, NC_CLASSES * 16384 * 2));
@@ -1118,7 +1108,8 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
 // every listed edge a workgroup of four waves: the table of the owner's neighbours is built by all of them (one size, the
 // largest class's, for every owner), the two sweeps over the other endpoint's row are dealt to the waves in batches of 64
 // rows (the slot counters are LDS atomics, every statistic a sum or a maximum: nc_edge with its loops strided by the wave
-// index).  Same integers, same closing expression.  DCR_NC_FINE=0: the class kernels with units of NC_LANES_FINE positions.
+// index).  Same integers, same closing expression.  Measured: the pass 0.240 -> 0.076 ms, the iteration 0.375 -> 0.21 ms.
+// DCR_NC_FINE=0: the class kernels, as for a pass behind more (coarsely flagged) edits.
 constexpr int NCF_SLOTS = 16384;
 constexpr int NCF_W = 4;
 struct NcFineAcc {
@@ -1356,7 +1347,7 @@ static int run_nc_fine(dcr_graph *g, int curv_type) {
         g->nc_fine_cap = need;
     }
     if (!g->nc_queues) DCR_TRY(dev_alloc(&g->nc_queues, 2 * NC_QUEUES * NC_QUEUE_STRIDE));
-    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, g->dirty, (int32_t)g->n, 1, nullptr, 1};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, g->dirty, (int32_t)g->n, 1, nullptr};
     hipLaunchKernelGGL(k_nc_clear, dim3(1), dim3(256), 0, g->stream, g->dres, g->nc_queues, 0, (unsigned *)nullptr, (int64_t)0);
     const int64_t blocks = (g->cap_total + 255) / 256;
     if (blocks > 0)
@@ -1369,7 +1360,8 @@ static int run_nc_fine(dcr_graph *g, int curv_type) {
 }
 
 int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental) {
-    static const bool fine_on = !(getenv("DCR_NC_FINE") && atoi(getenv("DCR_NC_FINE")) == 0);
+    const char *fine_env = getenv("DCR_NC_FINE");   // (read per call: the tests run both routes in one process)
+    const bool fine_on = !(fine_env && atoi(fine_env) == 0);
     if (incremental && fine_on && g->pending_edits <= DIRTY_EDITS && !getenv("DCR_NC_TRACE")) {
         if (curv_type == DCR_CURV_BFC) return run_nc_fine<MODE_BFC>(g, curv_type);
         return run_nc_fine<MODE_TRI>(g, curv_type);

@@ -418,9 +418,13 @@ def test_bfc_cuda_call_surface(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ incremental mode
-def test_incremental_pass_equals_full(dcr, oracle):
-    """After arbitrary edits, an incremental pass leaves exactly the bits a full pass would."""
+@pytest.mark.parametrize('route,every', [('edges', 3), ('classes', 3), ('edges', 7)])
+def test_incremental_pass_equals_full(dcr, oracle, route, every, monkeypatch):
+    """After arbitrary edits, an incremental pass leaves exactly the bits a full pass would: behind at most three edits (exact
+    flags) by the edge-by-edge kernels of round 5 and, with DCR_NC_FINE=0, by the class kernels; behind more edits (coarse
+    flags) by the class kernels."""
     from dcr import synthetic
+    monkeypatch.setenv('DCR_NC_FINE', '1' if route == 'edges' else '0')
     ei, nn = synthetic.powerlaw_graph(800, 5, seed=13)
     G = dcr(ei, nn)
     C = oracle.CGraph(ei, nn)
@@ -434,7 +438,7 @@ def test_incremental_pass_equals_full(dcr, oracle):
             G.remove_edge(u, v); C.remove_edge(u, v)
         else:
             G.add_edge(u, v); C.add_edge(u, v)
-        if step % 3 == 0:
+        if step % every == 0:
             G.curvature_pass('bfc', incremental=True)
             eu, ev, cv = G.curvature_read()
             ou, ov, oc = C.curv_all('bfc', nthreads=8)
