@@ -1110,8 +1110,8 @@ static int run_nc(dcr_graph *g, int curv_type, bool incremental) {
 // rows (the slot counters are LDS atomics, every statistic a sum or a maximum: nc_edge with its loops strided by the wave
 // index).  Same integers, same closing expression.  Measured: the pass 0.240 -> 0.076 ms, the iteration 0.375 -> 0.21 ms.
 // DCR_NC_FINE=0: the class kernels, as for a pass behind more (coarsely flagged) edits.
-constexpr int NCF_SLOTS = 16384;
-constexpr int NCF_W = 4;
+constexpr int NCF_W = 4;   // (table sizes: 1,024 / 4,096 / 16,384 slots, the smallest that holds the graph's largest degree at half load —
+                           //  a hub-to-hub edit flags tens of thousands of edges, and a smaller table is more workgroups per CU)
 struct NcFineAcc {
     int T, posu, s1, gam, s2, spilled;
 };
@@ -1274,7 +1274,7 @@ __device__ inline NcEdge nc_edge_wg(const View &g, int u, int v, int2 rv, const 
     return out;
 }
 
-template <int MODE>
+template <int NCF_SLOTS, int MODE>
 __global__ void __launch_bounds__(64 * NCF_W) k_nc_fine_edges(View g, const int2 *list, const int32_t *count, int64_t cap, int curv_type,
                                                                double *curv) {
     __shared__ __attribute__((aligned(16))) unsigned tab[NCF_SLOTS];
@@ -1294,7 +1294,11 @@ __global__ void __launch_bounds__(64 * NCF_W) k_nc_fine_edges(View g, const int2
         int v = -1;
         if (ok) {
             ru = g.rowinfo[u];
-            ok = row_ok(g, ru, 22, u, e) && p < ru.y && ru.y <= NCF_SLOTS / 2 - 2;
+            ok = row_ok(g, ru, 22, u, e) && p < ru.y;
+            if (ok && ru.y > NCF_SLOTS / 2 - 2) {  // the host's bound on the largest degree picked this table: cannot happen; never skip silently
+                row_ok(g, make_int2(-1, ru.y), 24, u, e);
+                ok = false;
+            }
         }
         if (ok) {
             v = g.col[ru.x + p];
@@ -1353,8 +1357,15 @@ static int run_nc_fine(dcr_graph *g, int curv_type) {
     if (blocks > 0)
         hipLaunchKernelGGL(k_nc_fine_list, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, curv_type, g->curv, g->nc_fine_list,
                            g->nc_fine_cap, &g->dres->nc_count[0]);
-    hipLaunchKernelGGL((k_nc_fine_edges<MODE>), dim3((unsigned)g->num_cu), dim3(64 * NCF_W), 0, g->stream, vw, g->nc_fine_list,
-                       &g->dres->nc_count[0], g->nc_fine_cap, curv_type, g->curv);
+    // (max_deg_bound: the host's upper bound on every degree, raised by one per edit; owners have at most NC_MAXD neighbours)
+    const int64_t dmax = g->max_deg_bound < NC_MAXD ? g->max_deg_bound : NC_MAXD;
+#define DCR_NCF_LAUNCH(SLOTS_, PER_CU_)                                                                                          \
+    hipLaunchKernelGGL((k_nc_fine_edges<SLOTS_, MODE>), dim3((unsigned)(g->num_cu * (PER_CU_))), dim3(64 * NCF_W), 0, g->stream, vw, \
+                       g->nc_fine_list, &g->dres->nc_count[0], g->nc_fine_cap, curv_type, g->curv)
+    if (dmax <= 1024 / 2 - 2) DCR_NCF_LAUNCH(1024, 8);
+    else if (dmax <= 4096 / 2 - 2) DCR_NCF_LAUNCH(4096, 4);
+    else DCR_NCF_LAUNCH(16384, 1);
+#undef DCR_NCF_LAUNCH
     DCR_HIP(hipGetLastError());
     return DCR_OK;
 }
