@@ -2086,7 +2086,8 @@ bool h2_grow_pools(dcr_graph *g) {
 // (preferential attachment m = 2 / 5 / 10 / 20 at 2k-500k nodes, uniform random graphs of mean degree 6-20, grids, a dense
 // random graph; profiles/r04_engine_choice.txt) and the pass times (ms, MI355X) are, within 11-15 % on average,
 //     node-centric:  0.127 + 0.438e-6 E + 1.135e-9 E s + 0.201 min(dmax, 400) / 400
-//     two-hop:       0.190 + 1.193e-6 n + 4.498e-9 (sum d^2) (1 + 60 s / n)
+//     two-hop:       0.120 + 1.193e-6 n + 4.498e-9 (sum d^2) (1 + 60 s / n)          (0.190 until round 5)
+//     edge by edge:  0.012 + E (5.0e-6 + 4.2e-9 s)                                   (round 5, csrc/dcr_bfc_nc.hip)
 // with E edges, n nodes, s = sum d^2 / n (the mean size of a 2-hop neighbourhood), dmax the largest degree: the node-centric
 // engine streams about s entries per edge and loses a tenth of a millisecond to the tail of its hub units; the two-hop
 // engine reads sum d^2 entries per pass, pays per node, and slows down as neighbourhoods overlap (s / n: the share of the
@@ -2098,11 +2099,15 @@ bool h2_can_take(const dcr_graph *g, int curv_type, bool incremental) {
     if (g->pass_impl == 3) return true;
     if (g->pass_impl != 0 || g->n < 3000) return false;
     static const double max_share = getenv("DCR_H2_MAX_SHARE") ? atof(getenv("DCR_H2_MAX_SHARE")) : 0.045;
-    const double n = (double)g->n, E = (double)g->n_edges, sd2 = g->sum_deg2, s = sd2 / n, share = s / n;
+    const double n = (double)g->n, sd2 = g->sum_deg2, s = sd2 / n, share = s / n;
     if (share > max_share) return false;
-    const double dmax = (double)(g->max_deg_bound < 400 ? g->max_deg_bound : 400);
-    const double t_nc = 0.127 + 0.438e-6 * E + 1.135e-9 * E * s + 0.201 * dmax / 400.0;
-    const double t_h2 = 0.190 + 1.193e-6 * n + 4.498e-9 * sd2 * (1.0 + 60.0 * share);
+    // (round 5: the fixed cost of a two-hop pass went from 0.19 to about 0.10 ms with the three-stream layout — re-fitted, kept a
+    //  little above the measurements: on a 500 k-node graph of two edges per node the per-node cost is underestimated — and small
+    //  graphs have a third candidate, a workgroup per edge: nc_edges_full_ms)
+    static const bool edges_on = !(getenv("DCR_NC_FINE") && atoi(getenv("DCR_NC_FINE")) == 0);
+    const double t_nc = nc_class_full_ms(g);
+    const double t_h2 = 0.120 + 1.193e-6 * n + 4.498e-9 * sd2 * (1.0 + 60.0 * share);
+    if (edges_on && nc_edges_full_ms(g) < t_h2) return false;
     return t_h2 < t_nc;
 }
 

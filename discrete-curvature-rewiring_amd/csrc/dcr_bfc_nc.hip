@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(256) k_nc_fine_list(View g, int curv_type, dou
     if (s < ru.x || (int)(s - ru.x) >= ru.y || ru.y > NC_MAXD) return;
     const int v = g.col[s];
     if (v < 0 || v >= g.n || v == u) return;
-    if (!edge_dirty(g.dirty[u], g.dirty[v])) return;  // no edit can have changed it: the stored value is still exact
+    if (g.dirty && !edge_dirty(g.dirty[u], g.dirty[v])) return;  // no edit can have changed it: the stored value is still exact
     const int2 rv = g.rowinfo[v];
     if (!row_ok(g, rv, 12, v, u)) return;
     const bool bfc = curv_type == DCR_CURV_BFC;
@@ -1337,7 +1337,7 @@ __global__ void __launch_bounds__(64 * NCF_W) k_nc_fine_edges(View g, const int2
 }
 
 template <int MODE>
-static int run_nc_fine(dcr_graph *g, int curv_type) {
+static int run_nc_fine(dcr_graph *g, int curv_type, bool incremental) {
     if (g->num_cu <= 0) {
         g->num_cu = 256;
         hipDeviceProp_t prop;
@@ -1351,7 +1351,7 @@ static int run_nc_fine(dcr_graph *g, int curv_type) {
         g->nc_fine_cap = need;
     }
     if (!g->nc_queues) DCR_TRY(dev_alloc(&g->nc_queues, 2 * NC_QUEUES * NC_QUEUE_STRIDE));
-    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, g->dirty, (int32_t)g->n, 1, nullptr};
+    View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr, (int32_t)g->n, 1, nullptr};
     hipLaunchKernelGGL(k_nc_clear, dim3(1), dim3(256), 0, g->stream, g->dres, g->nc_queues, 0, (unsigned *)nullptr, (int64_t)0);
     const int64_t blocks = (g->cap_total + 255) / 256;
     if (blocks > 0)
@@ -1370,12 +1370,40 @@ static int run_nc_fine(dcr_graph *g, int curv_type) {
     return DCR_OK;
 }
 
+// Estimates of a full Balanced Forman pass, milliseconds on one MI355X (fitted on 31 graphs of four families, tools/probe_engine_choice.py;
+// E edges, s = sum d^2 / n the mean size of a 2-hop neighbourhood, dmax the largest degree): the class kernels of this file (round 4's
+// model, unchanged) and the edge-by-edge kernels — a workgroup per edge costs its chain of dependent reads plus what it streams.
+double nc_class_full_ms(const dcr_graph *g) {
+    const double n = (double)(g->n > 0 ? g->n : 1), E = (double)g->n_edges, s = g->sum_deg2 / n;
+    const double dmax = (double)(g->max_deg_bound < 400 ? g->max_deg_bound : 400);
+    return 0.127 + 0.438e-6 * E + 1.135e-9 * E * s + 0.201 * dmax / 400.0;
+}
+double nc_edges_full_ms(const dcr_graph *g) {
+    const double n = (double)(g->n > 0 ? g->n : 1), E = (double)g->n_edges, s = g->sum_deg2 / n;
+    return 0.012 + E * (5.0e-6 + 4.2e-9 * s);
+}
+
 int launch_curvature_pass_nc(dcr_graph *g, int curv_type, bool incremental) {
     const char *fine_env = getenv("DCR_NC_FINE");   // (read per call: the tests run both routes in one process)
     const bool fine_on = !(fine_env && atoi(fine_env) == 0);
     if (incremental && fine_on && g->pending_edits <= DIRTY_EDITS && !getenv("DCR_NC_TRACE")) {
-        if (curv_type == DCR_CURV_BFC) return run_nc_fine<MODE_BFC>(g, curv_type);
-        return run_nc_fine<MODE_TRI>(g, curv_type);
+        if (curv_type == DCR_CURV_BFC) return run_nc_fine<MODE_BFC>(g, curv_type, true);
+        return run_nc_fine<MODE_TRI>(g, curv_type, true);
+    }
+    // A FULL pass of a small graph, edge by edge too: the class kernels are launch-bound there (plans, four persistent grids and
+    // their joins: 0.17-0.4 ms whatever the graph holds), a workgroup per edge is not — Cora's size (5 k edges) 0.19 -> 0.04 ms,
+    // 25 k edges 0.31 -> 0.17, break-even near 50 k edges (profiles/r05_engine_choice.txt).  Taken when its estimate is the
+    // lowest (nc_edges_full_ms against the two models of h2_can_take; automatic engine choice only: DCR_PASS=nc keeps the class
+    // kernels); DCR_NC_FINE_FULL=<slots> forces it for graphs of at most that many adjacency slots (A/B aid).
+    bool full_edges = false;
+    if (!incremental && fine_on && !getenv("DCR_NC_TRACE")) {
+        const char *full_env = getenv("DCR_NC_FINE_FULL");
+        if (full_env) full_edges = g->cap_total <= atoll(full_env);
+        else full_edges = g->pass_impl == 0 && nc_edges_full_ms(g) < nc_class_full_ms(g);
+    }
+    if (full_edges) {
+        if (curv_type == DCR_CURV_BFC) return run_nc_fine<MODE_BFC>(g, curv_type, false);
+        return run_nc_fine<MODE_TRI>(g, curv_type, false);
     }
     if (curv_type == DCR_CURV_BFC) return run_nc<MODE_BFC>(g, curv_type, incremental);
     return run_nc<MODE_TRI>(g, curv_type, incremental);

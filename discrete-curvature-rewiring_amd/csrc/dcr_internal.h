@@ -340,6 +340,8 @@ int launch_argext(dcr_graph *g, int want_max, int excl_u, int excl_v, hipStream_
 // the same from the per-block extrema of the last two-hop pass (g->ext_part_valid), without sweeping the edges again
 int launch_argext_from_parts(dcr_graph *g, int want_max, hipStream_t st = nullptr);
 int launch_argext_both(dcr_graph *g, hipStream_t st = nullptr, bool clear_dirty = false);
+double nc_class_full_ms(const dcr_graph *g);   // estimates of a full pass (csrc/dcr_bfc_nc.hip): class kernels / a workgroup per edge
+double nc_edges_full_ms(const dcr_graph *g);
 // reductions of per-workgroup partial results shared by the GCN kernels (csrc/dcr_gemm.hip, csrc/dcr_gcn.hip)
 void launch_slab_reduce(const float *part, float *C, int64_t mn, int N, int64_t ldc, int splits, hipStream_t st);
 void launch_slab_reduce_cols(const float *part, float *C, int64_t mn, int N, int ncols, int64_t ldc, int splits, hipStream_t st);

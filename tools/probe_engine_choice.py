@@ -1,6 +1,7 @@
 """Which engine the automatic choice (csrc/dcr_bfc_h2.hip: h2_can_take) picks for a full Balanced Forman pass, against both
 engines forced, on several graph families (timing only; parity on such families is tests/fuzz_parity.py).
--> one line per graph: n, E, sum d^2 / n^2, largest degree, node-centric ms, two-hop ms, chosen engine, chosen / better.
+-> one line per graph: n, E, sum d^2 / n^2, largest degree, node-centric ms, two-hop ms, edge-by-edge ms (graphs up to 400k edges), the
+automatic choice and its time / the best of the three.
 usage (GPU box): python tools/probe_engine_choice.py > gpurun_out/r04_engine_choice.txt"""
 import os, sys
 import numpy as np
@@ -11,7 +12,11 @@ from dcr.graph import DcrGraph
 
 
 def timed(ei, n, mode, reps):
-    if mode:
+    os.environ.pop('DCR_NC_FINE_FULL', None)
+    if mode == 'edges':      # the edge-by-edge kernels of round 5 forced for the full pass
+        os.environ['DCR_PASS'] = 'nc'
+        os.environ['DCR_NC_FINE_FULL'] = str(1 << 40)
+    elif mode:
         os.environ['DCR_PASS'] = mode
     else:
         os.environ.pop('DCR_PASS', None)
@@ -33,12 +38,12 @@ def run(name, ei, n):
     reps = 20 if E < 300000 else 8
     nc, _ = timed(ei, n, 'nc', reps)
     h2, e2 = timed(ei, n, 'h2', reps)
+    ed = timed(ei, n, 'edges', reps)[0] if E <= 400000 else float('inf')
     auto, ea = timed(ei, n, None, reps)
-    best = min(nc, h2)
-    chosen = h2 if ea == 'two-hop' else nc
+    best = min(nc, h2, ed)
     print(f'{name:38s} n={n:8d} E={E:9d} sum d^2/n^2={float((deg ** 2).sum()) / n / n:9.5f} sum d^2/n={float((deg ** 2).sum()) / n:9.1f} '
-          f'max deg {int(deg.max()):6d} | node-centric {nc:8.3f} ms  two-hop {h2:8.3f} ms ({e2}) | chosen {ea:12s} {auto:8.3f} ms '
-          f'| chosen / better {chosen / best:5.2f}', flush=True)
+          f'max deg {int(deg.max()):6d} | node-centric {nc:8.3f} ms  two-hop {h2:8.3f} ms ({e2})  edge by edge {ed:8.3f} ms | chosen {ea:12s} {auto:8.3f} ms '
+          f'| chosen / best {auto / best:5.2f}', flush=True)
 
 
 rng = np.random.Generator(np.random.PCG64(3))
