@@ -596,6 +596,34 @@ def main():
                 'edges_after': int(run5.G.number_of_edges()),
                 'note': 'BASELINE.json configs[2]: S100k, full Balanced Forman pass + SDRF, 500 iterations in one run'}
         run5 = None
+    # BASELINE.json configs[1]'s shape: a Cora-sized graph (2,485 nodes, 4,966 edges; Cora's tau and bound,
+    # utils/hyperparams.py:2-9), full recompute per iteration — a pass this small runs edge by edge (csrc/dcr_bfc_nc.hip)
+    cora_sdrf = None
+    if rank == 0 and not args.no_config2:
+        try:
+            ei_c, n_c = synthetic.powerlaw_graph(2485, 2, seed=12345)
+            run_c = SdrfRun(Data(edge_index=torch.from_numpy(ei_c), num_nodes=n_c), 'bfc', True, 0.95, 163.0, device=local_rank)
+            np.random.seed(0)
+            for _ in range(8):
+                run_c.step()
+            run_c.G.profile_reset()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            n_cs = 0
+            for _ in range(200):
+                n_cs += 1
+                if not run_c.step():
+                    break
+            torch.cuda.synchronize()
+            tc = time.perf_counter() - tc
+            pms, pcnt = run_c.G.profile_read()
+            cora_sdrf = {'value': n_cs / tc, 'unit': 'iterations/sec', 'ms_per_step': tc / n_cs * 1e3, 'bfc_pass_ms': pms / max(pcnt, 1),
+                         'nodes': int(n_c), 'edges': int(ei_c.shape[1] // 2), 'steps': n_cs,
+                         'note': "BASELINE.json configs[1]'s shape (Cora-sized synthetic graph, Cora's tau / removal bound): full "
+                                 'Balanced Forman recompute per iteration; the pass runs a workgroup per edge at this size'}
+            run_c = None
+        except Exception as e:   # a side figure must not cost the line
+            cora_sdrf = {'error': repr(e)}
     # tau = inf: the deterministic variant of SURVEY.md 8(d) (utils/softmax.py:5-8: one-hot at the first arg-max; the
     # improvements stay on the device, the draw consumes one uniform)
     tinf = None
@@ -830,6 +858,8 @@ def main():
                 out['sdrf_kernels_us'] = {kk: vv for kk, vv in k.items() if kk.startswith(('k_imp', 'k_argext', 'k_add', 'k_remove', 'k_pick'))}
         if cfg2 is not None:
             out['config2_500_iterations'] = cfg2
+        if cora_sdrf is not None:
+            out['sdrf_cora_shape'] = cora_sdrf
     # The side legs must not cost the headline line: a failure is recorded in their place, and a leg that does not come
     # back (a collective waiting for a rank that died) is cut off by a timer on every rank: rank 0 prints the line it has,
     # all ranks leave.  (The multi-GPU GCN leg has only ever run on one MI355X in the build environment.)

@@ -1,4 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-echo "== edge by edge where its estimate wins (default)"; timeout -k 10 200 python3 tools/probe_small_sdrf.py 2>&1 | grep -v amdgpu
-echo "== class kernels (DCR_NC_FINE=0)"; DCR_NC_FINE=0 timeout -k 10 200 python3 tools/probe_small_sdrf.py 2>&1 | grep -v amdgpu
+python bench.py --steps 20 --warmup 5 --no-gcn --no-cpu-baseline 2>/dev/null | python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print(d['value'], d['ms_per_step'], d['bfc_pass_ms'], d['outside_pass_ms'])
+        print(json.dumps(d.get('sdrf_cora_shape')))
+        print(json.dumps(d.get('incremental_mode')))
+"
