@@ -8,7 +8,7 @@ import torch
 from dcr import synthetic
 from dcr.data import Data
 from rewiring import sdrf_no_cuda as S
-ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+ei, n = synthetic.powerlaw_graph(int(os.environ.get("N", 100000)), int(os.environ.get("M", 10)), seed=12345)
 K = int(os.environ.get('K', 200))
 np.random.seed(0)
 run = S.SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0, incremental=True)

@@ -7,7 +7,7 @@ import torch
 from dcr import synthetic
 from dcr.data import Data
 from rewiring import sdrf_no_cuda as S
-ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
+ei, n = synthetic.powerlaw_graph(int(os.environ.get("N", 100000)), int(os.environ.get("M", 10)), seed=12345)
 inc = os.environ.get('INC', '0') == '1'
 K = int(os.environ.get('K', 60))
 for mode in ('1', '0', '1', '0'):
