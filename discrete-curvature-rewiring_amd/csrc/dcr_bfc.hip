@@ -777,6 +777,13 @@ extern "C" {
 
 static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incremental, bool with_argmin = false);
 
+// the per-node flags of the incremental pass and, with them, the list of flagged nodes (DevResult::touched_n: whoever zeroes the
+// flags resets the list — a node is appended when its byte leaves zero)
+static void clear_dirty_flags(dcr_graph *g) {
+    (void)hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream);
+    (void)hipMemsetAsync(&g->dres->touched_n, 0, sizeof(int32_t), g->stream);
+}
+
 int dcr_curvature_pass(dcr_graph *g, int curv_type) { return curvature_pass_impl(g, curv_type, false); }
 
 int dcr_curvature_pass_incremental(dcr_graph *g, int curv_type) { return curvature_pass_impl(g, curv_type, true); }
@@ -809,7 +816,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
         //  the stale arg-max of the removal step then is a 5 us reduction as behind the two-hop pass; DCR_ARGEXT_BOTH=0: two sweeps)
         static const bool both = !(getenv("DCR_ARGEXT_BOTH") && atoi(getenv("DCR_ARGEXT_BOTH")) == 0);
         if (!g->ext_part_valid && both) DCR_TRY(launch_argext_both(g, nullptr, dirty_clear_pending));
-        else if (dirty_clear_pending) DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+        else if (dirty_clear_pending) clear_dirty_flags(g);
         dirty_clear_pending = false;
         return g->ext_part_valid ? launch_argext_from_parts(g, 0) : launch_argext(g, 0, -1, -1);
     };
@@ -822,7 +829,7 @@ static int curvature_pass_impl(dcr_graph *g, int curv_type, bool want_incrementa
     // (the two-hop launch zeroes the flags in its first kernel: one fill launch less at the tail of every pass)
     if (!(g->last_engine == 0 && g->h2_cleared_dirty)) {
         if (with_argmin) dirty_clear_pending = true;
-        else DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(g->n > 0 ? g->n : 1), g->stream));
+        else clear_dirty_flags(g);
     }
     g->dirty_tracked = true;
     g->pending_edits = 0;

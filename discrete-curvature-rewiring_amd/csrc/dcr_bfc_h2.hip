@@ -1932,6 +1932,7 @@ __global__ void __launch_bounds__(256) k_h2_clear(DevResult *res, int32_t *weigh
     //  tail of every pass before)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_dirty_words; i += (int64_t)gridDim.x * 256) dirty_words[i] = 0u;
     if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0 && n_dirty_words > 0) res->touched_n = 0;   // (the list of flagged nodes goes with the flags)
     if (threadIdx.x < 8) res->misc[threadIdx.x] = 0;
     if (threadIdx.x < H2_NB) {
         res->h2_bucket[threadIdx.x] = 0;

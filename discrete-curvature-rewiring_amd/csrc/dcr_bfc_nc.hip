@@ -1138,6 +1138,44 @@ __global__ void __launch_bounds__(256) k_nc_fine_list(View g, int curv_type, dou
     if (idx >= 0 && idx < cap) list[idx] = make_int2(u, (int)(s - ru.x));
 }
 
+// The same list from the rows of the FLAGGED nodes (the touched list the edit kernels keep: every node whose dirty byte left zero
+// since the flags were cleared, csrc/dcr_graph.hip) — a wave per node.  A flagged edge has both endpoints flagged (an edited
+// node's neighbours carry its A or B bit), so its owner's row is among them.  Used for graphs of 4 M slots and more (S1M: the
+// sweep's 141 us -> 45 us; on S100k the sweep's 11 us are less than this kernel's chain of dependent reads).
+__global__ void __launch_bounds__(256) k_nc_fine_list_rows(View g, int curv_type, double *curv, const int32_t *touched, int64_t tcap,
+                                                           const DevResult *res, int2 *list, int64_t cap, int32_t *count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nt = res->touched_n;
+    if (nt < 0 || nt > tcap) {  // uniform: more appends than nodes — some clearing of the flags did not reset the list
+        row_ok(g, make_int2(-1, (int)nt), 25, 0, 0);
+        return;
+    }
+    const bool bfc = curv_type == DCR_CURV_BFC;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < nt; t += (int64_t)gridDim.x * 4) {
+        const int u = touched[t];
+        if (u < 0 || u >= g.n) continue;
+        const int2 ru = g.rowinfo[u];
+        if (!row_ok(g, ru, 26, u, (int)t) || ru.y > NC_MAXD) continue;
+        const unsigned du = g.dirty[u];
+        for (int base = 0; base < ru.y; base += 64) {
+            const int p = base + lane;
+            if (p >= ru.y) continue;
+            const int v = g.col[ru.x + p];
+            if (v < 0 || v >= g.n || v == u) continue;
+            if (!edge_dirty(du, g.dirty[v])) continue;
+            const int2 rv = g.rowinfo[v];
+            if (!row_ok(g, rv, 12, v, u)) continue;
+            if (!(rv.y > 0 && nc_owns(u, ru.y, v, rv.y, bfc))) continue;
+            if (bfc && (ru.y < rv.y ? ru.y : rv.y) == 1 && u < v) {  // bfc_naive.py:18-19
+                curv[ru.x + p] = 0.0;
+                continue;
+            }
+            const int idx = atomicAdd(count, 1);
+            if (idx >= 0 && idx < cap) list[idx] = make_int2(u, p);
+        }
+    }
+}
+
 // nc_edge by the NCF_W waves of a workgroup: `tab` (N(u)), `cnt` and `acc` are the workgroup's, `sc` this wave's
 template <int SLOTS, int MODE>
 __device__ inline NcEdge nc_edge_wg(const View &g, int u, int v, int2 rv, const unsigned *tab, unsigned *cnt, NcScratch *sc,
@@ -1353,8 +1391,16 @@ static int run_nc_fine(dcr_graph *g, int curv_type, bool incremental) {
     if (!g->nc_queues) DCR_TRY(dev_alloc(&g->nc_queues, 2 * NC_QUEUES * NC_QUEUE_STRIDE));
     View vw{g->rowinfo, g->col, g->slot_row, g->cap_total, g->dres->misc, incremental ? g->dirty : nullptr, (int32_t)g->n, 1, nullptr};
     hipLaunchKernelGGL(k_nc_clear, dim3(1), dim3(256), 0, g->stream, g->dres, g->nc_queues, 0, (unsigned *)nullptr, (int64_t)0);
+    // (the sweep over every slot costs 11 us per 2.6 M slots, the rows of the flagged nodes a chain of five dependent reads, 14 us
+    //  whatever the graph's size: S100k 0.203 / 0.208 ms per iteration sweep / rows, S1M 0.540 / 0.452 — by rows from 4 M slots;
+    //  DCR_NC_FINE_SWEEP=1 / 0 forces one: A/B aid)
+    const char *sweep_env = getenv("DCR_NC_FINE_SWEEP");
+    const bool by_rows = sweep_env ? atoi(sweep_env) == 0 : g->cap_total >= 4000000;
     const int64_t blocks = (g->cap_total + 255) / 256;
-    if (blocks > 0)
+    if (incremental && by_rows && g->touched)
+        hipLaunchKernelGGL(k_nc_fine_list_rows, dim3((unsigned)(2 * g->num_cu)), dim3(256), 0, g->stream, vw, curv_type, g->curv, g->touched,
+                           (int64_t)g->n, g->dres, g->nc_fine_list, g->nc_fine_cap, &g->dres->nc_count[0]);
+    else if (blocks > 0)
         hipLaunchKernelGGL(k_nc_fine_list, dim3((unsigned)blocks), dim3(256), 0, g->stream, vw, curv_type, g->curv, g->nc_fine_list,
                            g->nc_fine_cap, &g->dres->nc_count[0]);
     // (max_deg_bound: the host's upper bound on every degree, raised by one per edit; owners have at most NC_MAXD neighbours)

@@ -163,40 +163,47 @@ __global__ void __launch_bounds__(64) k_remove_if_above(int2 *rowinfo, int32_t *
 // Incremental curvature: the per-node flags behind edge_dirty() (dcr_bfc_common.h).  Edit number `edit` (0..2) of the
 // edge {u,v}: endpoint flag on u and v, bit A on the members of N(u), bit B on those of N(v); later edits: the coarse
 // flag on all of them.  A node can be in both rows, so the bytes are OR-ed atomically (through their 32-bit words).
-__device__ inline void dirty_or(uint8_t *dirty, int k, unsigned bits) {
-    atomicOr(reinterpret_cast<unsigned *>(dirty) + (k >> 2), bits << ((k & 3) * 8));
+// (round 5) ... and a node whose byte goes from zero to non-zero is put on the touched list: the incremental pass lists its edges
+// from the rows of those nodes instead of sweeping every adjacency slot for flags (0.14 ms of a 0.53 ms iteration at 1M nodes)
+__device__ inline void dirty_or_touch(uint8_t *dirty, int k, unsigned bits, int32_t *touched, int32_t cap, DevResult *res) {
+    const unsigned sh = (unsigned)(k & 3) * 8u;
+    const unsigned old = atomicOr(reinterpret_cast<unsigned *>(dirty) + (k >> 2), bits << sh);
+    if (((old >> sh) & 0xFFu) == 0u) {
+        const int idx = atomicAdd(&res->touched_n, 1);
+        if (idx >= 0 && idx < cap) touched[idx] = k;   // (each node at most once between two clears: never more than n)
+    }
 }
 __device__ inline void dev_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u, int32_t v,
-                                      int edit, int tid, int nthreads) {
+                                      int edit, int tid, int nthreads, int32_t *touched, int32_t tcap, DevResult *tres) {
     if (u < 0 || v < 0) return;
     const bool exact = edit >= 0 && edit < dcr::DIRTY_EDITS;
     const unsigned bit_u = exact ? 1u << (2 * edit) : dcr::DIRTY_COARSE, bit_v = exact ? 2u << (2 * edit) : dcr::DIRTY_COARSE;
     const unsigned bit_end = exact ? dcr::DIRTY_ENDPOINT : dcr::DIRTY_COARSE;
     const int2 ru = rowinfo[u], rv = rowinfo[v];
-    for (int i = tid; i < ru.y; i += nthreads) dirty_or(dirty, col[ru.x + i], bit_u);
-    for (int i = tid; i < rv.y; i += nthreads) dirty_or(dirty, col[rv.x + i], bit_v);
+    for (int i = tid; i < ru.y; i += nthreads) dirty_or_touch(dirty, col[ru.x + i], bit_u, touched, tcap, tres);
+    for (int i = tid; i < rv.y; i += nthreads) dirty_or_touch(dirty, col[rv.x + i], bit_v, touched, tcap, tres);
     if (tid == 0) {
-        dirty_or(dirty, u, bit_end);
-        dirty_or(dirty, v, bit_end);
+        dirty_or_touch(dirty, u, bit_end, touched, tcap, tres);
+        dirty_or_touch(dirty, v, bit_end, touched, tcap, tres);
     }
 }
 
 __global__ void __launch_bounds__(256) k_mark_dirty(const int2 *rowinfo, const int32_t *col, uint8_t *dirty, int32_t u,
-                                                     int32_t v, int edit, const DevResult *res) {
+                                                     int32_t v, int edit, DevResult *res, int32_t *touched, int32_t tcap) {
     if (u == -2) {
         if (res->draw_status != 0) return;
         u = res->cand_i;
         v = res->cand_j;
     }
-    dev_mark_dirty(rowinfo, col, dirty, u, v, edit, threadIdx.x, blockDim.x);
+    dev_mark_dirty(rowinfo, col, dirty, u, v, edit, threadIdx.x, blockDim.x, touched, tcap, res);
 }
 
 // the edge the tail is about to remove (it is only known on the device)
 __global__ void __launch_bounds__(256) k_mark_dirty_ext(const int2 *rowinfo, const int32_t *col, uint8_t *dirty,
-                                                         const DevResult *res, double bound, int edit) {
+                                                         DevResult *res, double bound, int edit, int32_t *touched, int32_t tcap) {
     if (res->add_status == 1 || res->add_status == 3) return;
     if (res->ext_slot >= 0 && res->ext_val > bound)
-        dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit, threadIdx.x, blockDim.x);
+        dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit, threadIdx.x, blockDim.x, touched, tcap, res);
 }
 
 // The whole tail of an SDRF iteration as ONE launch when the stale arg-max is already in the result block (sdrf_no_cuda.py:51,
@@ -204,7 +211,7 @@ __global__ void __launch_bounds__(256) k_mark_dirty_ext(const int2 *rowinfo, con
 // arg-max edge iff above the bound.  Four launches of one or four waves each cost their launch gaps, not their work.
 __global__ void __launch_bounds__(256) k_sdrf_tail(int2 *rowinfo, const int32_t *rowcap, int32_t *col, double *curv, uint8_t *dirty,
                                                     DevResult *res, int32_t u, int32_t v, int edit_add, int do_remove, double bound,
-                                                    int edit_rem) {
+                                                    int edit_rem, int32_t *touched, int32_t tcap) {
     const int tid = threadIdx.x;
     if (tid < 64) dev_add_edge(rowinfo, rowcap, col, u, v, res, tid);
     __threadfence_block();   // (one workgroup: its waves share the CU's cache, nothing has to reach the L2 before the barrier;
@@ -216,12 +223,12 @@ __global__ void __launch_bounds__(256) k_sdrf_tail(int2 *rowinfo, const int32_t 
         au = res->cand_i;
         av = res->cand_j;
     }
-    if (mark) dev_mark_dirty(rowinfo, col, dirty, au, av, edit_add, tid, 256);
+    if (mark) dev_mark_dirty(rowinfo, col, dirty, au, av, edit_add, tid, 256, touched, tcap, res);
     if (!do_remove) return;
     const int st_add = res->add_status;
     if (st_add == 1 || st_add == 3) return;  // (uniform) add overflowed: replayed after a re-layout / no draw
     const bool doit = res->ext_slot >= 0 && res->ext_val > bound;
-    if (doit) dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit_rem, tid, 256);
+    if (doit) dev_mark_dirty(rowinfo, col, dirty, res->ext_u, res->ext_v, edit_rem, tid, 256, touched, tcap, res);
     __threadfence_block();
     __syncthreads();
     if (tid >= 64) return;
@@ -284,7 +291,7 @@ void launch_sdrf_tail(dcr_graph *g, int32_t u, int32_t v, int edit_add, int do_r
     g->h2_eset_pending += 2;
     g->ext_part_valid = false;
     hipLaunchKernelGGL(k_sdrf_tail, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->rowcap, g->col, g->curv, g->dirty, g->dres, u, v,
-                       edit_add, do_remove, bound, edit_rem);
+                       edit_add, do_remove, bound, edit_rem, g->touched, (int32_t)g->n);
 }
 
 void launch_remove_if_above(dcr_graph *g, double bound, int edit) {
@@ -292,13 +299,14 @@ void launch_remove_if_above(dcr_graph *g, double bound, int edit) {
     g->ext_part_valid = false;
     // flag the neighbourhood while the edge is still there, then remove it
     hipLaunchKernelGGL(k_mark_dirty_ext, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, g->dres, bound,
-                       edit);
+                       edit, g->touched, (int32_t)g->n);
     hipLaunchKernelGGL(k_remove_if_above, dim3(1), dim3(64), 0, g->stream, g->rowinfo, g->col, g->curv, g->dres, bound);
 }
 
 void launch_mark_dirty(dcr_graph *g, int32_t u, int32_t v, int edit) {
     if (u != -2 && (u < 0 || v < 0)) return;
-    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v, edit, g->dres);
+    hipLaunchKernelGGL(k_mark_dirty, dim3(1), dim3(256), 0, g->stream, g->rowinfo, g->col, g->dirty, u, v, edit, g->dres, g->touched,
+                       (int32_t)g->n);
 }
 
 int sync_result(dcr_graph *g) {
@@ -476,6 +484,7 @@ int dcr_graph_create(int device, int64_t n, int64_t m, const int64_t *src, const
     DCR_TRY(dev_alloc(&g->draw_bsum, 256));
     DCR_TRY(dev_alloc(&g->dirty, n + 4));  // OR-ed through 32-bit words
     DCR_HIP(hipMemsetAsync(g->dirty, 0, (size_t)(n > 0 ? n : 1), g->stream));
+    DCR_TRY(dev_alloc(&g->touched, n + 64));
     DCR_HIP(hipHostMalloc((void **)&g->hres, sizeof(DevResult), hipHostMallocDefault));
     std::memset(g->hres, 0, sizeof(DevResult));
     DCR_HIP(hipMemsetAsync(g->dres, 0, sizeof(DevResult), g->stream));
@@ -501,7 +510,7 @@ int dcr_graph_destroy(dcr_graph *g) {
                         g->imp_table, g->imp_posx, g->imp_posy, g->imp_c1, g->imp_c2, g->imp_b, g->imp_c,
                         g->imp_rowcount, g->imp_rowoff, g->imp_adjbits, g->imp_out, g->imp_ci, g->imp_cj,
                         g->imp_stats, g->draw_bsum, g->dres, g->dirty, g->nc_units[0], g->nc_units[1], g->nc_units[2],
-                        g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_fine_list, g->nc_trace, g->nc_queues, g->giant_list,
+                        g->nc_units[3], g->nc_units[4], g->nc_touch, g->nc_fine_list, g->touched, g->nc_trace, g->nc_queues, g->giant_list,
                         g->giant_pos, g->giant_cnt, g->giant_acc, g->hub_list, g->hub_cnt, g->h2_weight,
                         g->h2_units[0], g->h2_units[1], g->h2_units[2], g->h2_units[3], g->h2_units[4], g->h2_retry, g->h2_task, g->h2_cand, g->h2_part, g->h2_bloom,
                         g->h2_rec, g->h2_eset, g->ext_part, g->h2_lists};

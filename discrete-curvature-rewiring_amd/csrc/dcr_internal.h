@@ -86,6 +86,8 @@ struct DevResult {
     // its own and rebuilds the set).  Written by dev_add_edge / dev_remove_edge, consumed by k_h2_eset_apply.
     int32_t edit_n;
     int32_t edit_log[3 * 8];
+    int32_t touched_n;  // nodes on the graph's touched list (every node whose dirty byte went from zero to non-zero since the flags
+                        // were last cleared: dev_mark_dirty appends, whoever clears the flags resets this)
     int32_t h2_retry;   // units on the retry list (nodes whose tables filled up in their class, redone by the largest class)
     int32_t h2_status;  // 0 ok; 1: a table filled up or a list overflowed (the pass is then redone by the node-centric kernels);
                         // 2: the triangle step's pools were too small (run again with larger ones); 3: the pass was launched
@@ -221,6 +223,7 @@ struct dcr_graph {
     int64_t nc_touch_cap = 0;
     int2 *nc_fine_list = nullptr;  // incremental pass behind a few exactly flagged edits: the edges to recompute {owner, position}
     int64_t nc_fine_cap = 0;
+    int32_t *touched = nullptr;    // [n + 64] the flagged nodes, each once (DevResult::touched_n of them)
     double sum_deg2 = 0.0;        // sum of squared degrees when the graph was created (engine choice: size of the 2-hop neighbourhoods)
     int32_t max_deg_bound = 0;    // host-side upper bound on the largest degree (exact after create / relayout)
     int pass_impl = 0;            // 0: automatic (default: two-hop kernels for full Balanced Forman passes of graphs large enough to

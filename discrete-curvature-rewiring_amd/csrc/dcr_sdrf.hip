@@ -94,10 +94,11 @@ __global__ void __launch_bounds__(256) k_argext_edges(RowView g, int64_t cap_tot
 // (round 5: clear_words — the incremental pass's node flags, which nothing reads between the pass and this sweep: their fill
 //  launch rode in front of it before)
 __global__ void __launch_bounds__(256) k_argext_edges_both(RowView g, int64_t cap_total, const double *curv, Ext *part_min, Ext *part_max,
-                                                            unsigned *clear_words, int64_t n_clear_words) {
+                                                            unsigned *clear_words, int64_t n_clear_words, DevResult *res) {
     __shared__ double shv[4];
     __shared__ int shs[4];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_clear_words; i += (int64_t)gridDim.x * blockDim.x) clear_words[i] = 0u;
+    if (n_clear_words > 0 && blockIdx.x == 0 && threadIdx.x == 0) res->touched_n = 0;   // (the list of flagged nodes goes with the flags)
     double lo_v = 0.0, hi_v = 0.0;
     int lo_s = -1, hi_s = -1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -223,7 +224,7 @@ int launch_argext_both(dcr_graph *g, hipStream_t st, bool clear_dirty) {
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_argext_edges_both, dim3((unsigned)blocks), dim3(256), 0, st, vw, g->cap_total, g->curv, (Ext *)g->ext_part,
                        (Ext *)g->ext_part + EXT_PART_BLOCKS, reinterpret_cast<unsigned *>(g->dirty),
-                       clear_dirty ? (int64_t)(g->n + 3) / 4 : (int64_t)0);   // (the flags hold n + 4 bytes)
+                       clear_dirty ? (int64_t)(g->n + 3) / 4 : (int64_t)0, g->dres);   // (the flags hold n + 4 bytes)
     DCR_HIP(hipGetLastError());
     g->ext_part_n = (int)blocks;
     g->ext_part_valid = true;

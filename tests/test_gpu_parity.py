@@ -418,13 +418,15 @@ def test_bfc_cuda_call_surface(oracle):
 
 
 # ------------------------------------------------------------------------------------------------ incremental mode
-@pytest.mark.parametrize('route,every', [('edges', 3), ('classes', 3), ('edges', 7)])
+@pytest.mark.parametrize('route,every', [('edges', 3), ('rows', 3), ('classes', 3), ('edges', 7)])
 def test_incremental_pass_equals_full(dcr, oracle, route, every, monkeypatch):
     """After arbitrary edits, an incremental pass leaves exactly the bits a full pass would: behind at most three edits (exact
-    flags) by the edge-by-edge kernels of round 5 and, with DCR_NC_FINE=0, by the class kernels; behind more edits (coarse
+    flags) by the edge-by-edge kernels of round 5 — their edge list from a sweep over the slots or from the rows of the flagged
+    nodes (the touched list, large graphs' default) — and, with DCR_NC_FINE=0, by the class kernels; behind more edits (coarse
     flags) by the class kernels."""
     from dcr import synthetic
-    monkeypatch.setenv('DCR_NC_FINE', '1' if route == 'edges' else '0')
+    monkeypatch.setenv('DCR_NC_FINE', '0' if route == 'classes' else '1')
+    monkeypatch.setenv('DCR_NC_FINE_SWEEP', '0' if route == 'rows' else '1')   # the edge list from the flagged nodes' rows / a sweep
     ei, nn = synthetic.powerlaw_graph(800, 5, seed=13)
     G = dcr(ei, nn)
     C = oracle.CGraph(ei, nn)
