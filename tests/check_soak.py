@@ -1,7 +1,7 @@
 """GPU-box checker: a long SDRF run on the north-star graph, full recompute against the incremental pass, final edge lists
 compared, and compared again with the list of a run whose draws are all made on the host; then the final graph's full pass
 against the C oracle on sampled edges.  tests/test_checkers_gpu.py runs it with
-200 iterations; the long version: ITERS=3000 python tests/check_soak.py"""
+200 iterations; the long version: ITERS=3000 python tests/check_soak.py (BOUND=-1.19 TAU=180: with removals)"""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +13,13 @@ from oracle import c_oracle
 from rewiring.sdrf_no_cuda import SdrfRun
 
 
-def run(iters=3000, samples=20000):
+def run(iters=3000, samples=20000, tau=163.0, bound=0.95):
+    """tau, bound: BASELINE's configs[2] by default; bound=-1.19, tau=180 removes an edge in most iterations (tests/golden/sdrf_s100k_removal_oracle.json)"""
     ei, n = synthetic.powerlaw_graph(100000, 10, seed=12345)
     out = {}
     for inc in (False, True):
         np.random.seed(0)
-        run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0, incremental=inc)
+        run = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, bound, tau, incremental=inc)
         t = time.time()
         done = 0
         for _ in range(iters):
@@ -36,7 +37,7 @@ def run(iters=3000, samples=20000):
     os.environ['DCR_DEVICE_DRAW'] = '0'
     try:
         np.random.seed(0)
-        run_h = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, 0.95, 163.0)
+        run_h = SdrfRun(Data(edge_index=torch.from_numpy(ei), num_nodes=n), 'bfc', True, bound, tau)
     finally:
         os.environ.pop('DCR_DEVICE_DRAW', None)
     t = time.time()
@@ -56,4 +57,4 @@ def run(iters=3000, samples=20000):
 
 
 if __name__ == '__main__':
-    run(int(os.environ.get('ITERS', 3000)))
+    run(int(os.environ.get('ITERS', 3000)), tau=float(os.environ.get('TAU', 163.0)), bound=float(os.environ.get('BOUND', 0.95)))
