@@ -1752,10 +1752,15 @@ __device__ inline int h2_probe_partners(const H2EdgeSet es, int w, const int32_t
 __global__ void __launch_bounds__(256) k_h2_triangles(H2EdgeSet es, H2Tasks tk, uint4 *rec, const int32_t *status, int second) {
     const int cand_now = *tk.n_cand;  // (stable: the kernels that list into this pool are through)
     const int first = second ? *tk.n_done : 0;
-    const int total = cand_now;
+    // Round 5 (found by the randomised sweep, one pass in ~1,500 on a graph whose pools had just been grown to what the pass before
+    // had counted): the counter advances by whole CHUNKS, so it can pass the end of the pool although every reservation fitted —
+    // no status is raised then (h2_pool_reserve fails only when c0 + nc exceeds the pool) and nothing lies beyond the pool.  This
+    // kernel used to take "counter beyond the pool" for a failed pass and return: a pass that was NOT run again lost every
+    // correction of this launch.  A reservation that did not fit has set the status, which is checked right below.
+    const int total = cand_now < tk.cand_cap ? cand_now : (int)tk.cand_cap;
     if (!second && blockIdx.x == 0 && threadIdx.x == 0) *tk.n_done = cand_now;  // read by the retry stage's launch only
     if (*status != 0) return;
-    if (total <= first || first < 0 || total > tk.cand_cap) return;  // (beyond the pool: the pass is run again with larger pools)
+    if (total <= first || first < 0) return;
     const int lane = threadIdx.x & 63;
     for (int64_t base = first + (((int64_t)blockIdx.x * 256 + threadIdx.x) & ~63ll); base < total; base += (int64_t)gridDim.x * 256) {
         const int64_t i = base + lane;
@@ -2255,6 +2260,20 @@ static void h2_print_unit_times(dcr_graph *g) {
 }
 #endif
 
+// DCR_H2_DEBUG: the counters of the pass just enqueued (synchronises)
+static int h2_debug_print(dcr_graph *g) {
+    DevResult h;
+    DCR_HIP(hipStreamSynchronize(g->stream));
+    DCR_HIP(hipMemcpy(&h, g->dres, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[h2] units per class %d %d %d %d %d, retry units %d (stage %s), status %d, failed per class %d %d %d %d %d retry %d\n",
+            h.h2_count[0], h.h2_count[1], h.h2_count[2], h.h2_count[3], h.h2_count[4], h.h2_retry, g->h2_expect_retry ? "on" : "off", h.h2_status,
+            h.h2_failed[0], h.h2_failed[1], h.h2_failed[2], h.h2_failed[3], h.h2_failed[4], h.h2_failed[5]);
+    fprintf(stderr, "[h2] triangle step: split class + retry %d tasks, %d candidates, %d partners; class M %d, %d, %d (pool slots, chunk tails "
+            "included; pools of %lld %lld %lld each)\n", h.h2_ntask[0], h.h2_ncand[0], h.h2_npart[0], h.h2_ntask[1], h.h2_ncand[1], h.h2_npart[1],
+            (long long)g->h2_task_cap / 2, (long long)g->h2_cand_cap / 2, (long long)g->h2_part_cap / 2);
+    return DCR_OK;
+}
+
 int launch_curvature_pass_h2(dcr_graph *g) {
     if (g->num_cu <= 0) {
         g->num_cu = 256;
@@ -2396,6 +2415,7 @@ int launch_curvature_pass_h2(dcr_graph *g) {
 #ifdef H2_UNIT_TIMES
         h2_print_unit_times(g);
 #endif
+        if (getenv("DCR_H2_DEBUG")) DCR_TRY(h2_debug_print(g));
         return DCR_OK;
     }
     // Streams: the block classes (long units; the triangle step waits for them only) on two high-priority streams, the
@@ -2526,17 +2546,7 @@ int launch_curvature_pass_h2(dcr_graph *g) {
         DCR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(h2_prof), z, sizeof(z)));
     }
 #endif
-    if (debug) {
-        DevResult h;
-        DCR_HIP(hipStreamSynchronize(g->stream));
-        DCR_HIP(hipMemcpy(&h, g->dres, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[h2] units per class %d %d %d %d %d, retry units %d, status %d, failed per class %d %d %d %d %d retry %d\n",
-                h.h2_count[0], h.h2_count[1], h.h2_count[2], h.h2_count[3], h.h2_count[4], h.h2_retry, h.h2_status, h.h2_failed[0],
-                h.h2_failed[1], h.h2_failed[2], h.h2_failed[3], h.h2_failed[4], h.h2_failed[5]);
-        fprintf(stderr, "[h2] triangle step: split class + retry %d tasks, %d candidates, %d partners; class M %d, %d, %d (pool slots, chunk tails "
-                "included; pools of %lld %lld %lld each)\n", h.h2_ntask[0], h.h2_ncand[0], h.h2_npart[0], h.h2_ntask[1], h.h2_ncand[1], h.h2_npart[1],
-                (long long)g->h2_task_cap / 2, (long long)g->h2_cand_cap / 2, (long long)g->h2_part_cap / 2);
-    }
+    if (debug) DCR_TRY(h2_debug_print(g));
     return DCR_OK;
 }
 

@@ -180,3 +180,23 @@ def test_dense_neighbourhoods_are_redone_one_class_up(h2graph):
     from dcr import synthetic
     ei, n = synthetic.powerlaw_graph(2500, 10, seed=11)
     _check_against_oracle(h2graph(ei, n), ei, n)
+
+
+def test_pools_grown_to_their_limit_lose_no_corrections(h2graph):
+    """Round 5 (found by tests/fuzz_parity.py, one pass in ~1,500): on this graph the two-hop pass outgrows its triangle-step pools,
+    is run again with pools grown to what it had counted, then once more with its retry stage — and the candidate counter,
+    which advances by whole chunks, ends within a few chunks of the grown pool's size, above it in one fresh pass in forty
+    although every reservation fitted.  k_h2_triangles took that for a failed pass and returned; no status was raised, the pass
+    was not run again, and a third of the edges lost their corrections.  120 fresh graphs (98 % to meet the case before the fix),
+    every pass against the C oracle (bfc_naive.py:25-40)."""
+    from dcr import synthetic
+    from oracle import c_oracle
+    ei, n = synthetic.powerlaw_graph(2997, 11, seed=210271642)
+    oc = c_oracle.CGraph(ei, n).curv_all('bfc', nthreads=8)[2]
+    for rep in range(120):
+        G = h2graph(ei, n)
+        cv = G.curvature_all('bfc')[2]
+        assert G.pass_engine() == 'two-hop'
+        bad = np.flatnonzero(cv != oc)
+        assert bad.size == 0, (rep, bad.size, bad[:5])
+        G.close()

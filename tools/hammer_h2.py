@@ -1,0 +1,43 @@
+"""A graph of the randomised sweep (tests/fuzz_parity.py, seed 1, graph 70: preferential attachment, 2,997 nodes, 32,846 edges,
+largest degree 314) on which ONE two-hop pass in ~1,500 came out wrong in round 5: the same pass repeated, every result compared
+with the first one (and the first with the C oracle).  REPS, FRESH=1 (a new graph object per pass) from the environment."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, 'discrete-curvature-rewiring_amd'), os.path.join(REPO, 'tests')]
+import numpy as np
+import fuzz_parity as F
+from dcr.graph import DcrGraph
+from oracle import c_oracle
+
+want_n, want_shape = int(os.environ.get('GRAPH_N', 2997)), int(os.environ.get('GRAPH_COLS', 65692))
+rng = np.random.Generator(np.random.PCG64(1))
+while True:
+    ei, n = F.random_graph(rng, 0.04)
+    if ei.shape[1] == 0:
+        continue
+    if n == want_n and ei.shape[1] == want_shape:
+        break
+    for step in range(12):
+        rng.integers(0, n, 2)
+    if ei.shape[1] >= 4 and n <= 1500:
+        rng.integers(0, 4); rng.choice([float('inf'), 5.0, 50.0, 163.0]); rng.choice([0.0, 0.5, 0.95, 3.0])
+        rng.integers(1 << 20); rng.integers(1, 25); rng.integers(0, 2); rng.integers(0, 2)
+os.environ.setdefault('DCR_PASS', 'h2')
+C = c_oracle.CGraph(ei, n)
+oc = C.curv_all('bfc', nthreads=8)[2]
+reps, fresh = int(os.environ.get('REPS', 300)), os.environ.get('FRESH', '0') == '1'
+G = DcrGraph(ei, n)
+bad_runs = 0
+for r in range(reps):
+    if fresh and r:
+        G.close()
+        G = DcrGraph(ei, n)
+    cv = G.curvature_all('bfc')[2]
+    bad = np.nonzero(cv != oc)[0]
+    if bad.size:
+        bad_runs += 1
+        eu, ev = G.curvature_read()[:2]
+        if bad_runs <= 3:
+            print(f'run {r}: {bad.size} edges differ, engine {G.pass_engine()}, first: {[(int(eu[i]), int(ev[i]), float(cv[i]), float(oc[i])) for i in bad[:4]]}', flush=True)
+print(f'{bad_runs} of {reps} passes differ from the oracle (fresh={fresh}, layout={os.environ.get("DCR_H2_LAYOUT", "default")}, '
+      f'serial={os.environ.get("DCR_SERIAL_BINS", "0")})', flush=True)
