@@ -1,7 +1,8 @@
 #!/bin/bash
-# round 5: the randomised parity sweep (tests/fuzz_parity.py) on the final sources — default routes, then the incremental pass's
-# edge list taken from the flagged nodes' rows (large graphs' route) forced on every graph
+# round 5: the randomised parity sweep (tests/fuzz_parity.py) on the final sources with other seeds than the test suite's
+# (progress goes straight to a file under gpurun_out/: a pipe into tail looks like a hung run to the box's watchdog)
 cd $GRAFT_REPO_ROOT
-SECONDS_BUDGET=420 timeout -k 10 700 python3 tests/fuzz_parity.py 2>&1 | tail -1 | tee gpurun_out/r05_fuzz.txt
-DCR_NC_FINE_SWEEP=0 SECONDS_BUDGET=200 timeout -k 10 500 python3 tests/fuzz_parity.py 2>&1 | tail -1 | tee -a gpurun_out/r05_fuzz.txt
-DCR_NC_FINE_FULL=1000000000 SECONDS_BUDGET=150 timeout -k 10 500 python3 tests/fuzz_parity.py 2>&1 | tail -1 | tee -a gpurun_out/r05_fuzz.txt
+SEED=2 SECONDS_BUDGET=360 timeout -k 10 600 python3 tests/fuzz_parity.py > gpurun_out/r05_fuzz_seed2.txt 2>&1
+tail -1 gpurun_out/r05_fuzz_seed2.txt
+SEED=3 HUB_PROB=0.12 SECONDS_BUDGET=300 timeout -k 10 600 python3 tests/fuzz_parity.py > gpurun_out/r05_fuzz_seed3.txt 2>&1
+tail -1 gpurun_out/r05_fuzz_seed3.txt
