@@ -2,7 +2,7 @@
 three curvature-pass engines (node-centric, edge-centric, two-hop), the incremental pass, SDRF runs with random parameters,
 hubs beyond the LDS tables and the bfc_cuda compatibility mode against the oracles (which are pinned to the reference's own
 outputs: curvature/bfc_naive.py:7-40, rewiring/sdrf_no_cuda.py:22-66, curvature/bfc_cuda.py, rewiring/sdrf_cuda_bfc.py).
-The long versions stay runnable as scripts (tests/fuzz_parity.py, fuzz_bfc_cuda.py, check_soak.py, check_hub_sdrf.py)."""
+The long versions stay runnable as scripts (tests/fuzz_parity.py, fuzz_engines.py, fuzz_bfc_cuda.py, check_soak.py, check_hub_sdrf.py)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +27,13 @@ def test_hub_graph_through_every_engine():
     import fuzz_parity
     graphs, values, runs = fuzz_parity.run(seed=3, seconds=240.0, graphs=1, engines=('nc', 'edge', 'h2'), hub_prob=1.0, verbose=False)
     assert graphs == 1 and values > 0
+
+
+def test_engines_agree_on_medium_graphs():
+    """tests/fuzz_engines.py with a small budget: graphs of 5 k - 150 k nodes through the two-hop kernels, the node-centric class
+    kernels and the edge-by-edge kernels (round 5) — the same bits — and an incremental pass behind three edits at the hubs."""
+    import fuzz_engines
+    assert fuzz_engines.run(seed=4, seconds=12.0) >= 5
 
 
 def test_soak_200_iterations_incremental_equals_full():
