@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -15,7 +16,7 @@ void set_error(const std::string &msg);
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
-            ::dcr::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+            ::dcr::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + (strrchr(__FILE__, '/') ? strrchr(__FILE__, '/') + 1 : __FILE__) + ":" + std::to_string(__LINE__) + ")"); \
             return DCR_EHIP;                                                                   \
         }                                                                                      \
     } while (0)
